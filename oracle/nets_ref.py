@@ -1,0 +1,250 @@
+"""CPU oracle: the three BBH networks and their train steps, restated on top of keras_ref.py.
+
+TEST INFRASTRUCTURE ONLY (see keras_ref.py header).  PARITY UNPINNED against real Keras/TF.
+
+Follows /root/reference/BBH_version/bbhMahoGANy.py:
+  generator_model              :212-295
+  signal_pe_model (2-branch)   :356-404
+  signal_discriminator_model   :408-498 (active branch num_lays=2: :439-453, :491-495)
+  MyLayer / compositions       :164-188, :500-539
+  compile / frozen-D semantics :797-809, :1100-1119
+  CNN train step               :1153-1168
+  GAN iteration                :1241-1299
+
+Layer specs are tuples; parameters live in flat python lists of numpy arrays so a test can copy the
+very same arrays into the HIP-backed model.
+"""
+import numpy as np
+from . import keras_ref as K
+
+
+# ----------------------------------------------------------------------------------------------
+# layer specs
+# ----------------------------------------------------------------------------------------------
+def generator_spec(n_pix):
+    L = [('dense', 100, 256 * (n_pix // 2)), ('bn', 256 * (n_pix // 2)), ('act', 'tanh', 0.0), ('drop', 0.2),
+         ('reshape', (n_pix // 2, 256)),
+         ('up', 2), ('conv1d', 256, 64, 5, 2, 'same'), ('bn', 64), ('act', 'tanh', 0.0), ('drop', 0.2),
+         ('up', 2), ('conv1d', 64, 128, 5, 1, 'same'), ('bn', 128), ('act', 'tanh', 0.0), ('drop', 0.2)]
+    for cin, cout in ((128, 256), (256, 512), (512, 1024)):
+        L += [('conv1d', cin, cout, 5, 1, 'same'), ('bn', cout), ('act', 'tanh', 0.0), ('drop', 0.2)]
+    L += [('conv1d', 1024, 1, 5, 1, 'same'), ('act', 'linear', 0.0)]
+    return L
+
+
+def discriminator_spec(n_pix):
+    return [('conv2d', 1, 256, (5, 5), (2, 1), 'same'), ('act', 'leaky', 0.2), ('drop', 0.4),
+            ('conv2d', 256, 512, (5, 5), (2, 1), 'same'), ('act', 'leaky', 0.2), ('drop', 0.4),
+            ('flatten',), ('dense', (n_pix // 4) * 2 * 512, 1), ('act', 'sigmoid', 0.0)]
+
+
+def pe_branch_specs(n_pix):
+    mc = [('conv1d', 1, 64, 5, 2, 'same'), ('act', 'relu', 0.0)]
+    L = K.conv_out_len(n_pix, 5, 2, 'same')
+    for cin, cout in ((64, 128), (128, 256), (256, 512)):
+        mc += [('conv1d', cin, cout, 5, 2, 'valid'), ('act', 'relu', 0.0)]
+        L = K.conv_out_len(L, 5, 2, 'valid')
+    mc += [('flatten',), ('dense', L * 512, 1), ('act', 'relu', 0.0)]
+    q = [('conv1d', 1, 64, 5, 1, 'same'), ('act', 'relu', 0.0)]
+    L = n_pix
+    for cin, cout, s in ((64, 128, 1), (128, 256, 1), (256, 512, 2), (512, 1024, 2)):
+        q += [('conv1d', cin, cout, 5, s, 'valid'), ('act', 'relu', 0.0)]
+        L = K.conv_out_len(L, 5, s, 'valid')
+    q += [('flatten',), ('dense', L * 1024, 1), ('act', 'relu_max', 1.0)]
+    return mc, q
+
+
+# ----------------------------------------------------------------------------------------------
+# a sequential stack with explicit forward/backward
+# ----------------------------------------------------------------------------------------------
+class Stack(object):
+    """Parameters: self.params = list of arrays in keras weight order per layer
+    (conv/dense: kernel, bias; bn: gamma, beta [+ moving_mean, moving_var in self.state])."""
+
+    def __init__(self, spec, rng=None, dtype=np.float64):
+        self.spec = spec
+        self.dtype = dtype
+        self.params = []          # trainable, in order
+        self.pidx = []            # per layer: indices into params
+        self.state = {}           # layer index -> [moving_mean, moving_var]
+        rng = rng or np.random.RandomState(0)
+        for li, s in enumerate(spec):
+            idx = []
+            if s[0] == 'dense':
+                idx = self._add(K.glorot_uniform(rng, (s[1], s[2]), dtype), np.zeros(s[2], dtype))
+            elif s[0] == 'conv1d':
+                idx = self._add(K.glorot_uniform(rng, (s[3], s[1], s[2]), dtype), np.zeros(s[2], dtype))
+            elif s[0] == 'conv2d':
+                idx = self._add(K.glorot_uniform(rng, (s[3][0], s[3][1], s[1], s[2]), dtype), np.zeros(s[2], dtype))
+            elif s[0] == 'bn':
+                idx = self._add(np.ones(s[1], dtype), np.zeros(s[1], dtype))
+                self.state[li] = [np.zeros(s[1], dtype), np.ones(s[1], dtype)]
+            self.pidx.append(idx)
+
+    def _add(self, *arrs):
+        i0 = len(self.params)
+        self.params.extend(arrs)
+        return list(range(i0, i0 + len(arrs)))
+
+    def forward(self, x, training, masks=None, momentum=0.99, update_moving=True):
+        """masks: dict layer-index -> keep mask for dropout layers (training only)."""
+        self.tape = []
+        for li, s in enumerate(self.spec):
+            p = [self.params[i] for i in self.pidx[li]]
+            kind = s[0]
+            if kind == 'dense':
+                self.tape.append(x); x = K.dense_fwd(x, p[0], p[1])
+            elif kind == 'conv1d':
+                self.tape.append(x); x = K.conv1d_fwd(x, p[0], p[1], s[4], s[5])
+            elif kind == 'conv2d':
+                self.tape.append(x); x = K.conv2d_fwd(x, p[0], p[1], s[4], s[5])
+            elif kind == 'bn':
+                if training:
+                    y, cache, mean, var = K.bn_train_fwd(x, p[0], p[1])
+                    if update_moving:
+                        n = x.size // x.shape[-1]
+                        self.state[li] = list(K.bn_moving_update(self.state[li][0], self.state[li][1], mean, var, n, momentum))
+                    self.tape.append(cache); x = y
+                else:
+                    self.tape.append(None)
+                    x = K.bn_infer_fwd(x, p[0], p[1], self.state[li][0], self.state[li][1])
+            elif kind == 'act':
+                x = K.act_fwd(x, s[1], s[2]); self.tape.append(x)
+            elif kind == 'drop':
+                if training:
+                    m = masks[li]
+                    self.tape.append(m); x = K.dropout_fwd(x, m, s[1])
+                else:
+                    self.tape.append(None)
+            elif kind == 'reshape':
+                self.tape.append(x.shape); x = x.reshape((x.shape[0],) + tuple(s[1]))
+            elif kind == 'flatten':
+                self.tape.append(x.shape); x = x.reshape(x.shape[0], -1)
+            elif kind == 'up':
+                self.tape.append(None); x = K.upsample1d_fwd(x, s[1])
+            else:
+                raise ValueError(kind)
+        return x
+
+    def backward(self, dy):
+        """Returns (dx, grads) with grads aligned to self.params (None where untouched)."""
+        grads = [None] * len(self.params)
+        for li in range(len(self.spec) - 1, -1, -1):
+            s = self.spec[li]; t = self.tape[li]
+            p = [self.params[i] for i in self.pidx[li]]
+            kind = s[0]
+            if kind == 'dense':
+                dy, dW, db = K.dense_bwd(t, p[0], dy)
+                grads[self.pidx[li][0]], grads[self.pidx[li][1]] = dW, db
+            elif kind == 'conv1d':
+                dy, dW, db = K.conv1d_bwd(t, p[0], dy, s[4], s[5])
+                grads[self.pidx[li][0]], grads[self.pidx[li][1]] = dW, db
+            elif kind == 'conv2d':
+                dy, dW, db = K.conv2d_bwd(t, p[0], dy, s[4], s[5])
+                grads[self.pidx[li][0]], grads[self.pidx[li][1]] = dW, db
+            elif kind == 'bn':
+                dy, dg, dbt = K.bn_train_bwd(dy, t, p[0])
+                grads[self.pidx[li][0]], grads[self.pidx[li][1]] = dg, dbt
+            elif kind == 'act':
+                dy = K.act_bwd(dy, t, s[1], s[2])
+            elif kind == 'drop':
+                if t is not None:
+                    dy = dy * t / (1.0 - s[1])
+            elif kind in ('reshape', 'flatten'):
+                dy = dy.reshape(t)
+            elif kind == 'up':
+                dy = K.upsample1d_bwd(dy, s[1])
+        return dy, grads
+
+
+class AdamState(object):
+    """One keras optimizer instance: own t, m, v for the parameter list it was compiled with."""
+
+    def __init__(self, params, lr=9e-5, b1=0.5):
+        self.lr, self.b1, self.t = lr, b1, 0
+        self.m = [np.zeros_like(p) for p in params]
+        self.v = [np.zeros_like(p) for p in params]
+
+    def step(self, params, grads):
+        self.t += 1
+        for i, (p, g) in enumerate(zip(params, grads)):
+            p_new, self.m[i], self.v[i] = K.adam_step(p, g, self.m[i], self.v[i], self.t, self.lr, self.b1)
+            params[i][...] = p_new
+
+
+# ----------------------------------------------------------------------------------------------
+# CNN point-estimator train step  (bbhMahoGANy.py:1165: train_on_batch(x, [mc, q]))
+# ----------------------------------------------------------------------------------------------
+class PENet(object):
+    def __init__(self, n_pix, rng=None, dtype=np.float64):
+        rng = rng or np.random.RandomState(1)
+        mc, q = pe_branch_specs(n_pix)
+        self.mc, self.q = Stack(mc, rng, dtype), Stack(q, rng, dtype)
+        self.opt = AdamState(self.mc.params + self.q.params)
+
+    def predict(self, x):
+        return [self.mc.forward(x, False), self.q.forward(x, False)]
+
+    def train_on_batch(self, x, y_mc, y_q):
+        """Returns [total, mc_loss, q_loss, mc_acc, q_acc] (keras multi-output order)."""
+        y_mc = np.asarray(y_mc, x.dtype).reshape(-1, 1); y_q = np.asarray(y_q, x.dtype).reshape(-1, 1)
+        pm = self.mc.forward(x, True); pq = self.q.forward(x, True)
+        lm, dm = K.mse_loss(pm, y_mc); lq, dq = K.mse_loss(pq, y_q)
+        out = [lm + lq, lm, lq, K.binary_accuracy(pm, y_mc), K.binary_accuracy(pq, y_q)]
+        _, gm = self.mc.backward(dm); _, gq = self.q.backward(dq)
+        self.last_grads = gm + gq
+        self.opt.step(self.mc.params + self.q.params, gm + gq)
+        return out
+
+
+# ----------------------------------------------------------------------------------------------
+# GAN: generator G, discriminator D, combined G -> MyLayer(event) -> D(frozen)
+# ----------------------------------------------------------------------------------------------
+class GAN(object):
+    def __init__(self, n_pix, event, rng=None, dtype=np.float64):
+        rng = rng or np.random.RandomState(2)
+        self.n_pix = n_pix
+        self.G = Stack(generator_spec(n_pix), rng, dtype)
+        self.D = Stack(discriminator_spec(n_pix), rng, dtype)
+        self.event = np.asarray(event, dtype).reshape(n_pix, 1)
+        self.opt_g = AdamState(self.G.params)      # signal_discriminator_on_generator (:1107), D frozen
+        self.opt_d = AdamState(self.D.params)      # signal_discriminator (:1115)
+
+    def generate(self, z):
+        """generator.predict: inference phase (moving-stat BN, no dropout)."""
+        return self.G.forward(z, False)
+
+    def d_train_on_batch(self, sX, sy, masks):
+        sy = np.asarray(sy, sX.dtype).reshape(-1, 1)
+        p = self.D.forward(sX, True, masks)
+        loss, dp = K.bce_loss(p, sy)
+        _, g = self.D.backward(dp)
+        self.last_d_grads = g
+        self.opt_d.step(self.D.params, g)
+        return [loss, K.binary_accuracy(p, sy)]
+
+    def g_train_on_batch(self, z, sy, g_masks, d_masks):
+        """combined model: learning phase 1 for the whole graph (G batch-stat BN + dropout, D dropout active),
+        gradients only into G (D collected as frozen at compile time)."""
+        sy = np.asarray(sy, z.dtype).reshape(-1, 1)
+        x = self.G.forward(z, True, g_masks)
+        img = K.mylayer_fwd(x, self.event)
+        p = self.D.forward(img, True, d_masks)
+        loss, dp = K.bce_loss(p, sy)
+        dimg, _ = self.D.backward(dp)
+        dx = K.mylayer_bwd(dimg)
+        _, g = self.G.backward(dx)
+        self.last_g_grads = g
+        self.opt_g.step(self.G.params, g)
+        return [loss, K.binary_accuracy(p, sy)]
+
+    def assemble_d_batch(self, real, noise, fake):
+        """bbhMahoGANy.py:1268-1289.  real (B,n), noise (B,n,1) ~ N(0,1), fake (B,n,1) = G.predict(z).
+        Fake half is in REVERSED sample order (np.append prepend at :1271)."""
+        B = real.shape[0]
+        resid = self.event[None] - fake
+        fake2 = np.concatenate([fake, resid], axis=2)[::-1]
+        real2 = np.concatenate([real.reshape(B, self.n_pix, 1), noise], axis=2)
+        sX = np.concatenate([real2, fake2]).reshape(2 * B, self.n_pix, 2, 1)
+        sy = [1.0] * B + [0.0] * B
+        return sX, sy
