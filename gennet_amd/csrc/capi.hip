@@ -1,0 +1,407 @@
+// extern "C" surface of libgennet_hip.so (see include/gennet_hip.h).  Argument checking, tap-table construction and
+// kernel-family dispatch live here; no torch types, no allocation, no synchronisation.
+#include <stdarg.h>
+#include <mutex>
+#include <vector>
+#include "common.h"
+
+namespace gn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return GN_ELAUNCH;
+  }
+  return GN_OK;
+}
+
+// ---- profiling: HIP events around the MFMA launches, on the stream they are launched on ------------------
+struct ProfRec {
+  hipEvent_t a, b;
+  double flop;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_pool;
+static hipEvent_t g_cur;
+static std::mutex g_prof_mu;
+
+static hipEvent_t get_event() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void prof_begin(hipStream_t s) {
+  if (!g_prof_on) return;
+  g_cur = get_event();
+  (void)hipEventRecord(g_cur, s);
+}
+
+void prof_end(hipStream_t s, double flop) {
+  if (!g_prof_on) return;
+  hipEvent_t b = get_event();
+  (void)hipEventRecord(b, s);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof.push_back({g_cur, b, flop});
+}
+
+static void fwd_taps(ConvTaps* t, int k, int stride, int pad_left) {
+  t->ntaps = k;
+  t->in_stride = stride;
+  for (int j = 0; j < k; ++j) {
+    t->off[j] = j - pad_left;
+    t->widx[j] = j;
+  }
+  t->out_stride = 1;
+  t->out_off = 0;
+}
+
+static int conv_dispatch(const ConvArgs& a, hipStream_t s) {
+  if (a.Cin <= 4) return conv_smallcin_dispatch(a, s);
+  if (a.Cout <= 4) return conv_smallcout_dispatch(a, s);
+  return conv_mfma_dispatch(a, s);
+}
+
+// small C (< 4 or not a multiple of 4) column sums: fp64 block partials + fp64 atomics
+__global__ void colsum_anyc_kernel(const float* __restrict__ x, double* __restrict__ acc, size_t n, int C) {
+  double s[4] = {0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int c = (int)(i % C);
+    const double v = (double)x[i];
+    s[0] += c == 0 ? v : 0.0; s[1] += c == 1 ? v : 0.0; s[2] += c == 2 ? v : 0.0; s[3] += c == 3 ? v : 0.0;
+  }
+  __shared__ double red[4][256];
+  for (int c = 0; c < 4; ++c) red[c][threadIdx.x] = s[c];
+  __syncthreads();
+  for (int sft = 128; sft >= 1; sft >>= 1) {
+    if (threadIdx.x < sft)
+      for (int c = 0; c < 4; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x < C) atomicAdd(&acc[threadIdx.x], red[threadIdx.x][0]);
+}
+__global__ void f64_to_f32_small_kernel(const double* __restrict__ a, float* __restrict__ o, int n) {
+  if ((int)threadIdx.x < n) o[threadIdx.x] = (float)a[threadIdx.x];
+}
+
+// db[c] = sum over rows of dy[row, c]; ws needs colred_workspace_bytes(rows, C) (C % 4 == 0) or 32 bytes otherwise
+static int bias_grad(const float* dy, float* db, size_t rows, int C, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (C % 4 == 0) {
+    ColRedArgs r = {};
+    r.a = dy; r.rows = rows; r.C = C;
+    return colred_run(0, r, ws, ws_bytes, nullptr, db, s);
+  }
+  if (C > 4) { set_error("bias_grad: C %d unsupported", C); return GN_EINVAL; }
+  if (ws_bytes < 32) { set_error("bias_grad: workspace too small"); return GN_EWORKSPACE; }
+  (void)hipMemsetAsync(ws, 0, 32, s);
+  size_t g = (rows * C + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(colsum_anyc_kernel, dim3((unsigned)g), dim3(256), 0, s, dy, (double*)ws, rows * C, C);
+  hipLaunchKernelGGL(f64_to_f32_small_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, db, C);
+  return check_launch("bias_grad");
+}
+
+static size_t bias_grad_ws(size_t rows, int C) { return C % 4 == 0 ? colred_workspace_bytes(rows, C) : 32; }
+
+}  // namespace gn
+
+using namespace gn;
+
+extern "C" {
+
+const char* gn_last_error(void) { return g_err; }
+int gn_version(void) { return 100; }
+
+int gn_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return GN_OK;
+}
+int gn_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof) {
+    g_pool.push_back(r.a);
+    g_pool.push_back(r.b);
+  }
+  g_prof.clear();
+  return GN_OK;
+}
+int gn_prof_collect(double* out) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double ms = 0, flop = 0;
+  for (auto& r : g_prof) {
+    if (hipEventSynchronize(r.b) != hipSuccess) { set_error("prof: event sync failed"); return GN_ELAUNCH; }
+    float t = 0;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) { set_error("prof: elapsed failed"); return GN_ELAUNCH; }
+    ms += t;
+    flop += r.flop;
+  }
+  out[0] = (double)g_prof.size();
+  out[1] = ms;
+  out[2] = flop;
+  return GN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+int gn_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout,
+                  int act, float act_param, void* stream) {
+  GN_REQUIRE(x && w && y, "conv1d_fwd: null pointer");
+  GN_REQUIRE(B >= 0 && L > 0 && Cin > 0 && Cout > 0 && k >= 1 && k <= 8 && stride >= 1 && Lout > 0, "conv1d_fwd: bad shape");
+  GN_REQUIRE(pad_left >= 0 && stride * (Lout - 1) + k - pad_left <= L + k, "conv1d_fwd: Lout %d inconsistent with L %d k %d stride %d", Lout, L, k, stride);
+  if (B == 0) return GN_OK;
+  ConvArgs a = {};
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.B = B; a.Lin = L; a.Cin = Cin; a.Cout = Cout; a.M = Lout; a.Ly = Lout;
+  fwd_taps(&a.t, k, stride, pad_left);
+  a.act = act; a.act_param = act_param;
+  return conv_dispatch(a, (hipStream_t)stream);
+}
+
+int gn_conv1d_transpose_w(const float* w, float* wt, int k, int Cin, int Cout, void* stream) {
+  GN_REQUIRE(w && wt && k >= 1 && Cin > 0 && Cout > 0, "transpose_w: bad arguments");
+  return transpose_w(w, wt, k, Cin, Cout, (hipStream_t)stream);
+}
+
+int gn_conv1d_dgrad(const float* dy, const float* wt, float* dx, int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout, void* stream) {
+  GN_REQUIRE(dy && wt && dx, "conv1d_dgrad: null pointer");
+  GN_REQUIRE(B >= 0 && L > 0 && Cin > 0 && Cout > 0 && k >= 1 && k <= 8 && stride >= 1 && Lout > 0 && pad_left >= 0, "conv1d_dgrad: bad shape");
+  if (B == 0) return GN_OK;
+  // dx[b, tau, ci] = sum_{k', co} dy[b, t, co] * wt[k', co, ci]  with  stride*t + k' - pad_left == tau.
+  // Output phase p = tau mod stride uses the taps with (p + pad_left - k') divisible by stride, at dy row m + (p+pad_left-k')/stride.
+  for (int p = 0; p < stride; ++p) {
+    if (p >= L) break;
+    ConvArgs a = {};
+    a.x = dy; a.w = wt; a.bias = nullptr; a.y = dx;
+    a.B = B; a.Lin = Lout; a.Cin = Cout; a.Cout = Cin;
+    a.M = (L - p + stride - 1) / stride; a.Ly = L;
+    a.t.in_stride = 1; a.t.out_stride = stride; a.t.out_off = p;
+    int nt = 0;
+    for (int kk = 0; kk < k; ++kk) {
+      const int d = p + pad_left - kk;
+      if (((d % stride) + stride) % stride) continue;
+      a.t.off[nt] = (d >= 0) ? d / stride : -((-d) / stride);
+      a.t.widx[nt] = kk;
+      ++nt;
+    }
+    GN_REQUIRE(nt > 0, "conv1d_dgrad: phase %d has no taps (k %d < stride %d)", p, k, stride);
+    a.t.ntaps = nt;
+    a.act = GN_ACT_LINEAR;
+    int rc = conv_dispatch(a, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return GN_OK;
+}
+
+size_t gn_conv1d_wgrad_workspace(int B, int L, int Cin, int Cout, int k, int stride, int Lout) {
+  (void)L; (void)stride;
+  size_t w = (Cin <= 4 || Cout <= 4) ? wgrad_small_workspace_bytes(B, Lout, Cin, Cout, k) : wgrad_workspace_bytes(B, Cin, Cout, k);
+  size_t b = bias_grad_ws((size_t)B * Lout, Cout);
+  return (w > b ? w : b) + 256;
+}
+
+int gn_conv1d_wgrad(const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int B, int L, int Cin, int Cout, int k, int stride,
+                    int pad_left, int Lout, void* stream) {
+  GN_REQUIRE(x && dy && dw && ws, "conv1d_wgrad: null pointer");
+  GN_REQUIRE(B > 0 && L > 0 && Cin > 0 && Cout > 0 && k >= 1 && k <= 5 && stride >= 1 && Lout > 0 && pad_left >= 0, "conv1d_wgrad: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (Cin <= 4 || Cout <= 4) {
+    WgradSmallArgs a = {};
+    a.x = x; a.dy = dy; a.part = (float*)ws;
+    a.B = B; a.Lin = L; a.Cin = Cin; a.Cout = Cout; a.M = Lout; a.ntaps = k; a.in_stride = stride;
+    for (int j = 0; j < k; ++j) a.off[j] = j - pad_left;
+    rc = wgrad_small_dispatch(a, dw, ws_bytes, s);
+  } else {
+    WgradArgs a = {};
+    a.x = x; a.dy = dy; a.part = (float*)ws;
+    a.B = B; a.Lin = L; a.Cin = Cin; a.Cout = Cout; a.M = Lout; a.ntaps = k; a.in_stride = stride;
+    for (int j = 0; j < k; ++j) a.off[j] = j - pad_left;
+    rc = wgrad_mfma_dispatch(a, dw, ws_bytes, s);
+  }
+  if (rc) return rc;
+  if (db) rc = bias_grad(dy, db, (size_t)B * Lout, Cout, ws, ws_bytes, s);
+  return rc;
+}
+
+int gn_conv2d_w2_fold(const float* w, const float* bias, float* wf, float* biasf, int kh, int Cin, int Cout, void* stream) {
+  GN_REQUIRE(w && wf && kh >= 1 && Cin > 0 && Cout > 0, "conv2d_w2_fold: bad arguments");
+  return conv2d_w2_fold(w, bias, wf, biasf, kh, Cin, Cout, (hipStream_t)stream);
+}
+int gn_conv2d_w2_unfold_grad(const float* dwf, const float* dbf, float* dw, float* db, int kh, int Cin, int Cout, void* stream) {
+  GN_REQUIRE(dwf && dw && kh >= 1 && Cin > 0 && Cout > 0, "conv2d_w2_unfold_grad: bad arguments");
+  return conv2d_w2_unfold(dwf, dbf, dw, db, kh, Cin, Cout, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+int gn_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in, int out, int act, float act_param, void* stream) {
+  GN_REQUIRE(x && w && y && B >= 0 && in > 0 && out > 0, "dense_fwd: bad arguments");
+  if (B == 0) return GN_OK;
+  if (out <= 4) return dense_small_fwd(x, w, bias, y, B, in, out, act, act_param, (hipStream_t)stream);
+  ConvArgs a = {};
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.B = 1; a.Lin = B; a.Cin = in; a.Cout = out; a.M = B; a.Ly = B;
+  fwd_taps(&a.t, 1, 1, 0);
+  a.act = act; a.act_param = act_param;
+  return conv_mfma_dispatch(a, (hipStream_t)stream);
+}
+
+size_t gn_dense_bwd_workspace(int B, int in, int out) {
+  if (out <= 4) return 256;
+  size_t w = wgrad_workspace_bytes(1, in, out, 1);
+  size_t b = bias_grad_ws((size_t)B, out);
+  return (w > b ? w : b) + (size_t)in * out * sizeof(float) + 256;
+}
+
+int gn_dense_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, void* ws, size_t ws_bytes, int B, int in, int out, void* stream) {
+  GN_REQUIRE(x && w && dy && dw && B > 0 && in > 0 && out > 0, "dense_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (out <= 4) return dense_small_bwd(x, w, dy, dx, dw, db, B, in, out, s);
+  GN_REQUIRE(ws && ws_bytes >= gn_dense_bwd_workspace(B, in, out), "dense_bwd: workspace too small");
+  const size_t wt_bytes = (size_t)in * out * sizeof(float);
+  float* wt = (float*)ws;
+  void* ws2 = (char*)ws + wt_bytes;
+  const size_t ws2_bytes = ws_bytes - wt_bytes;
+  int rc;
+  if (dx) {
+    rc = transpose_w(w, wt, 1, in, out, s);
+    if (rc) return rc;
+    ConvArgs a = {};
+    a.x = dy; a.w = wt; a.y = dx;
+    a.B = 1; a.Lin = B; a.Cin = out; a.Cout = in; a.M = B; a.Ly = B;
+    fwd_taps(&a.t, 1, 1, 0);
+    a.act = GN_ACT_LINEAR;
+    rc = conv_dispatch(a, s);
+    if (rc) return rc;
+  }
+  WgradArgs g = {};
+  g.x = x; g.dy = dy; g.part = (float*)ws2;
+  g.B = 1; g.Lin = B; g.Cin = in; g.Cout = out; g.M = B; g.ntaps = 1; g.in_stride = 1; g.off[0] = 0;
+  rc = wgrad_mfma_dispatch(g, dw, ws2_bytes, s);
+  if (rc) return rc;
+  if (db) rc = bias_grad(dy, db, (size_t)B, out, ws2, ws2_bytes, s);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+int gn_act_fwd(const float* x, float* y, size_t n, int act, float p, void* stream) {
+  GN_REQUIRE(x && y, "act_fwd: null pointer");
+  return act_fwd(x, y, n, act, p, (hipStream_t)stream);
+}
+int gn_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float p, void* stream) {
+  GN_REQUIRE(dy && y && dx, "act_bwd: null pointer");
+  return act_bwd(dy, y, dx, n, act, p, (hipStream_t)stream);
+}
+int gn_dropout_mask(uint8_t* mask, size_t n, float rate, uint64_t seed, uint64_t offset, void* stream) {
+  GN_REQUIRE(mask && rate >= 0.f && rate < 1.f, "dropout_mask: bad arguments");
+  return dropout_mask(mask, n, rate, seed, offset, (hipStream_t)stream);
+}
+int gn_dropout_apply(const float* x, const uint8_t* mask, float* y, size_t n, float rate, void* stream) {
+  GN_REQUIRE(x && mask && y && rate >= 0.f && rate < 1.f, "dropout_apply: bad arguments");
+  return dropout_apply(x, mask, y, n, rate, (hipStream_t)stream);
+}
+int gn_upsample2_fwd(const float* x, float* y, int B, int L, int C, void* stream) {
+  GN_REQUIRE(x && y, "upsample2_fwd: null pointer");
+  return upsample2_fwd(x, y, B, L, C, (hipStream_t)stream);
+}
+int gn_upsample2_bwd(const float* dy, float* dx, int B, int L, int C, void* stream) {
+  GN_REQUIRE(dy && dx, "upsample2_bwd: null pointer");
+  return upsample2_bwd(dy, dx, B, L, C, (hipStream_t)stream);
+}
+int gn_subtract_stack_fwd(const float* x, const float* event, float* img, int B, int n, void* stream) {
+  GN_REQUIRE(x && event && img, "subtract_stack_fwd: null pointer");
+  return subtract_stack_fwd(x, event, img, B, n, (hipStream_t)stream);
+}
+int gn_subtract_stack_bwd(const float* dimg, float* dx, int B, int n, void* stream) {
+  GN_REQUIRE(dimg && dx, "subtract_stack_bwd: null pointer");
+  return subtract_stack_bwd(dimg, dx, B, n, (hipStream_t)stream);
+}
+int gn_fill_uniform(float* out, size_t n, float lo, float hi, uint64_t seed, uint64_t offset, void* stream) {
+  GN_REQUIRE(out, "fill_uniform: null pointer");
+  return fill_uniform(out, n, lo, hi, seed, offset, (hipStream_t)stream);
+}
+int gn_fill_normal(float* out, size_t n, float mean, float sd, uint64_t seed, uint64_t offset, void* stream) {
+  GN_REQUIRE(out, "fill_normal: null pointer");
+  return fill_normal(out, n, mean, sd, seed, offset, (hipStream_t)stream);
+}
+int gn_gather_rows(const float* src, const int64_t* idx, float* out, int rows, int width, void* stream) {
+  GN_REQUIRE(src && idx && out && rows >= 0 && width > 0, "gather_rows: bad arguments");
+  return gather_rows(src, idx, out, rows, width, (hipStream_t)stream);
+}
+int gn_axpy(float* y, const float* x, float a, size_t n, void* stream) {
+  GN_REQUIRE(y && x, "axpy: null pointer");
+  return axpy(y, x, a, n, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+size_t gn_bn_stats_workspace(size_t rows, int C) { return colred_workspace_bytes(rows, C) + 256; }
+
+int gn_bn_stats(const float* x, size_t rows, int C, double* sums, void* ws, size_t ws_bytes, void* stream) {
+  GN_REQUIRE(x && sums && ws && rows > 0 && C > 0, "bn_stats: bad arguments");
+  ColRedArgs r = {};
+  r.a = x; r.rows = rows; r.C = C;
+  return colred_run(1, r, ws, ws_bytes, sums, nullptr, (hipStream_t)stream);
+}
+int gn_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
+                   float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream) {
+  GN_REQUIRE(sums && gamma && beta && scale && shift && save_mean && save_invstd && C > 0 && count > 1.0, "bn_finalize: bad arguments");
+  GN_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving_mean/moving_var must both be given or both be NULL");
+  return bn_finalize(sums, count, gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, save_mean, save_invstd, C, (hipStream_t)stream);
+}
+int gn_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var, float eps, float* scale, float* shift, int C,
+                       void* stream) {
+  GN_REQUIRE(gamma && beta && moving_mean && moving_var && scale && shift && C > 0, "bn_infer_coeffs: bad arguments");
+  return bn_infer_coeffs(gamma, beta, moving_mean, moving_var, eps, scale, shift, C, (hipStream_t)stream);
+}
+int gn_bn_apply(const float* x, const float* scale, const float* shift, const uint8_t* mask, float* y, size_t rows, int C, int act, float p, float rate,
+                void* stream) {
+  GN_REQUIRE(x && scale && shift && y && C > 0, "bn_apply: bad arguments");
+  GN_REQUIRE(rate >= 0.f && rate < 1.f && (mask || rate == 0.f), "bn_apply: dropout rate %f without mask", rate);
+  return bn_apply(x, scale, shift, mask, y, rows, C, act, p, mask ? rate : 0.f, (hipStream_t)stream);
+}
+int gn_bn_bwd_stats(const float* dy, const float* y, const float* x, const uint8_t* mask, const float* save_mean, const float* save_invstd, double* dsums, void* ws,
+                    size_t ws_bytes, size_t rows, int C, int act, float p, float rate, void* stream) {
+  GN_REQUIRE(dy && y && x && save_mean && save_invstd && dsums && ws && rows > 0 && C > 0, "bn_bwd_stats: bad arguments");
+  ColRedArgs r = {};
+  r.a = dy; r.y = y; r.xpre = x; r.mask = mask; r.mean = save_mean; r.invstd = save_invstd;
+  r.rows = rows; r.C = C; r.act = act; r.act_param = p; r.keep_scale = 1.0f / (1.0f - (mask ? rate : 0.f));
+  return colred_run(2, r, ws, ws_bytes, dsums, nullptr, (hipStream_t)stream);
+}
+int gn_bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8_t* mask, const float* gamma, const float* save_mean, const float* save_invstd,
+                    const double* dsums_global, double count, const double* dsums_local, float* dx, float* dgamma, float* dbeta, size_t rows, int C, int act,
+                    float p, float rate, void* stream) {
+  GN_REQUIRE(dy && y && x && gamma && save_mean && save_invstd && dsums_global && dsums_local && dx && dgamma && dbeta && C > 0, "bn_bwd_apply: bad arguments");
+  return bn_bwd_apply(dy, y, x, mask, gamma, save_mean, save_invstd, dsums_global, count, dsums_local, dx, dgamma, dbeta, rows, C, act, p, mask ? rate : 0.f,
+                      (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+int gn_bce_loss(const float* p, const float* y, float* dp, float* out, int B, int Bglobal, void* stream) {
+  GN_REQUIRE(p && y && dp && out, "bce_loss: null pointer");
+  return loss_run(0, p, y, dp, out, B, Bglobal, (hipStream_t)stream);
+}
+int gn_mse_loss(const float* p, const float* y, float* dp, float* out, int B, int Bglobal, void* stream) {
+  GN_REQUIRE(p && y && dp && out, "mse_loss: null pointer");
+  return loss_run(1, p, y, dp, out, B, Bglobal, (hipStream_t)stream);
+}
+int gn_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, void* stream) {
+  GN_REQUIRE(p && g && m && v, "adam_step: null pointer");
+  return adam_step(p, g, m, v, n, lr_t, b1, b2, eps, (hipStream_t)stream);
+}
+
+}  // extern "C"

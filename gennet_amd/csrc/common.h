@@ -1,0 +1,189 @@
+// Shared helpers for the gfx950 kernel library (libgennet_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/gennet_hip.h"
+
+namespace gn {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// Event-based timing of the MFMA kernels (bench.py roofline leg).  No-ops unless gn_prof_enable(1).
+void prof_begin(hipStream_t s);
+void prof_end(hipStream_t s, double flop);
+
+
+// ---------------------------------------------------------------------------------------------
+// Generic tap description shared by all convolution kernels:
+//   y[b, out_stride*m + out_off, n] = act(bias[n] + sum_j sum_c x[b, in_stride*m + off[j], c] * w[widx[j], c, n])
+// covers Conv1D forward (off[j] = j - pad_left), its data gradient (per output phase when stride = 2) and Dense (1 tap).
+// ---------------------------------------------------------------------------------------------
+struct ConvTaps {
+  int ntaps;
+  int in_stride;
+  int off[8];
+  int widx[8];
+  int out_stride, out_off;
+};
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  float* y;
+  int B, Lin, Cin, Cout;
+  int M;   // output positions m per batch element (this phase)
+  int Ly;  // rows per batch element in y
+  ConvTaps t;
+  int act;
+  float act_param;
+};
+
+struct WgradArgs {
+  const float* x;
+  const float* dy;
+  float* part;  // [splits][ntaps][Cin][Cout]
+  int B, Lin, Cin, Cout, M;
+  int ntaps, in_stride;
+  int off[8];
+  int b_per_split;
+};
+
+struct WgradSmallArgs {
+  const float* x;
+  const float* dy;
+  float* part;
+  int B, Lin, Cin, Cout, M;
+  int ntaps, in_stride;
+  int off[8];
+  int rows_per_chunk;
+};
+
+struct ColRedArgs {
+  const float* a;        // x (MODE 0/1) or dy (MODE 2)
+  const float* y;        // MODE 2: layer output (post act, post dropout)
+  const float* xpre;     // MODE 2: BN input
+  const uint8_t* mask;   // MODE 2: dropout keep mask or NULL
+  const float* mean;
+  const float* invstd;
+  double* part;
+  size_t rows;
+  int C;
+  int rows_per_chunk;
+  int act;
+  float act_param;
+  float keep_scale;      // 1/(1-rate)
+};
+
+// conv_mfma.hip
+int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s);
+size_t wgrad_workspace_bytes(int B, int Cin, int Cout, int ntaps);
+int wgrad_mfma_dispatch(WgradArgs a, float* dw, size_t ws_bytes, hipStream_t s);
+// small_conv.hip
+int conv_smallcin_dispatch(const ConvArgs& a, hipStream_t s);
+int conv_smallcout_dispatch(const ConvArgs& a, hipStream_t s);
+size_t wgrad_small_workspace_bytes(int B, int M, int Cin, int Cout, int ntaps);
+int wgrad_small_dispatch(WgradSmallArgs a, float* dw, size_t ws_bytes, hipStream_t s);
+int dense_small_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in, int out, int act, float p, hipStream_t s);
+int dense_small_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int in, int out, hipStream_t s);
+// elementwise.hip
+int act_fwd(const float* x, float* y, size_t n, int act, float p, hipStream_t s);
+int act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float p, hipStream_t s);
+int dropout_mask(uint8_t* mask, size_t n, float rate, uint64_t seed, uint64_t offset, hipStream_t s);
+int dropout_apply(const float* x, const uint8_t* mask, float* y, size_t n, float rate, hipStream_t s);
+int upsample2_fwd(const float* x, float* y, int B, int L, int C, hipStream_t s);
+int upsample2_bwd(const float* dy, float* dx, int B, int L, int C, hipStream_t s);
+int subtract_stack_fwd(const float* x, const float* ev, float* img, int B, int n, hipStream_t s);
+int subtract_stack_bwd(const float* dimg, float* dx, int B, int n, hipStream_t s);
+int gather_rows(const float* src, const int64_t* idx, float* out, int rows, int width, hipStream_t s);
+int axpy(float* y, const float* x, float a, size_t n, hipStream_t s);
+int fill_uniform(float* out, size_t n, float lo, float hi, uint64_t seed, uint64_t offset, hipStream_t s);
+int fill_normal(float* out, size_t n, float mean, float sd, uint64_t seed, uint64_t offset, hipStream_t s);
+size_t colred_workspace_bytes(size_t rows, int C);
+int colred_run(int mode, ColRedArgs a, void* ws, size_t ws_bytes, double* out_f64, float* out_f32, hipStream_t s);
+int bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum, float* mm, float* mv,
+                float* scale, float* shift, float* smean, float* sinv, int C, hipStream_t s);
+int bn_infer_coeffs(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, float* scale, float* shift, int C, hipStream_t s);
+int bn_apply(const float* x, const float* scale, const float* shift, const uint8_t* mask, float* y, size_t rows, int C, int act, float p, float rate, hipStream_t s);
+int bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8_t* mask, const float* gamma, const float* mean, const float* invstd,
+                 const double* dsums_global, double count, const double* dsums_local, float* dx, float* dgamma, float* dbeta, size_t rows, int C,
+                 int act, float p, float rate, hipStream_t s);
+int loss_run(int kind, const float* p, const float* y, float* dp, float* out, int B, int Bglobal, hipStream_t s);
+int adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s);
+int transpose_w(const float* w, float* wt, int k, int Cin, int Cout, hipStream_t s);
+int conv2d_w2_fold(const float* w, const float* bias, float* wf, float* bf, int kh, int Cin, int Cout, hipStream_t s);
+int conv2d_w2_unfold(const float* dwf, const float* dbf, float* dw, float* db, int kh, int Cin, int Cout, hipStream_t s);
+
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+#define GN_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      gn::set_error(__VA_ARGS__);        \
+      return GN_EINVAL;                  \
+    }                                    \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// activation epilogues (fwd on the pre-activation, bwd through the OUTPUT value)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float x, int act, float p) {
+  switch (act) {
+    case GN_ACT_RELU: return fmaxf(x, 0.f);
+    case GN_ACT_RELU_MAX: return fminf(fmaxf(x, 0.f), p);
+    case GN_ACT_LEAKY: return x > 0.f ? x : p * x;
+    case GN_ACT_TANH: return tanhf(x);
+    case GN_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+    default: return x;
+  }
+}
+
+__device__ __forceinline__ float act_grad_from_y(float y, int act, float p) {
+  switch (act) {
+    case GN_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case GN_ACT_RELU_MAX: return (y > 0.f && y < p) ? 1.f : 0.f;
+    case GN_ACT_LEAKY: return y > 0.f ? 1.f : p;
+    case GN_ACT_TANH: return 1.f - y * y;
+    case GN_ACT_SIGMOID: return y * (1.f - y);
+    default: return 1.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), counter-based: stateless, so every rank / kernel derives
+// its stream from (seed, offset) alone.
+// ---------------------------------------------------------------------------------------------
+struct Philox4 {
+  uint32_t v[4];
+};
+
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t counter, uint64_t seed) {
+  uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0, c3 = 0;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t h0 = mulhi32(M0, c0), l0 = M0 * c0;
+    uint32_t h1 = mulhi32(M1, c2), l1 = M1 * c2;
+    uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  Philox4 o;
+  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}
+
+// uniform in [0,1) with 24 random bits (exactly representable in fp32)
+__host__ __device__ __forceinline__ float u01_24(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// uniform in (0,1) with 53-ish bits for fp64 Box-Muller
+__host__ __device__ __forceinline__ double u01_53(uint32_t hi, uint32_t lo) {
+  uint64_t x = (((uint64_t)hi << 32) | lo) >> 11;
+  return ((double)x + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+}  // namespace gn

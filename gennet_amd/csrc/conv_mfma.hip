@@ -1,0 +1,338 @@
+// Implicit-GEMM 1-D convolution on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, = fmaf chain).
+//
+// One kernel serves Conv1D forward, its data gradient (per output phase for stride 2) and Dense-as-1-tap-conv:
+//     y[b, os*m + o0, n] = act(bias[n] + sum_j sum_c x[b, is*m + off[j], c] * w[widx[j], c, n]),   rows outside [0,Lin) read 0
+// GEMM view: M = (b, m), N = Cout, K = (tap, Cin).  Channels-last makes the im2col operand a set of SHIFTED VIEWS of
+// one input slab: per Cin-chunk the block stages [is*(TM-1)+span+1 rows] x [KC channels] once into LDS and reads it
+// ntaps times, so A-side global traffic is 1/ntaps of a materialised im2col.
+//
+// Replaces the TF kernels behind bbhMahoGANy.py:250-292 (generator Conv1D), :362-394 (point-estimator Conv1D) and
+// :439,:447 (discriminator Conv2D after the width-2 fold).
+//
+// Tile: block = WAVES_M x WAVES_N waves, each wave WM x WN MFMA tiles of 32x32 -> TM x TN outputs per block.
+// LDS: slab rows padded to KC+1 words (stride-17 -> conflict-free ds_read_b32 across the 32 M-lanes); for in_stride 2
+// the slab is de-interleaved by row parity so the lane stride stays KC+1.  Weight tile [tap][KC][TN], N contiguous.
+#include "common.h"
+
+namespace gn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KC>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvArgs a, int m_tiles, int n_tiles) {
+  constexpr int TM = WAVES_M * WM * 32;
+  constexpr int TN = WAVES_N * WN * 32;
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int RS = KC + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int i32 = lane & 31, h = lane >> 5;
+
+  // n fastest: blocks b and b+8 share an XCD (round-robin dispatch), so with n_tiles | 8 or 8 | n_tiles each XCD keeps
+  // re-reading the same weight panel from its own L2.  Pure speed; nothing depends on placement.
+  const int bid = blockIdx.x;
+  const int n_tile = bid % n_tiles;
+  const int rest = bid / n_tiles;
+  const int m_tile = rest % m_tiles;
+  const int b = rest / m_tiles;
+  const int m0 = m_tile * TM, n0 = n_tile * TN;
+
+  const int is = a.t.in_stride, ntaps = a.t.ntaps;
+  int minoff = a.t.off[0], maxoff = a.t.off[0];
+  for (int j = 1; j < ntaps; ++j) {
+    minoff = min(minoff, a.t.off[j]);
+    maxoff = max(maxoff, a.t.off[j]);
+  }
+  const int R = is * (TM - 1) + (maxoff - minoff) + 1;
+  const int Rper = (R + is - 1) / is;
+  const int slab_floats = (is * Rper * RS + 3) & ~3;
+  float* slab = smem;
+  float* wl = smem + slab_floats;
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const int t_base = is * m0 + minoff;
+  const float* xb = a.x + (size_t)b * a.Lin * a.Cin;
+
+  for (int c0 = 0; c0 < a.Cin; c0 += KC) {
+    // ---- stage the input slab: R rows x KC channels (zero outside the sequence / past Cin)
+    for (int id = tid; id < R * (KC / 4); id += NT) {
+      const int r = id / (KC / 4), c4 = id % (KC / 4);
+      const int t = t_base + r, c = c0 + 4 * c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t >= 0 && t < a.Lin && c < a.Cin) v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.Cin + c);
+      const int lr = (is == 1) ? r : ((r & 1) * Rper + (r >> 1));
+      float* d = slab + lr * RS + 4 * c4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    // ---- stage the weight tile: [tap][KC][TN]
+    for (int id = tid; id < ntaps * KC * (TN / 4); id += NT) {
+      const int n4 = id % (TN / 4);
+      const int kk = (id / (TN / 4)) % KC;
+      const int j = id / ((TN / 4) * KC);
+      const int c = c0 + kk, n = n0 + 4 * n4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < a.Cin && n < a.Cout) v = *reinterpret_cast<const float4*>(a.w + ((size_t)a.t.widx[j] * a.Cin + c) * a.Cout + n);
+      *reinterpret_cast<float4*>(wl + (j * KC + kk) * TN + 4 * n4) = v;
+    }
+    __syncthreads();
+
+    for (int j = 0; j < ntaps; ++j) {
+      const int d = a.t.off[j] - minoff;
+      const int rowbase = (is == 1) ? d : ((d & 1) * Rper + (d >> 1));
+      const float* ap = slab + (rowbase + wm * WM * 32 + i32) * RS + h;
+      const float* bp = wl + (j * KC + h) * TN + wn * WN * 32 + i32;
+#pragma unroll
+      for (int q = 0; q < KC / 2; ++q) {
+        float av[WM], bv[WN];
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) av[mt] = ap[mt * 32 * RS + 2 * q];
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) bv[nt] = bp[2 * q * TN + nt * 32];
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* yb = a.y + (size_t)b * a.Ly * a.Cout;
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    const int n = n0 + wn * WN * 32 + nt * 32 + i32;
+    if (n >= a.Cout) continue;
+    const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = m0 + wm * WM * 32 + mt * 32 + row;
+        if (m < a.M) yb[(size_t)(a.t.out_stride * m + a.t.out_off) * a.Cout + n] = act_apply(acc[mt][nt][r] + bias, a.act, a.act_param);
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KC>
+static int launch_conv(const ConvArgs& a, hipStream_t s) {
+  constexpr int TM = WAVES_M * WM * 32, TN = WAVES_N * WN * 32;
+  const int is = a.t.in_stride;
+  int minoff = a.t.off[0], maxoff = a.t.off[0];
+  for (int j = 1; j < a.t.ntaps; ++j) {
+    minoff = std::min(minoff, a.t.off[j]);
+    maxoff = std::max(maxoff, a.t.off[j]);
+  }
+  const int R = is * (TM - 1) + (maxoff - minoff) + 1;
+  const int Rper = (R + is - 1) / is;
+  const int slab_floats = (is * Rper * (KC + 1) + 3) & ~3;
+  const size_t lds = sizeof(float) * ((size_t)slab_floats + (size_t)a.t.ntaps * KC * TN);
+  if (lds > 64 * 1024) {
+    set_error("conv_mfma: LDS tile %zu B exceeds 64 KiB (ntaps=%d, in_stride=%d)", lds, a.t.ntaps, is);
+    return GN_EINVAL;
+  }
+  const int m_tiles = (a.M + TM - 1) / TM, n_tiles = (a.Cout + TN - 1) / TN;
+  const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
+  if (blocks == 0 || blocks > 0x7fffffffull) {
+    set_error("conv_mfma: bad grid %zu", blocks);
+    return GN_EINVAL;
+  }
+  prof_begin(s);
+  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, KC>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles);
+  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout);
+  return check_launch("conv_mfma");
+}
+
+// Entry used by the C-ABI wrappers in capi.hip.
+int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s) {
+  if (a.Cin % 4 || a.Cout % 4) {
+    set_error("conv_mfma: Cin (%d) and Cout (%d) must be multiples of 4", a.Cin, a.Cout);
+    return GN_EINVAL;
+  }
+  if (a.t.in_stride != 1 && a.t.in_stride != 2) {
+    set_error("conv_mfma: in_stride %d unsupported", a.t.in_stride);
+    return GN_EINVAL;
+  }
+  if (a.t.ntaps < 1 || a.t.ntaps > 8) {
+    set_error("conv_mfma: ntaps %d unsupported", a.t.ntaps);
+    return GN_EINVAL;
+  }
+  if (a.Cout <= 64) return launch_conv<2, 2, 4, 1, 16>(a, s);  // 256 x 64 tile
+  return launch_conv<2, 2, 2, 2, 16>(a, s);                    // 128 x 128 tile
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient: dw[j, c, n] = sum_{b,m} x[b, is*m + off[j], c] * dy[b, m, n]   (GEMM: M = Cin, N = Cout, K = (b, m))
+// Block = one (Cin-tile, Cout-tile, K-split); every wave keeps ntaps accumulator tiles (the x slab again serves all
+// taps as shifted views).  Partial slabs [split][tap][Cin][Cout] are summed by wgrad_reduce_kernel in a fixed order.
+// ---------------------------------------------------------------------------------------------
+
+template <int WAVES_C, int WAVES_N, int NTAPS, int KT>
+__global__ __launch_bounds__(64 * WAVES_C * WAVES_N) void wgrad_mfma_kernel(WgradArgs a) {
+  constexpr int TC = WAVES_C * 32, TN = WAVES_N * 32;
+  constexpr int NT = 64 * WAVES_C * WAVES_N;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave / WAVES_N, wn = wave % WAVES_N;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int c0 = blockIdx.x * TC, n0 = blockIdx.y * TN, split = blockIdx.z;
+  const int is = a.in_stride;
+
+  int minoff = a.off[0], maxoff = a.off[0];
+#pragma unroll
+  for (int j = 1; j < NTAPS; ++j) {
+    minoff = min(minoff, a.off[j]);
+    maxoff = max(maxoff, a.off[j]);
+  }
+  const int R = is * (KT - 1) + (maxoff - minoff) + 1;
+  float* slab = smem;                                    // [R][TC]
+  float* dyl = smem + ((R * TC + 3) & ~3);               // [KT][TN]
+
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int j = 0; j < NTAPS; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int b_lo = split * a.b_per_split, b_hi = min(a.B, b_lo + a.b_per_split);
+  for (int b = b_lo; b < b_hi; ++b) {
+    const float* xb = a.x + (size_t)b * a.Lin * a.Cin;
+    const float* dyb = a.dy + (size_t)b * a.M * a.Cout;
+    for (int m0 = 0; m0 < a.M; m0 += KT) {
+      const int t_base = is * m0 + minoff;
+      for (int id = tid; id < R * (TC / 4); id += NT) {
+        const int r = id / (TC / 4), c4 = id % (TC / 4);
+        const int t = t_base + r, c = c0 + 4 * c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < a.Lin && c < a.Cin) v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.Cin + c);
+        *reinterpret_cast<float4*>(slab + r * TC + 4 * c4) = v;
+      }
+      for (int id = tid; id < KT * (TN / 4); id += NT) {
+        const int r = id / (TN / 4), n4 = id % (TN / 4);
+        const int m = m0 + r, n = n0 + 4 * n4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < a.M && n < a.Cout) v = *reinterpret_cast<const float4*>(dyb + (size_t)m * a.Cout + n);
+        *reinterpret_cast<float4*>(dyl + r * TN + 4 * n4) = v;
+      }
+      __syncthreads();
+      const float* bp = dyl + h * TN + wn * 32 + i32;
+#pragma unroll
+      for (int q = 0; q < KT / 2; ++q) {
+        const float bv = bp[2 * q * TN];
+#pragma unroll
+        for (int j = 0; j < NTAPS; ++j) {
+          const float av = slab[(is * (2 * q + h) + (a.off[j] - minoff)) * TC + wc * 32 + i32];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  const int n = n0 + wn * 32 + i32;
+  if (n < a.Cout) {
+#pragma unroll
+    for (int j = 0; j < NTAPS; ++j) {
+      float* pj = a.part + ((size_t)split * NTAPS + j) * a.Cin * a.Cout;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (c < a.Cin) pj[(size_t)c * a.Cout + n] = acc[j][r];
+      }
+    }
+  }
+}
+
+// dw[e] = sum_s part[s][e]  (fixed order: reproducible); float4 over e
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n4, int splits, size_t stride4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4* p = reinterpret_cast<const float4*>(part);
+  float4 s = p[i];
+  for (int k = 1; k < splits; ++k) {
+    const float4 v = p[(size_t)k * stride4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(dw)[i] = s;
+}
+
+static int wgrad_splits(int B, int Cin, int Cout, int TC, int TN) {
+  const int tiles = cdiv(Cin, TC) * cdiv(Cout, TN);
+  int s = (2048 + tiles - 1) / tiles;
+  if (s > B) s = B;
+  if (s < 1) s = 1;
+  const int bps = (B + s - 1) / s;
+  return (B + bps - 1) / bps;
+}
+
+static void wgrad_tile(int Cout, int* TC, int* TN) {
+  if (Cout <= 64) { *TC = 64; *TN = 64; } else { *TC = 32; *TN = 128; }
+}
+
+size_t wgrad_workspace_bytes(int B, int Cin, int Cout, int ntaps) {
+  int TC, TN;
+  wgrad_tile(Cout, &TC, &TN);
+  const int s = wgrad_splits(B, Cin, Cout, TC, TN);
+  return (size_t)s * ntaps * Cin * Cout * sizeof(float);
+}
+
+template <int WAVES_C, int WAVES_N, int NTAPS>
+static int launch_wgrad(WgradArgs a, float* dw, hipStream_t s) {
+  constexpr int KT = 32, TC = WAVES_C * 32, TN = WAVES_N * 32;
+  const int splits = wgrad_splits(a.B, a.Cin, a.Cout, TC, TN);
+  a.b_per_split = (a.B + splits - 1) / splits;
+  int minoff = a.off[0], maxoff = a.off[0];
+  for (int j = 1; j < NTAPS; ++j) {
+    minoff = std::min(minoff, a.off[j]);
+    maxoff = std::max(maxoff, a.off[j]);
+  }
+  const int R = a.in_stride * (KT - 1) + (maxoff - minoff) + 1;
+  const size_t lds = sizeof(float) * (((size_t)R * TC + 3 & ~(size_t)3) + (size_t)KT * TN);
+  dim3 grid(cdiv(a.Cin, TC), cdiv(a.Cout, TN), splits);
+  prof_begin(s);
+  hipLaunchKernelGGL((wgrad_mfma_kernel<WAVES_C, WAVES_N, NTAPS, KT>), grid, dim3(64 * WAVES_C * WAVES_N), lds, s, a);
+  prof_end(s, 2.0 * a.B * (double)a.M * NTAPS * a.Cin * a.Cout);
+  int rc = check_launch("wgrad_mfma");
+  if (rc) return rc;
+  const size_t n = (size_t)NTAPS * a.Cin * a.Cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a.part, dw, n / 4, splits, n / 4);
+  return check_launch("wgrad_reduce");
+}
+
+int wgrad_mfma_dispatch(WgradArgs a, float* dw, size_t ws_bytes, hipStream_t s) {
+  if (a.Cin % 4 || a.Cout % 4) {
+    set_error("wgrad_mfma: Cin (%d) and Cout (%d) must be multiples of 4", a.Cin, a.Cout);
+    return GN_EINVAL;
+  }
+  if (a.in_stride != 1 && a.in_stride != 2) {
+    set_error("wgrad_mfma: in_stride %d unsupported", a.in_stride);
+    return GN_EINVAL;
+  }
+  if (ws_bytes < wgrad_workspace_bytes(a.B, a.Cin, a.Cout, a.ntaps)) {
+    set_error("wgrad_mfma: workspace too small");
+    return GN_EWORKSPACE;
+  }
+  const bool narrow = a.Cout <= 64;
+  switch (a.ntaps) {
+    case 1: return narrow ? launch_wgrad<2, 2, 1>(a, dw, s) : launch_wgrad<1, 4, 1>(a, dw, s);
+    case 5: return narrow ? launch_wgrad<2, 2, 5>(a, dw, s) : launch_wgrad<1, 4, 5>(a, dw, s);
+    default:
+      set_error("wgrad_mfma: ntaps %d unsupported (1 or 5)", a.ntaps);
+      return GN_EINVAL;
+  }
+}
+
+}  // namespace gn

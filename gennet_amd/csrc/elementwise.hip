@@ -1,0 +1,576 @@
+// Streaming (HBM-bound) kernels: activations, dropout, upsample, subtract-stack, RNG fills, gather, BatchNorm passes,
+// losses and the fused Adam update.  All are float4-vectorised grid-stride loops sized to ~8 blocks/CU.
+#include "common.h"
+
+namespace gn {
+
+static inline unsigned stream_grid(size_t n_items, int block = 256) {
+  size_t g = (n_items + block - 1) / block;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// activations
+// ---------------------------------------------------------------------------------------------
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act, float p) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x = act_apply(v.x, act, p); v.y = act_apply(v.y, act, p); v.z = act_apply(v.z, act, p); v.w = act_apply(v.w, act, p);
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = act_apply(x[i], act, p);
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, size_t n, int act, float p) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    float4 o;
+    o.x = g.x * act_grad_from_y(v.x, act, p); o.y = g.y * act_grad_from_y(v.y, act, p);
+    o.z = g.z * act_grad_from_y(v.z, act, p); o.w = g.w * act_grad_from_y(v.w, act, p);
+    reinterpret_cast<float4*>(dx)[i] = o;
+  }
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dx[i] = dy[i] * act_grad_from_y(y[i], act, p);
+}
+
+int act_fwd(const float* x, float* y, size_t n, int act, float p, hipStream_t s) {
+  if (n == 0) return GN_OK;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, x, y, n, act, p);
+  return check_launch("act_fwd");
+}
+int act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float p, hipStream_t s) {
+  if (n == 0) return GN_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, dy, y, dx, n, act, p);
+  return check_launch("act_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// dropout: one Philox call yields 4 uniforms -> 4 consecutive mask bytes
+// ---------------------------------------------------------------------------------------------
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ mask, size_t n, float rate, uint64_t seed, uint64_t offset) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = (n + 3) >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const Philox4 r = philox4x32_10(offset + i, seed);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const size_t k = 4 * i + e;
+      if (k < n) mask[k] = u01_24(r.v[e]) >= rate ? 1 : 0;
+    }
+  }
+}
+
+__global__ void dropout_apply_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, float* __restrict__ y, size_t n, float scale) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = mask[i] ? x[i] * scale : 0.f;
+}
+
+int dropout_mask(uint8_t* mask, size_t n, float rate, uint64_t seed, uint64_t offset, hipStream_t s) {
+  if (n == 0) return GN_OK;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, mask, n, rate, seed, offset);
+  return check_launch("dropout_mask");
+}
+int dropout_apply(const float* x, const uint8_t* mask, float* y, size_t n, float rate, hipStream_t s) {
+  if (n == 0) return GN_OK;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(stream_grid(n)), dim3(256), 0, s, x, mask, y, n, 1.0f / (1.0f - rate));
+  return check_launch("dropout_apply");
+}
+
+// ---------------------------------------------------------------------------------------------
+// UpSampling1D(2), MyLayer stack, gather, axpy, RNG fills
+// ---------------------------------------------------------------------------------------------
+__global__ void upsample2_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y, size_t rows, int C4) {
+  const size_t n = rows * C4, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const size_t r = i / C4, c = i % C4;
+    const float4 v = x[i];
+    y[(2 * r) * C4 + c] = v;
+    y[(2 * r + 1) * C4 + c] = v;
+  }
+}
+__global__ void upsample2_bwd_kernel(const float4* __restrict__ dy, float4* __restrict__ dx, size_t rows, int C4) {
+  const size_t n = rows * C4, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const size_t r = i / C4, c = i % C4;
+    const float4 a = dy[(2 * r) * C4 + c], b = dy[(2 * r + 1) * C4 + c];
+    dx[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+int upsample2_fwd(const float* x, float* y, int B, int L, int C, hipStream_t s) {
+  if (C % 4) { set_error("upsample2: C %d %% 4 != 0", C); return GN_EINVAL; }
+  const size_t rows = (size_t)B * L;
+  if (!rows) return GN_OK;
+  hipLaunchKernelGGL(upsample2_fwd_kernel, dim3(stream_grid(rows * (C / 4))), dim3(256), 0, s, (const float4*)x, (float4*)y, rows, C / 4);
+  return check_launch("upsample2_fwd");
+}
+int upsample2_bwd(const float* dy, float* dx, int B, int L, int C, hipStream_t s) {
+  if (C % 4) { set_error("upsample2: C %d %% 4 != 0", C); return GN_EINVAL; }
+  const size_t rows = (size_t)B * L;
+  if (!rows) return GN_OK;
+  hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(stream_grid(rows * (C / 4))), dim3(256), 0, s, (const float4*)dy, (float4*)dx, rows, C / 4);
+  return check_launch("upsample2_bwd");
+}
+
+__global__ void subtract_stack_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ev, float2* __restrict__ img, size_t total, int n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float v = x[i];
+    img[i] = make_float2(v, ev[i % n] - v);
+  }
+}
+__global__ void subtract_stack_bwd_kernel(const float2* __restrict__ d, float* __restrict__ dx, size_t total) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float2 v = d[i];
+    dx[i] = v.x - v.y;
+  }
+}
+int subtract_stack_fwd(const float* x, const float* ev, float* img, int B, int n, hipStream_t s) {
+  const size_t total = (size_t)B * n;
+  if (!total) return GN_OK;
+  hipLaunchKernelGGL(subtract_stack_fwd_kernel, dim3(stream_grid(total)), dim3(256), 0, s, x, ev, (float2*)img, total, n);
+  return check_launch("subtract_stack_fwd");
+}
+int subtract_stack_bwd(const float* dimg, float* dx, int B, int n, hipStream_t s) {
+  const size_t total = (size_t)B * n;
+  if (!total) return GN_OK;
+  hipLaunchKernelGGL(subtract_stack_bwd_kernel, dim3(stream_grid(total)), dim3(256), 0, s, (const float2*)dimg, dx, total);
+  return check_launch("subtract_stack_bwd");
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ out, size_t rows, int width) {
+  const size_t total = rows * width, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t r = i / width, c = i % width;
+    out[i] = src[(size_t)idx[r] * width + c];
+  }
+}
+int gather_rows(const float* src, const int64_t* idx, float* out, int rows, int width, hipStream_t s) {
+  const size_t total = (size_t)rows * width;
+  if (!total) return GN_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(stream_grid(total)), dim3(256), 0, s, src, idx, out, (size_t)rows, width);
+  return check_launch("gather_rows");
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = fmaf(a, x[i], y[i]);
+}
+int axpy(float* y, const float* x, float a, size_t n, hipStream_t s) {
+  if (!n) return GN_OK;
+  hipLaunchKernelGGL(axpy_kernel, dim3(stream_grid(n)), dim3(256), 0, s, y, x, a, n);
+  return check_launch("axpy");
+}
+
+__global__ void fill_uniform_kernel(float* __restrict__ out, size_t n, float lo, float hi, uint64_t seed, uint64_t offset) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = (n + 3) >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const Philox4 r = philox4x32_10(offset + i, seed);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const size_t k = 4 * i + e;
+      if (k < n) out[k] = lo + (hi - lo) * u01_24(r.v[e]);
+    }
+  }
+}
+// Box-Muller on two 24-bit uniforms per pair; u1 in (0,1] so log is finite
+__global__ void fill_normal_kernel(float* __restrict__ out, size_t n, float mean, float sd, uint64_t seed, uint64_t offset) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = (n + 3) >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const Philox4 r = philox4x32_10(offset + i, seed);
+    float z[4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float u1 = 1.0f - u01_24(r.v[2 * e]);
+      const float u2 = u01_24(r.v[2 * e + 1]);
+      const float rad = sqrtf(-2.0f * logf(u1));
+      float sn, cs;
+      sincosf(6.283185307179586f * u2, &sn, &cs);
+      z[2 * e] = rad * cs;
+      z[2 * e + 1] = rad * sn;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const size_t k = 4 * i + e;
+      if (k < n) out[k] = mean + sd * z[e];
+    }
+  }
+}
+int fill_uniform(float* out, size_t n, float lo, float hi, uint64_t seed, uint64_t offset, hipStream_t s) {
+  if (!n) return GN_OK;
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, out, n, lo, hi, seed, offset);
+  return check_launch("fill_uniform");
+}
+int fill_normal(float* out, size_t n, float mean, float sd, uint64_t seed, uint64_t offset, hipStream_t s) {
+  if (!n) return GN_OK;
+  hipLaunchKernelGGL(fill_normal_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, out, n, mean, sd, seed, offset);
+  return check_launch("fill_normal");
+}
+
+// ---------------------------------------------------------------------------------------------
+// column reductions in fp64 (BatchNorm statistics, bias gradients):  x viewed as (rows, C), C % 4 == 0
+// grid = (column blocks, row chunks); thread = one float4 column group x one row lane; partials [chunk][NV][C] fp64.
+// MODE 0: sum x                (bias gradient)
+// MODE 1: sum x, sum x^2       (BN forward statistics)
+// MODE 2: sum g, sum g*xhat    (BN backward statistics; g = dy through dropout and activation)
+// ---------------------------------------------------------------------------------------------
+
+// value of g for one element (shared by backward pass 1 and 2)
+__device__ __forceinline__ float bn_bwd_g(float dy, float y, uint8_t keep, int act, float p, float keep_scale) {
+  if (!keep) return 0.f;
+  const float yact = y / keep_scale;  // undo the inverted-dropout scale to recover the activation output
+  return dy * keep_scale * act_grad_from_y(yact, act, p);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void colred_kernel(ColRedArgs a) {
+  constexpr int NV = MODE == 0 ? 1 : 2;
+  const int NQ = a.C >> 2;
+  const int NQc = NQ < 256 ? NQ : 256;
+  const int RL = 256 / NQc;
+  const int tid = threadIdx.x, ql = tid % NQc, rl = tid / NQc;
+  const int q = blockIdx.x * NQc + ql;
+  double s[NV][4];
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[v][e] = 0.0;
+  const size_t r_lo = (size_t)blockIdx.y * a.rows_per_chunk;
+  const size_t r_hi = r_lo + a.rows_per_chunk < a.rows ? r_lo + a.rows_per_chunk : a.rows;
+  if (rl < RL && q < NQ) {
+    float mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0};
+    if (MODE == 2) {
+      const float4 m4 = *reinterpret_cast<const float4*>(a.mean + 4 * q), i4 = *reinterpret_cast<const float4*>(a.invstd + 4 * q);
+      mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+      is[0] = i4.x; is[1] = i4.y; is[2] = i4.z; is[3] = i4.w;
+    }
+    for (size_t r = r_lo + rl; r < r_hi; r += RL) {
+      const size_t o = r * a.C + 4 * q;
+      const float4 v4 = *reinterpret_cast<const float4*>(a.a + o);
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[0][e] += (double)v[e];
+      } else if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[0][e] += (double)v[e];
+          s[1][e] += (double)v[e] * (double)v[e];
+        }
+      } else {
+        const float4 y4 = *reinterpret_cast<const float4*>(a.y + o), x4 = *reinterpret_cast<const float4*>(a.xpre + o);
+        const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+        uint8_t k[4] = {1, 1, 1, 1};
+        if (a.mask) {
+          const uchar4 m = *reinterpret_cast<const uchar4*>(a.mask + o);
+          k[0] = m.x; k[1] = m.y; k[2] = m.z; k[3] = m.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = bn_bwd_g(v[e], yv[e], k[e], a.act, a.act_param, a.keep_scale);
+          const float xh = (xv[e] - mu[e]) * is[e];
+          s[0][e] += (double)g;
+          s[NV - 1][e] += (double)g * (double)xh;
+        }
+      }
+    }
+  }
+  __shared__ double red[256 * 4];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[tid * 4 + e] = s[v][e];
+    __syncthreads();
+    if (rl == 0 && q < NQ) {
+      double t[4] = {red[ql * 4], red[ql * 4 + 1], red[ql * 4 + 2], red[ql * 4 + 3]};
+      for (int k = 1; k < RL; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] += red[(k * NQc + ql) * 4 + e];
+      double* d = a.part + ((size_t)blockIdx.y * NV + v) * a.C + 4 * q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = t[e];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void colred_final_kernel(const double* __restrict__ part, double* __restrict__ out, size_t n, int chunks) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = part[i];
+  for (int k = 1; k < chunks; ++k) s += part[(size_t)k * n + i];
+  out[i] = s;
+}
+__global__ void colred_final_f32_kernel(const double* __restrict__ part, float* __restrict__ out, size_t n, int chunks) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = part[i];
+  for (int k = 1; k < chunks; ++k) s += part[(size_t)k * n + i];
+  out[i] = (float)s;
+}
+
+static int colred_chunks(size_t rows, int C) {
+  const int NQ = C / 4, NQc = NQ < 256 ? NQ : 256, RL = 256 / NQc;
+  const int gx = (NQ + NQc - 1) / NQc;
+  int chunks = (2048 + gx - 1) / gx;
+  const size_t max_chunks = (rows + (size_t)RL * 4 - 1) / ((size_t)RL * 4);
+  if ((size_t)chunks > max_chunks) chunks = (int)max_chunks;
+  if (chunks < 1) chunks = 1;
+  return chunks;
+}
+size_t colred_workspace_bytes(size_t rows, int C) { return (size_t)colred_chunks(rows, C) * 2 * C * sizeof(double); }
+
+// out_f64 (NV*C doubles) or out_f32 (MODE 0 only) receives the reduced sums
+int colred_run(int mode, ColRedArgs a, void* ws, size_t ws_bytes, double* out_f64, float* out_f32, hipStream_t s) {
+  if (a.C % 4) { set_error("column reduction: C %d %% 4 != 0", a.C); return GN_EINVAL; }
+  if (a.rows == 0) { set_error("column reduction: no rows"); return GN_EINVAL; }
+  const int chunks = colred_chunks(a.rows, a.C);
+  const int NV = mode == 0 ? 1 : 2;
+  if (ws_bytes < (size_t)chunks * NV * a.C * sizeof(double)) { set_error("column reduction: workspace too small"); return GN_EWORKSPACE; }
+  a.part = (double*)ws;
+  a.rows_per_chunk = (int)((a.rows + chunks - 1) / chunks);
+  const int NQ = a.C / 4, NQc = NQ < 256 ? NQ : 256;
+  dim3 grid((NQ + NQc - 1) / NQc, chunks);
+  if (mode == 0) hipLaunchKernelGGL(colred_kernel<0>, grid, dim3(256), 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL(colred_kernel<1>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(colred_kernel<2>, grid, dim3(256), 0, s, a);
+  int rc = check_launch("colred");
+  if (rc) return rc;
+  const size_t n = (size_t)NV * a.C;
+  if (out_f32) hipLaunchKernelGGL(colred_final_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const double*)ws, out_f32, n, chunks);
+  else hipLaunchKernelGGL(colred_final_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const double*)ws, out_f64, n, chunks);
+  return check_launch("colred_final");
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm finalize / apply / backward-apply
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* __restrict__ mm, float* __restrict__ mv, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ smean, float* __restrict__ sinv, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sums[c] / count;
+  double var = sums[C + c] / count - mean * mean;
+  if (var < 0) var = 0;
+  const float meanf = (float)mean, varf = (float)var;
+  const float inv = 1.0f / sqrtf(varf + eps);
+  const float sc = gamma[c] * inv;
+  scale[c] = sc;
+  shift[c] = beta[c] - meanf * sc;
+  smean[c] = meanf;
+  sinv[c] = inv;
+  if (mm) {
+    const float corr = (float)(count / (count - (1.0 + (double)eps)));
+    mm[c] = mm[c] * momentum + meanf * (1.0f - momentum);
+    mv[c] = mv[c] * momentum + varf * corr * (1.0f - momentum);
+  }
+}
+int bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum, float* mm, float* mv,
+                float* scale, float* shift, float* smean, float* sinv, int C, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, sums, count, gamma, beta, eps, momentum, mm, mv, scale, shift, smean, sinv, C);
+  return check_launch("bn_finalize");
+}
+
+__global__ void bn_infer_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mm,
+                                       const float* __restrict__ mv, float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(mv[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - mm[c] * sc;
+}
+int bn_infer_coeffs(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, float* scale, float* shift, int C, hipStream_t s) {
+  hipLaunchKernelGGL(bn_infer_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, gamma, beta, mm, mv, eps, scale, shift, C);
+  return check_launch("bn_infer_coeffs");
+}
+
+__global__ void bn_apply_kernel(const float4* __restrict__ x, const float4* __restrict__ scale, const float4* __restrict__ shift,
+                                const uchar4* __restrict__ mask, float4* __restrict__ y, size_t n4, int C4, int act, float p, float keep_scale) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int c = (int)(i % C4);
+    const float4 v = x[i], sc = scale[c], sh = shift[c];
+    float4 o;
+    o.x = act_apply(fmaf(v.x, sc.x, sh.x), act, p); o.y = act_apply(fmaf(v.y, sc.y, sh.y), act, p);
+    o.z = act_apply(fmaf(v.z, sc.z, sh.z), act, p); o.w = act_apply(fmaf(v.w, sc.w, sh.w), act, p);
+    if (mask) {
+      const uchar4 m = mask[i];
+      o.x = m.x ? o.x * keep_scale : 0.f; o.y = m.y ? o.y * keep_scale : 0.f;
+      o.z = m.z ? o.z * keep_scale : 0.f; o.w = m.w ? o.w * keep_scale : 0.f;
+    }
+    y[i] = o;
+  }
+}
+int bn_apply(const float* x, const float* scale, const float* shift, const uint8_t* mask, float* y, size_t rows, int C, int act, float p, float rate, hipStream_t s) {
+  if (C % 4) { set_error("bn_apply: C %d %% 4 != 0", C); return GN_EINVAL; }
+  const size_t n4 = rows * (C / 4);
+  if (!n4) return GN_OK;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, s, (const float4*)x, (const float4*)scale, (const float4*)shift,
+                     (const uchar4*)mask, (float4*)y, n4, C / 4, act, p, 1.0f / (1.0f - rate));
+  return check_launch("bn_apply");
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const double* __restrict__ dsums, double count, float* __restrict__ dx, size_t n, int C, int act, float p, float keep_scale) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int c = (int)(i % C);
+    const float g = bn_bwd_g(dy[i], y[i], mask ? mask[i] : (uint8_t)1, act, p, keep_scale);
+    const float inv = invstd[c];
+    const float xh = (x[i] - mean[c]) * inv;
+    const float mg = (float)(dsums[c] / count), mgx = (float)(dsums[C + c] / count);
+    dx[i] = gamma[c] * inv * (g - mg - xh * mgx);
+  }
+}
+__global__ void bn_param_grads_kernel(const double* __restrict__ dsums_local, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = (float)dsums_local[c];
+  dgamma[c] = (float)dsums_local[C + c];
+}
+int bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8_t* mask, const float* gamma, const float* mean, const float* invstd,
+                 const double* dsums_global, double count, const double* dsums_local, float* dx, float* dgamma, float* dbeta, size_t rows, int C,
+                 int act, float p, float rate, hipStream_t s) {
+  const size_t n = rows * C;
+  if (!n) return GN_OK;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n)), dim3(256), 0, s, dy, y, x, mask, gamma, mean, invstd, dsums_global, count, dx, n, C, act, p,
+                     1.0f / (1.0f - rate));
+  int rc = check_launch("bn_bwd_apply");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dsums_local, dgamma, dbeta, C);
+  return check_launch("bn_param_grads");
+}
+
+// ---------------------------------------------------------------------------------------------
+// losses: single block (B is a batch size, a few thousand at most)
+// ---------------------------------------------------------------------------------------------
+template <int KIND>  // 0 = BCE, 1 = MSE
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ p, const float* __restrict__ y, float* __restrict__ dp, float* __restrict__ out,
+                                                   int B, int Bglobal) {
+  const float eps = 1e-7f;
+  float lsum = 0.f, hits = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    const float pv = p[i], yv = y[i];
+    if (KIND == 0) {
+      const float pc = fminf(fmaxf(pv, eps), 1.f - eps);
+      const float z = logf(pc / (1.f - pc));
+      lsum += fmaxf(z, 0.f) - z * yv + log1pf(expf(-fabsf(z)));
+      const bool inside = (pv >= eps) && (pv <= 1.f - eps);
+      const float sg = 1.f / (1.f + expf(-z));
+      dp[i] = inside ? (sg - yv) / (pc * (1.f - pc)) / (float)Bglobal : 0.f;
+    } else {
+      const float d = pv - yv;
+      lsum += d * d;
+      dp[i] = 2.f * d / (float)Bglobal;
+    }
+    hits += (rintf(pv) == yv) ? 1.f : 0.f;
+  }
+  __shared__ float r0[256], r1[256];
+  r0[threadIdx.x] = lsum; r1[threadIdx.x] = hits;
+  __syncthreads();
+  for (int sft = 128; sft >= 1; sft >>= 1) {
+    if (threadIdx.x < sft) { r0[threadIdx.x] += r0[threadIdx.x + sft]; r1[threadIdx.x] += r1[threadIdx.x + sft]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = r0[0] / (float)Bglobal; out[1] = r1[0]; }
+}
+int loss_run(int kind, const float* p, const float* y, float* dp, float* out, int B, int Bglobal, hipStream_t s) {
+  if (B < 1 || Bglobal < B) { set_error("loss: bad batch sizes %d / %d", B, Bglobal); return GN_EINVAL; }
+  if (kind == 0) hipLaunchKernelGGL(loss_kernel<0>, dim3(1), dim3(256), 0, s, p, y, dp, out, B, Bglobal);
+  else hipLaunchKernelGGL(loss_kernel<1>, dim3(1), dim3(256), 0, s, p, y, dp, out, B, Bglobal);
+  return check_launch("loss");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (keras form), one fused pass over the flat parameter segment
+// ---------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr_t, float b1,
+                            float b2, float eps) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+int adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s) {
+  if (!n) return GN_OK;
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps);
+  return check_launch("adam");
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight layout helpers: conv transpose, width-2 Conv2D fold/unfold
+// ---------------------------------------------------------------------------------------------
+__global__ void transpose_w_kernel(const float* __restrict__ w, float* __restrict__ wt, int k, int Cin, int Cout) {
+  __shared__ float tile[32][33];
+  const int j = blockIdx.z;
+  const int c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, n = n0 + tx;
+    tile[r][tx] = (c < Cin && n < Cout) ? w[((size_t)j * Cin + c) * Cout + n] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r, c = c0 + tx;
+    if (n < Cout && c < Cin) wt[((size_t)j * Cout + n) * Cin + c] = tile[tx][r];
+  }
+}
+int transpose_w(const float* w, float* wt, int k, int Cin, int Cout, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_w_kernel, dim3(cdiv(Cout, 32), cdiv(Cin, 32), k), dim3(256), 0, s, w, wt, k, Cin, Cout);
+  return check_launch("transpose_w");
+}
+
+__global__ void conv2d_w2_fold_kernel(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ wf, float* __restrict__ bf, int kh, int Cin, int Cout) {
+  const size_t total = (size_t)kh * 2 * Cin * 2 * Cout, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int co = (int)(i % (2 * Cout));
+    const int ci = (int)((i / (2 * Cout)) % (2 * Cin));
+    const int h = (int)(i / ((size_t)4 * Cin * Cout));
+    const int wo = co / Cout, c2 = co % Cout, wi = ci / Cin, c = ci % Cin;
+    wf[i] = w[(((size_t)h * 5 + (wi - wo + 2)) * Cin + c) * Cout + c2];
+  }
+  if (bias && blockIdx.x == 0)
+    for (int o = threadIdx.x; o < 2 * Cout; o += blockDim.x) bf[o] = bias[o % Cout];
+}
+__global__ void conv2d_w2_unfold_kernel(const float* __restrict__ dwf, const float* __restrict__ dbf, float* __restrict__ dw, float* __restrict__ db, int kh, int Cin, int Cout) {
+  const size_t total = (size_t)kh * 5 * Cin * Cout, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c2 = (int)(i % Cout);
+    const int c = (int)((i / Cout) % Cin);
+    const int kw = (int)((i / ((size_t)Cin * Cout)) % 5);
+    const int h = (int)(i / ((size_t)5 * Cin * Cout));
+    float s = 0.f;
+    for (int wi = 0; wi < 2; ++wi) {
+      const int wo = wi + 2 - kw;
+      if (wo < 0 || wo > 1) continue;
+      s += dwf[((size_t)h * 2 * Cin + wi * Cin + c) * (2 * Cout) + wo * Cout + c2];
+    }
+    dw[i] = s;
+  }
+  if (db && blockIdx.x == 0)
+    for (int o = threadIdx.x; o < Cout; o += blockDim.x) db[o] = dbf[o] + dbf[Cout + o];
+}
+int conv2d_w2_fold(const float* w, const float* bias, float* wf, float* bf, int kh, int Cin, int Cout, hipStream_t s) {
+  hipLaunchKernelGGL(conv2d_w2_fold_kernel, dim3(stream_grid((size_t)kh * 4 * Cin * Cout)), dim3(256), 0, s, w, bias, wf, bf, kh, Cin, Cout);
+  return check_launch("conv2d_w2_fold");
+}
+int conv2d_w2_unfold(const float* dwf, const float* dbf, float* dw, float* db, int kh, int Cin, int Cout, hipStream_t s) {
+  hipLaunchKernelGGL(conv2d_w2_unfold_kernel, dim3(stream_grid((size_t)kh * 5 * Cin * Cout)), dim3(256), 0, s, dwf, dbf, dw, db, kh, Cin, Cout);
+  return check_launch("conv2d_w2_unfold");
+}
+
+}  // namespace gn

@@ -1,0 +1,417 @@
+// HBM-bound convolution edge cases that do not belong on the matrix cores:
+//   * small-Cin (1..4 input channels): first layers of the point-estimator (bbhMahoGANy.py:362,:382), the folded first
+//     discriminator Conv2D (:439, Cin' = 2), and the data gradient of the generator's Cout=1 output conv (:292).
+//     Write-bound: each thread keeps its weights in registers and streams float4 outputs.
+//   * small-Cout (1..4 output channels): generator output conv (:292) and the data gradient of the small-Cin layers.
+//     Read-bound: one wave per output row, lanes across channels, shuffle reduction.
+//   * flatten -> Dense(1) heads (:377,:399,:494): one 1024-thread block per sample.
+// All use the same generic tap description as conv_mfma.hip.
+#include "common.h"
+
+namespace gn {
+
+
+
+// ---------------------------------------------------------------------------------------------
+// small Cin: y[b, os*m+o0, n] = act(bias[n] + sum_j sum_c x[b, is*m+off_j, c] * w[widx_j, c, n]),  Cin <= 4, Cout % 4 == 0
+// block = 256 threads: NQc = min(Cout/4, 256) float4 columns x (256/NQc) row lanes; MT rows per block.
+// ---------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvArgs a, int m_tiles, int MT) {
+  constexpr int MAXT = 5;
+  const int NQ = a.Cout >> 2;
+  const int NQc = NQ < 256 ? NQ : 256;
+  const int RL = 256 / NQc;
+  const int tid = threadIdx.x;
+  const int q0 = tid % NQc, rl = tid / NQc;
+  const int m_tile = blockIdx.x % m_tiles, b = blockIdx.x / m_tiles;
+  const int m_lo = m_tile * MT, m_hi = min(a.M, m_lo + MT);
+  const float* xb = a.x + (size_t)b * a.Lin * CIN;
+  float* yb = a.y + (size_t)b * a.Ly * a.Cout;
+  if (rl >= RL) return;
+  for (int q = q0; q < NQ; q += NQc) {
+    float4 wv[MAXT][CIN];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+      for (int c = 0; c < CIN; ++c)
+        wv[j][c] = j < a.t.ntaps ? *reinterpret_cast<const float4*>(a.w + ((size_t)a.t.widx[j] * CIN + c) * a.Cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bias = *reinterpret_cast<const float4*>(a.bias + 4 * q);
+    for (int m = m_lo + rl; m < m_hi; m += RL) {
+      float4 s = bias;
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        if (j >= a.t.ntaps) break;
+        const int t = a.t.in_stride * m + a.t.off[j];
+        if (t < 0 || t >= a.Lin) continue;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+          const float xv = xb[(size_t)t * CIN + c];
+          s.x = fmaf(xv, wv[j][c].x, s.x); s.y = fmaf(xv, wv[j][c].y, s.y);
+          s.z = fmaf(xv, wv[j][c].z, s.z); s.w = fmaf(xv, wv[j][c].w, s.w);
+        }
+      }
+      s.x = act_apply(s.x, a.act, a.act_param); s.y = act_apply(s.y, a.act, a.act_param);
+      s.z = act_apply(s.z, a.act, a.act_param); s.w = act_apply(s.w, a.act, a.act_param);
+      *reinterpret_cast<float4*>(yb + (size_t)(a.t.out_stride * m + a.t.out_off) * a.Cout + 4 * q) = s;
+    }
+  }
+}
+
+int conv_smallcin_dispatch(const ConvArgs& a, hipStream_t s) {
+  if (a.Cin < 1 || a.Cin > 4 || a.Cout % 4 || a.t.ntaps > 5) {
+    set_error("conv_smallcin: Cin %d (1..4) / Cout %d (%%4) / ntaps %d (<=5) unsupported", a.Cin, a.Cout, a.t.ntaps);
+    return GN_EINVAL;
+  }
+  const int NQ = a.Cout / 4, NQc = NQ < 256 ? NQ : 256, RL = 256 / NQc;
+  const int MT = RL * 16;  // 16 rows per thread: amortises the register-resident weights
+  const int m_tiles = cdiv(a.M, MT);
+  const unsigned grid = (unsigned)m_tiles * a.B;
+  if (grid == 0) return GN_OK;
+  switch (a.Cin) {
+    case 1: hipLaunchKernelGGL(conv_smallcin_kernel<1>, dim3(grid), dim3(256), 0, s, a, m_tiles, MT); break;
+    case 2: hipLaunchKernelGGL(conv_smallcin_kernel<2>, dim3(grid), dim3(256), 0, s, a, m_tiles, MT); break;
+    case 3: hipLaunchKernelGGL(conv_smallcin_kernel<3>, dim3(grid), dim3(256), 0, s, a, m_tiles, MT); break;
+    default: hipLaunchKernelGGL(conv_smallcin_kernel<4>, dim3(grid), dim3(256), 0, s, a, m_tiles, MT); break;
+  }
+  return check_launch("conv_smallcin");
+}
+
+// ---------------------------------------------------------------------------------------------
+// small Cout: one wave per output row (b, m); lanes across Cin in float4 steps.  Cin % 4 == 0, Cout <= 4.
+// w layout [tap][Cin][Cout].
+// ---------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_smallcout_kernel(ConvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (size_t)a.B * a.M) return;
+  const int b = (int)(row / a.M), m = (int)(row % a.M);
+  const float* xb = a.x + (size_t)b * a.Lin * a.Cin;
+  float acc[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+  for (int j = 0; j < a.t.ntaps; ++j) {
+    const int t = a.t.in_stride * m + a.t.off[j];
+    if (t < 0 || t >= a.Lin) continue;
+    const float* xr = xb + (size_t)t * a.Cin;
+    const float* wj = a.w + (size_t)a.t.widx[j] * a.Cin * COUT;
+    for (int c = 4 * lane; c < a.Cin; c += 256) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+      if (COUT == 1) {
+        const float4 wv = *reinterpret_cast<const float4*>(wj + c);
+        acc[0] = fmaf(xv.x, wv.x, acc[0]); acc[0] = fmaf(xv.y, wv.y, acc[0]);
+        acc[0] = fmaf(xv.z, wv.z, acc[0]); acc[0] = fmaf(xv.w, wv.w, acc[0]);
+      } else {
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int o = 0; o < COUT; ++o) acc[o] = fmaf(xs[e], wj[(size_t)(c + e) * COUT + o], acc[o]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+    float v = acc[o];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
+    acc[o] = v;
+  }
+  if (lane == 0) {
+    float* yr = a.y + ((size_t)b * a.Ly + (size_t)(a.t.out_stride * m + a.t.out_off)) * COUT;
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) yr[o] = act_apply(acc[o] + (a.bias ? a.bias[o] : 0.f), a.act, a.act_param);
+  }
+}
+
+int conv_smallcout_dispatch(const ConvArgs& a, hipStream_t s) {
+  if (a.Cout < 1 || a.Cout > 4 || a.Cin % 4) {
+    set_error("conv_smallcout: Cout %d (1..4) / Cin %d (%%4) unsupported", a.Cout, a.Cin);
+    return GN_EINVAL;
+  }
+  const size_t rows = (size_t)a.B * a.M;
+  if (rows == 0) return GN_OK;
+  const unsigned grid = cdiv(rows, 4);
+  switch (a.Cout) {
+    case 1: hipLaunchKernelGGL(conv_smallcout_kernel<1>, dim3(grid), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(conv_smallcout_kernel<2>, dim3(grid), dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(conv_smallcout_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(conv_smallcout_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;
+  }
+  return check_launch("conv_smallcout");
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient when Cin or Cout is tiny: dw[j, c, n] = sum_{b,m} x[b, is*m+off_j, c] * dy[b, m, n]
+// (ntaps*CS) scalar-by-row products per row, CS = the small side.  Grid: (column blocks, row chunks); each thread owns
+// one float4 column group of the LARGE side and accumulates ntaps*CS float4 sums over its rows; row lanes reduced
+// through LDS; partials [chunk][ntaps*CS][Clarge] summed by the caller-visible reduce (fixed order).
+//   SMALL_IS_IN = true : x has CS channels (small Cin), dy has Clarge = Cout channels -> dw[j][c][n]
+//   SMALL_IS_IN = false: dy has CS channels (small Cout), x has Clarge = Cin channels -> dw[j][n][c]
+// ---------------------------------------------------------------------------------------------
+
+template <int CS, bool SMALL_IS_IN>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(WgradSmallArgs a) {
+  constexpr int MAXT = 5;
+  const int CL = SMALL_IS_IN ? a.Cout : a.Cin;
+  const int NQ = CL >> 2;
+  const int NQc = NQ < 256 ? NQ : 256;
+  const int RL = 256 / NQc;
+  const int tid = threadIdx.x;
+  const int ql = tid % NQc, rl = tid / NQc;
+  const int q = blockIdx.x * NQc + ql;
+  const bool active = (rl < RL) && (q < NQ);
+  float4 acc[MAXT][CS];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+    for (int c = 0; c < CS; ++c) acc[j][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const size_t rows = (size_t)a.B * a.M;
+  const size_t r_lo = (size_t)blockIdx.y * a.rows_per_chunk;
+  const size_t r_hi = r_lo + a.rows_per_chunk < rows ? r_lo + a.rows_per_chunk : rows;
+  if (active) {
+    for (size_t r = r_lo + rl; r < r_hi; r += RL) {
+      const int b = (int)(r / a.M), m = (int)(r % a.M);
+      if (SMALL_IS_IN) {
+        const float4 g = *reinterpret_cast<const float4*>(a.dy + r * a.Cout + 4 * q);
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) {
+          if (j >= a.ntaps) break;
+          const int t = a.in_stride * m + a.off[j];
+          if (t < 0 || t >= a.Lin) continue;
+#pragma unroll
+          for (int c = 0; c < CS; ++c) {
+            const float xv = a.x[((size_t)b * a.Lin + t) * CS + c];
+            acc[j][c].x = fmaf(xv, g.x, acc[j][c].x); acc[j][c].y = fmaf(xv, g.y, acc[j][c].y);
+            acc[j][c].z = fmaf(xv, g.z, acc[j][c].z); acc[j][c].w = fmaf(xv, g.w, acc[j][c].w);
+          }
+        }
+      } else {
+        float gs[CS];
+#pragma unroll
+        for (int c = 0; c < CS; ++c) gs[c] = a.dy[r * CS + c];
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) {
+          if (j >= a.ntaps) break;
+          const int t = a.in_stride * m + a.off[j];
+          if (t < 0 || t >= a.Lin) continue;
+          const float4 xv = *reinterpret_cast<const float4*>(a.x + ((size_t)b * a.Lin + t) * a.Cin + 4 * q);
+#pragma unroll
+          for (int c = 0; c < CS; ++c) {
+            acc[j][c].x = fmaf(xv.x, gs[c], acc[j][c].x); acc[j][c].y = fmaf(xv.y, gs[c], acc[j][c].y);
+            acc[j][c].z = fmaf(xv.z, gs[c], acc[j][c].z); acc[j][c].w = fmaf(xv.w, gs[c], acc[j][c].w);
+          }
+        }
+      }
+    }
+  }
+  // reduce the RL row lanes through LDS (one (j,c) pair at a time keeps LDS at 4 KiB)
+  __shared__ float4 red[256];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    if (j >= a.ntaps) break;
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+      red[tid] = acc[j][c];
+      __syncthreads();
+      if (rl == 0 && q < NQ) {
+        float4 s = red[ql];
+        for (int k = 1; k < RL; ++k) {
+          const float4 v = red[k * NQc + ql];
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float* pc = a.part + (size_t)blockIdx.y * a.ntaps * a.Cin * a.Cout;
+        if (SMALL_IS_IN) {
+          *reinterpret_cast<float4*>(pc + ((size_t)j * CS + c) * a.Cout + 4 * q) = s;      // dw[j][c][n]
+        } else {
+          float* d = pc + ((size_t)j * a.Cin + 4 * q) * CS + c;                            // dw[j][n=cin][c=cout]
+          d[0] = s.x; d[CS] = s.y; d[2 * CS] = s.z; d[3 * CS] = s.w;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+static int wgrad_small_chunks(size_t rows, int CL) {
+  const int NQ = CL / 4, NQc = NQ < 256 ? NQ : 256, RL = 256 / NQc;
+  const int gx = (NQ + NQc - 1) / NQc;
+  int chunks = (1024 + gx - 1) / gx;
+  const size_t max_chunks = (rows + (size_t)RL * 8 - 1) / ((size_t)RL * 8);
+  if ((size_t)chunks > max_chunks) chunks = (int)max_chunks;
+  if (chunks < 1) chunks = 1;
+  return chunks;
+}
+
+size_t wgrad_small_workspace_bytes(int B, int M, int Cin, int Cout, int ntaps) {
+  const int CL = Cin <= 4 ? Cout : Cin;
+  return (size_t)wgrad_small_chunks((size_t)B * M, CL) * ntaps * Cin * Cout * sizeof(float);
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int chunks) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = part[i];
+  for (int k = 1; k < chunks; ++k) s += part[(size_t)k * n + i];
+  out[i] = s;
+}
+
+int wgrad_small_dispatch(WgradSmallArgs a, float* dw, size_t ws_bytes, hipStream_t s) {
+  const bool small_in = a.Cin <= 4;
+  const int CS = small_in ? a.Cin : a.Cout, CL = small_in ? a.Cout : a.Cin;
+  if (CS < 1 || CS > 4 || CL % 4 || a.ntaps > 5) {
+    set_error("wgrad_small: Cin %d Cout %d ntaps %d unsupported", a.Cin, a.Cout, a.ntaps);
+    return GN_EINVAL;
+  }
+  const size_t rows = (size_t)a.B * a.M;
+  const int chunks = wgrad_small_chunks(rows, CL);
+  if (ws_bytes < (size_t)chunks * a.ntaps * a.Cin * a.Cout * sizeof(float)) {
+    set_error("wgrad_small: workspace too small");
+    return GN_EWORKSPACE;
+  }
+  a.rows_per_chunk = (int)((rows + chunks - 1) / chunks);
+  const int NQ = CL / 4, NQc = NQ < 256 ? NQ : 256;
+  dim3 grid((NQ + NQc - 1) / NQc, chunks);
+#define GN_WS(CSV)                                                                                            \
+  if (small_in) hipLaunchKernelGGL((wgrad_small_kernel<CSV, true>), grid, dim3(256), 0, s, a);                \
+  else hipLaunchKernelGGL((wgrad_small_kernel<CSV, false>), grid, dim3(256), 0, s, a);
+  switch (CS) {
+    case 1: GN_WS(1); break;
+    case 2: GN_WS(2); break;
+    case 3: GN_WS(3); break;
+    default: GN_WS(4); break;
+  }
+#undef GN_WS
+  int rc = check_launch("wgrad_small");
+  if (rc) return rc;
+  const size_t n = (size_t)a.ntaps * a.Cin * a.Cout;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a.part, dw, n, chunks);
+  return check_launch("wgrad_small_reduce");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense with a tiny output (flatten -> Dense(1)):  y[b,o] = act(bias[o] + sum_i x[b,i] w[i,o]),  out <= 4
+// one 1024-thread block per sample; w is L2-resident across blocks.
+// ---------------------------------------------------------------------------------------------
+template <int OUT>
+__global__ __launch_bounds__(1024) void dense_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ y, int in, int act, float act_param) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* xb = x + (size_t)b * in;
+  float acc[OUT];
+#pragma unroll
+  for (int o = 0; o < OUT; ++o) acc[o] = 0.f;
+  for (int i = 4 * tid; i < in; i += 4096) {
+    const float4 xv = *reinterpret_cast<const float4*>(xb + i);
+    if (OUT == 1) {
+      const float4 wv = *reinterpret_cast<const float4*>(w + i);
+      acc[0] = fmaf(xv.x, wv.x, acc[0]); acc[0] = fmaf(xv.y, wv.y, acc[0]);
+      acc[0] = fmaf(xv.z, wv.z, acc[0]); acc[0] = fmaf(xv.w, wv.w, acc[0]);
+    } else {
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) acc[o] = fmaf(xs[e], w[(size_t)(i + e) * OUT + o], acc[o]);
+    }
+  }
+  __shared__ float red[16][OUT];
+#pragma unroll
+  for (int o = 0; o < OUT; ++o) {
+    float v = acc[o];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
+    if ((tid & 63) == 0) red[tid >> 6][o] = v;
+  }
+  __syncthreads();
+  if (tid < OUT) {
+    float v = 0.f;
+    for (int k = 0; k < 16; ++k) v += red[k][tid];
+    y[(size_t)b * OUT + tid] = act_apply(v + (bias ? bias[tid] : 0.f), act, act_param);
+  }
+}
+
+int dense_small_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in, int out, int act, float p, hipStream_t s) {
+  if (out < 1 || out > 4 || in % 4) {
+    set_error("dense_small_fwd: out %d (1..4) / in %d (%%4) unsupported", out, in);
+    return GN_EINVAL;
+  }
+  if (B == 0) return GN_OK;
+  switch (out) {
+    case 1: hipLaunchKernelGGL(dense_small_fwd_kernel<1>, dim3(B), dim3(1024), 0, s, x, w, bias, y, in, act, p); break;
+    case 2: hipLaunchKernelGGL(dense_small_fwd_kernel<2>, dim3(B), dim3(1024), 0, s, x, w, bias, y, in, act, p); break;
+    case 3: hipLaunchKernelGGL(dense_small_fwd_kernel<3>, dim3(B), dim3(1024), 0, s, x, w, bias, y, in, act, p); break;
+    default: hipLaunchKernelGGL(dense_small_fwd_kernel<4>, dim3(B), dim3(1024), 0, s, x, w, bias, y, in, act, p); break;
+  }
+  return check_launch("dense_small_fwd");
+}
+
+// dw[i,o] = sum_b x[b,i] dy[b,o];  dx[b,i] = sum_o dy[b,o] w[i,o];  one thread per 4 input features, loop over b.
+template <int OUT>
+__global__ __launch_bounds__(256) void dense_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+                                                              float* __restrict__ dx, float* __restrict__ dw, int B, int in) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= (size_t)in) return;
+  float wv[4][OUT], acc[4][OUT];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) {
+      wv[e][o] = w[(i + e) * OUT + o];
+      acc[e][o] = 0.f;
+    }
+  for (int b = 0; b < B; ++b) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)b * in + i);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    float g[OUT];
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) g[o] = dy[(size_t)b * OUT + o];
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int o = 0; o < OUT; ++o) {
+        acc[e][o] = fmaf(xs[e], g[o], acc[e][o]);
+        d[e] = fmaf(g[o], wv[e][o], d[e]);
+      }
+    if (dx) *reinterpret_cast<float4*>(dx + (size_t)b * in + i) = make_float4(d[0], d[1], d[2], d[3]);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) dw[(i + e) * OUT + o] = acc[e][o];
+}
+
+__global__ void colsum_small_kernel(const float* __restrict__ dy, float* __restrict__ db, int B, int out) {
+  const int o = threadIdx.x;
+  if (o >= out) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += dy[(size_t)b * out + o];
+  db[o] = s;
+}
+
+int dense_small_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int in, int out, hipStream_t s) {
+  if (out < 1 || out > 4 || in % 4) {
+    set_error("dense_small_bwd: out %d (1..4) / in %d (%%4) unsupported", out, in);
+    return GN_EINVAL;
+  }
+  const unsigned grid = cdiv((size_t)in / 4, 256);
+  switch (out) {
+    case 1: hipLaunchKernelGGL(dense_small_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, x, w, dy, dx, dw, B, in); break;
+    case 2: hipLaunchKernelGGL(dense_small_bwd_kernel<2>, dim3(grid), dim3(256), 0, s, x, w, dy, dx, dw, B, in); break;
+    case 3: hipLaunchKernelGGL(dense_small_bwd_kernel<3>, dim3(grid), dim3(256), 0, s, x, w, dy, dx, dw, B, in); break;
+    default: hipLaunchKernelGGL(dense_small_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, x, w, dy, dx, dw, B, in); break;
+  }
+  int rc = check_launch("dense_small_bwd");
+  if (rc) return rc;
+  if (db) {
+    hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(64), 0, s, dy, db, B, out);
+    rc = check_launch("colsum_small");
+  }
+  return rc;
+}
+
+}  // namespace gn

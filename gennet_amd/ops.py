@@ -1,0 +1,315 @@
+"""Thin tensor-level wrappers over the C ABI: torch supplies device memory and the current HIP stream, nothing else.
+
+Every function takes / returns contiguous fp32 CUDA tensors in Keras channels-last layout and launches on
+torch's current stream.  No function here computes anything itself.
+"""
+import torch
+
+from . import _lib
+
+ACT = {'linear': 0, None: 0, 'relu': 1, 'relu_max': 2, 'leaky': 3, 'tanh': 4, 'sigmoid': 5}
+
+_ws = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.GennetHipError('gennet_amd ops need CUDA (HIP) tensors; got a %s tensor -- there is no CPU path' % t.device)
+        if not t.is_contiguous():
+            raise ValueError('non-contiguous tensor passed to a gennet_amd op')
+
+
+def workspace(nbytes, device):
+    """Stream-ordered scratch, grown on demand and reused (all ops run on one stream per process)."""
+    key = (device.type, device.index)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def same_pad(L, k, s):
+    """TF 'SAME': out = ceil(L/s); pad_total = max((out-1)*s + k - L, 0); left = total // 2."""
+    out = -(-L // s)
+    tot = max((out - 1) * s + k - L, 0)
+    return out, tot // 2
+
+
+def conv_geometry(L, k, stride, padding):
+    if padding == 'same':
+        return same_pad(L, k, stride)
+    if padding == 'valid':
+        return (L - k) // stride + 1, 0
+    raise ValueError('padding %r' % (padding,))
+
+
+# ---------------------------------------------------------------------------------------------- conv / dense
+def conv1d_fwd(x, w, b, stride, pad_left, Lout, act='linear', act_param=0.0):
+    _chk(x, w, b)
+    B, L, Cin = x.shape
+    k, _, Cout = w.shape
+    y = torch.empty((B, Lout, Cout), dtype=torch.float32, device=x.device)
+    _lib.call('gn_conv1d_fwd', _p(x), _p(w), _p(b), _p(y), B, L, Cin, Cout, k, stride, pad_left, Lout, ACT[act], float(act_param), _stream())
+    return y
+
+
+def conv1d_transpose_w(w):
+    _chk(w)
+    k, Cin, Cout = w.shape
+    wt = torch.empty((k, Cout, Cin), dtype=torch.float32, device=w.device)
+    _lib.call('gn_conv1d_transpose_w', _p(w), _p(wt), k, Cin, Cout, _stream())
+    return wt
+
+
+def conv1d_dgrad(dy, wt, L, stride, pad_left):
+    _chk(dy, wt)
+    B, Lout, Cout = dy.shape
+    k, _, Cin = wt.shape
+    dx = torch.empty((B, L, Cin), dtype=torch.float32, device=dy.device)
+    _lib.call('gn_conv1d_dgrad', _p(dy), _p(wt), _p(dx), B, L, Cin, Cout, k, stride, pad_left, Lout, _stream())
+    return dx
+
+
+def conv1d_wgrad(x, dy, k, stride, pad_left, dw=None, db=None):
+    _chk(x, dy, dw, db)
+    B, L, Cin = x.shape
+    _, Lout, Cout = dy.shape
+    if dw is None:
+        dw = torch.empty((k, Cin, Cout), dtype=torch.float32, device=x.device)
+    if db is None:
+        db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    nb = _lib.size('gn_conv1d_wgrad_workspace', B, L, Cin, Cout, k, stride, Lout)
+    ws = workspace(nb, x.device)
+    _lib.call('gn_conv1d_wgrad', _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws.numel(), B, L, Cin, Cout, k, stride, pad_left, Lout, _stream())
+    return dw, db
+
+
+def conv2d_w2_fold(w, b):
+    _chk(w, b)
+    kh, kw, Cin, Cout = w.shape
+    assert kw == 5
+    wf = torch.empty((kh, 2 * Cin, 2 * Cout), dtype=torch.float32, device=w.device)
+    bf = torch.empty((2 * Cout,), dtype=torch.float32, device=w.device)
+    _lib.call('gn_conv2d_w2_fold', _p(w), _p(b), _p(wf), _p(bf), kh, Cin, Cout, _stream())
+    return wf, bf
+
+
+def conv2d_w2_unfold_grad(dwf, dbf, Cin, Cout, dw=None, db=None):
+    _chk(dwf, dbf, dw, db)
+    kh = dwf.shape[0]
+    if dw is None:
+        dw = torch.empty((kh, 5, Cin, Cout), dtype=torch.float32, device=dwf.device)
+    if db is None:
+        db = torch.empty((Cout,), dtype=torch.float32, device=dwf.device)
+    _lib.call('gn_conv2d_w2_unfold_grad', _p(dwf), _p(dbf), _p(dw), _p(db), kh, Cin, Cout, _stream())
+    return dw, db
+
+
+def dense_fwd(x, w, b, act='linear', act_param=0.0):
+    _chk(x, w, b)
+    B, n_in = x.shape
+    n_out = w.shape[1]
+    y = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
+    _lib.call('gn_dense_fwd', _p(x), _p(w), _p(b), _p(y), B, n_in, n_out, ACT[act], float(act_param), _stream())
+    return y
+
+
+def dense_bwd(x, w, dy, need_dx=True, dw=None, db=None):
+    _chk(x, w, dy, dw, db)
+    B, n_in = x.shape
+    n_out = w.shape[1]
+    dx = torch.empty_like(x) if need_dx else None
+    if dw is None:
+        dw = torch.empty_like(w)
+    if db is None:
+        db = torch.empty((n_out,), dtype=torch.float32, device=x.device)
+    nb = _lib.size('gn_dense_bwd_workspace', B, n_in, n_out)
+    ws = workspace(nb, x.device)
+    _lib.call('gn_dense_bwd', _p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), _p(ws), ws.numel(), B, n_in, n_out, _stream())
+    return dx, dw, db
+
+
+# ---------------------------------------------------------------------------------------------- elementwise
+def act_fwd(x, act, act_param=0.0):
+    _chk(x)
+    y = torch.empty_like(x)
+    _lib.call('gn_act_fwd', _p(x), _p(y), x.numel(), ACT[act], float(act_param), _stream())
+    return y
+
+
+def act_bwd(dy, y, act, act_param=0.0, inplace=False):
+    _chk(dy, y)
+    dx = dy if inplace else torch.empty_like(dy)
+    _lib.call('gn_act_bwd', _p(dy), _p(y), _p(dx), dy.numel(), ACT[act], float(act_param), _stream())
+    return dx
+
+
+def dropout_mask(shape, rate, seed, offset, device):
+    m = torch.empty(shape, dtype=torch.uint8, device=device)
+    _lib.call('gn_dropout_mask', _p(m), m.numel(), float(rate), int(seed), int(offset), _stream())
+    return m
+
+
+def dropout_apply(x, mask, rate):
+    _chk(x, mask)
+    y = torch.empty_like(x)
+    _lib.call('gn_dropout_apply', _p(x), _p(mask), _p(y), x.numel(), float(rate), _stream())
+    return y
+
+
+def upsample2_fwd(x):
+    _chk(x)
+    B, L, Cc = x.shape
+    y = torch.empty((B, 2 * L, Cc), dtype=torch.float32, device=x.device)
+    _lib.call('gn_upsample2_fwd', _p(x), _p(y), B, L, Cc, _stream())
+    return y
+
+
+def upsample2_bwd(dy):
+    _chk(dy)
+    B, L2, Cc = dy.shape
+    dx = torch.empty((B, L2 // 2, Cc), dtype=torch.float32, device=dy.device)
+    _lib.call('gn_upsample2_bwd', _p(dy), _p(dx), B, L2 // 2, Cc, _stream())
+    return dx
+
+
+def subtract_stack_fwd(x, event):
+    _chk(x, event)
+    B, n = x.shape[0], x.shape[1]
+    img = torch.empty((B, n, 2, 1), dtype=torch.float32, device=x.device)
+    _lib.call('gn_subtract_stack_fwd', _p(x), _p(event), _p(img), B, n, _stream())
+    return img
+
+
+def subtract_stack_bwd(dimg):
+    _chk(dimg)
+    B, n = dimg.shape[0], dimg.shape[1]
+    dx = torch.empty((B, n, 1), dtype=torch.float32, device=dimg.device)
+    _lib.call('gn_subtract_stack_bwd', _p(dimg), _p(dx), B, n, _stream())
+    return dx
+
+
+def fill_uniform(shape, lo, hi, seed, offset, device):
+    t = torch.empty(shape, dtype=torch.float32, device=device)
+    _lib.call('gn_fill_uniform', _p(t), t.numel(), float(lo), float(hi), int(seed), int(offset), _stream())
+    return t
+
+
+def fill_normal(shape, mean, std, seed, offset, device):
+    t = torch.empty(shape, dtype=torch.float32, device=device)
+    _lib.call('gn_fill_normal', _p(t), t.numel(), float(mean), float(std), int(seed), int(offset), _stream())
+    return t
+
+
+def gather_rows(src, idx):
+    _chk(src, idx)
+    rows, width = idx.numel(), src.shape[1]
+    out = torch.empty((rows, width), dtype=torch.float32, device=src.device)
+    _lib.call('gn_gather_rows', _p(src), _p(idx), _p(out), rows, width, _stream())
+    return out
+
+
+def axpy(y, x, a):
+    _chk(y, x)
+    _lib.call('gn_axpy', _p(y), _p(x), float(a), y.numel(), _stream())
+    return y
+
+
+# ---------------------------------------------------------------------------------------------- batch norm
+def bn_stats(x2d):
+    """x2d: (rows, C) view.  Returns fp64 sums tensor (2*C,): [sum x | sum x^2]."""
+    _chk(x2d)
+    rows, Cc = x2d.shape
+    sums = torch.empty((2 * Cc,), dtype=torch.float64, device=x2d.device)
+    nb = _lib.size('gn_bn_stats_workspace', rows, Cc)
+    ws = workspace(nb, x2d.device)
+    _lib.call('gn_bn_stats', _p(x2d), rows, Cc, _p(sums), _p(ws), ws.numel(), _stream())
+    return sums
+
+
+def bn_finalize(sums, count, gamma, beta, eps, momentum, moving_mean, moving_var):
+    Cc = gamma.numel()
+    dev = gamma.device
+    scale, shift, smean, sinv = (torch.empty((Cc,), dtype=torch.float32, device=dev) for _ in range(4))
+    _lib.call('gn_bn_finalize', _p(sums), float(count), _p(gamma), _p(beta), float(eps), float(momentum), _p(moving_mean), _p(moving_var),
+              _p(scale), _p(shift), _p(smean), _p(sinv), Cc, _stream())
+    return scale, shift, smean, sinv
+
+
+def bn_infer_coeffs(gamma, beta, moving_mean, moving_var, eps):
+    Cc = gamma.numel()
+    scale, shift = (torch.empty((Cc,), dtype=torch.float32, device=gamma.device) for _ in range(2))
+    _lib.call('gn_bn_infer_coeffs', _p(gamma), _p(beta), _p(moving_mean), _p(moving_var), float(eps), _p(scale), _p(shift), Cc, _stream())
+    return scale, shift
+
+
+def bn_apply(x2d, scale, shift, mask=None, act='linear', act_param=0.0, rate=0.0):
+    _chk(x2d, mask)
+    rows, Cc = x2d.shape
+    y = torch.empty_like(x2d)
+    _lib.call('gn_bn_apply', _p(x2d), _p(scale), _p(shift), _p(mask), _p(y), rows, Cc, ACT[act], float(act_param), float(rate), _stream())
+    return y
+
+
+def bn_bwd_stats(dy2d, y2d, x2d, mask, smean, sinv, act='linear', act_param=0.0, rate=0.0):
+    _chk(dy2d, y2d, x2d, mask)
+    rows, Cc = x2d.shape
+    dsums = torch.empty((2 * Cc,), dtype=torch.float64, device=x2d.device)
+    nb = _lib.size('gn_bn_stats_workspace', rows, Cc)
+    ws = workspace(nb, x2d.device)
+    _lib.call('gn_bn_bwd_stats', _p(dy2d), _p(y2d), _p(x2d), _p(mask), _p(smean), _p(sinv), _p(dsums), _p(ws), ws.numel(), rows, Cc,
+              ACT[act], float(act_param), float(rate), _stream())
+    return dsums
+
+
+def bn_bwd_apply(dy2d, y2d, x2d, mask, gamma, smean, sinv, dsums_global, count, dsums_local, dgamma, dbeta, act='linear', act_param=0.0, rate=0.0):
+    rows, Cc = x2d.shape
+    dx = torch.empty_like(x2d)
+    _lib.call('gn_bn_bwd_apply', _p(dy2d), _p(y2d), _p(x2d), _p(mask), _p(gamma), _p(smean), _p(sinv), _p(dsums_global), float(count),
+              _p(dsums_local), _p(dx), _p(dgamma), _p(dbeta), rows, Cc, ACT[act], float(act_param), float(rate), _stream())
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------- loss / optimizer
+def loss(kind, p, y, Bglobal=None):
+    """kind 'binary_crossentropy' | 'mean_squared_error'. p, y (B,1). Returns (dp, out[2] = [loss share, hit count])."""
+    _chk(p, y)
+    B = p.shape[0]
+    dp = torch.empty_like(p)
+    out = torch.empty((2,), dtype=torch.float32, device=p.device)
+    fn = {'binary_crossentropy': 'gn_bce_loss', 'mean_squared_error': 'gn_mse_loss'}[kind]
+    _lib.call(fn, _p(p), _p(y), _p(dp), _p(out), B, int(Bglobal or B), _stream())
+    return dp, out
+
+
+def adam_step(p, g, m, v, lr_t, b1, b2, eps):
+    _chk(p, g, m, v)
+    _lib.call('gn_adam_step', _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), float(b1), float(b2), float(eps), _stream())
+
+
+# ---------------------------------------------------------------------------------------------- profiling hooks
+def prof_enable(on=True):
+    _lib.call('gn_prof_enable', 1 if on else 0)
+
+
+def prof_reset():
+    _lib.call('gn_prof_reset')
+
+
+def prof_collect():
+    import ctypes
+    out = (ctypes.c_double * 3)()
+    _lib.call('gn_prof_collect', ctypes.cast(out, ctypes.c_void_p))
+    return {'launches': int(out[0]), 'ms': out[1], 'flop': out[2]}

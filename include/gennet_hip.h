@@ -1,0 +1,172 @@
+/*
+ * gennet_hip.h -- C ABI of libgennet_hip.so, the MI355X (gfx950) kernel library behind gennet_amd.
+ *
+ * The reference (hagabbar/GenNet, BBH_version/) has no native boundary of its own: every FLOP of its hot
+ * path runs inside Keras 2.2.4 / TensorFlow 1.12 ops and numpy.  Each entry point below therefore cites
+ * the reference call site whose arithmetic it replaces (file:line in /root/reference/BBH_version/), i.e.
+ * the TF kernel that `model.add(<Layer>)` / `train_on_batch` / `predict` would have dispatched.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM) unless the name ends in _host; buffers are caller-owned
+ *   - activations are channels-last fp32: (B, L, C) row-major, exactly Keras' layout
+ *   - Conv1D kernels (k, Cin, Cout), Dense kernels (in, out), Conv2D kernels (kh, kw, Cin, Cout)
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); no hidden syncs, no allocation
+ *   - return 0 on success, a negative GN_E* code on bad arguments or launch failure (no exceptions)
+ */
+#ifndef GENNET_HIP_H
+#define GENNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GN_OK 0
+#define GN_EINVAL (-1)   /* bad shape / unsupported configuration */
+#define GN_ELAUNCH (-2)  /* hipLaunch / runtime error (see gn_last_error) */
+#define GN_EWORKSPACE (-3) /* workspace too small */
+
+/* activation kinds (Activation('relu'|'tanh'|'sigmoid'|'linear'), LeakyReLU(alpha), ReLU(max_value)):
+ * bbhMahoGANy.py:238,254,...,293 (tanh/linear), :363-400 (relu, ReLU(max_value=1.0)), :440,448 (LeakyReLU 0.2), :495 (sigmoid) */
+enum gn_act { GN_ACT_LINEAR = 0, GN_ACT_RELU = 1, GN_ACT_RELU_MAX = 2, GN_ACT_LEAKY = 3, GN_ACT_TANH = 4, GN_ACT_SIGMOID = 5 };
+
+const char* gn_last_error(void);
+int gn_version(void);
+
+/* ---- Conv1D (bbhMahoGANy.py:250,259,267,275,283,292 generator; :362-371, :382-394 point-estimator; the
+ *      width-2 Conv2D of :439,:447 after gn_conv2d_w2_fold) ----------------------------------------------
+ * y[b,t,co] = act(bias[co] + sum_{k,ci} x[b, stride*t + k - pad_left, ci] * w[k,ci,co]), zero outside [0,L).
+ * Lout is the caller-computed output length (TF SAME/VALID rule).  bias may be NULL.
+ * Dispatches to the MFMA implicit-GEMM kernel (Cin >= 16), the small-Cin streaming kernel (Cin <= 4) or the
+ * small-Cout reduction kernel (Cout <= 4). */
+int gn_conv1d_fwd(const float* x, const float* w, const float* bias, float* y,
+                  int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout,
+                  int act, float act_param, void* stream);
+
+/* wt[k, co, ci] = w[k, ci, co]  (operand layout the dgrad GEMM consumes) */
+int gn_conv1d_transpose_w(const float* w, float* wt, int k, int Cin, int Cout, void* stream);
+
+/* dx[b,tau,ci] = sum_{k,co} dy[b,t,co] * w[k,ci,co] over stride*t + k - pad_left == tau.  wt from
+ * gn_conv1d_transpose_w.  (Backward of the call sites above; TF Conv2DBackpropInput.) */
+int gn_conv1d_dgrad(const float* dy, const float* wt, float* dx,
+                    int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout, void* stream);
+
+/* dw[k,ci,co] = sum_{b,t} x[b, stride*t + k - pad_left, ci] * dy[b,t,co];  db[co] = sum_{b,t} dy[b,t,co] (db may be NULL).
+ * ws: workspace of at least gn_conv1d_wgrad_workspace(...) bytes (split-K partial slabs, summed in a fixed order,
+ * so the result is bitwise reproducible).  (TF Conv2DBackpropFilter + BiasAddGrad.) */
+size_t gn_conv1d_wgrad_workspace(int B, int L, int Cin, int Cout, int k, int stride, int Lout);
+int gn_conv1d_wgrad(const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes,
+                    int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout, void* stream);
+
+/* ---- width-2 Conv2D fold (bbhMahoGANy.py:439,:447: Conv2D(C,(5,5),strides=(2,1),padding='same') on (n,2,Cin)) ----
+ * wf[kh, w*Cin+c, w2*Cout+c2] = w[kh, w-w2+2, c, c2];   biasf = [bias, bias]
+ * unfold_grad: dw[kh,kw,c,c2] = sum over the (w,w2) blocks with w-w2+2 == kw (0 for kw in {0,4}); db = dbf[:Cout]+dbf[Cout:] */
+int gn_conv2d_w2_fold(const float* w, const float* bias, float* wf, float* biasf, int kh, int Cin, int Cout, void* stream);
+int gn_conv2d_w2_unfold_grad(const float* dwf, const float* dbf, float* dw, float* db, int kh, int Cin, int Cout, void* stream);
+
+/* ---- Dense (bbhMahoGANy.py:234 generator 100 -> 256*n_pix/2; :377,:399,:494 flatten -> 1 heads) -------------
+ * y[b,o] = act(bias[o] + sum_i x[b,i] * w[i,o]).  Large `out` goes through the MFMA GEMM, out <= 4 through
+ * the streaming dot-product kernel. */
+int gn_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in, int out,
+                 int act, float act_param, void* stream);
+/* dw[i,o] = sum_b x[b,i]*dy[b,o]; db[o] = sum_b dy[b,o]; dx[b,i] = sum_o dy[b,o]*w[i,o] (dx may be NULL). */
+size_t gn_dense_bwd_workspace(int B, int in, int out);
+int gn_dense_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                 void* ws, size_t ws_bytes, int B, int in, int out, void* stream);
+
+/* ---- elementwise ----------------------------------------------------------------------------------------- */
+/* y = act(x) (Activation / LeakyReLU / ReLU layers when not fused into the producing kernel) */
+int gn_act_fwd(const float* x, float* y, size_t n, int act, float act_param, void* stream);
+/* dx = dy * act'(.) expressed through the activation OUTPUT y; in-place (dx == dy) allowed */
+int gn_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float act_param, void* stream);
+/* Dropout (bbhMahoGANy.py:239,255,...,288 rate 0.2; :443,:452 rate 0.4): keep-mask generation (Philox4x32-10,
+ * element i draws counter (offset + i/4), lane i%4; keep iff u >= rate) and application y = x*mask/(1-rate). */
+int gn_dropout_mask(uint8_t* mask, size_t n, float rate, uint64_t seed, uint64_t offset, void* stream);
+int gn_dropout_apply(const float* x, const uint8_t* mask, float* y, size_t n, float rate, void* stream);
+/* UpSampling1D(size=2) (bbhMahoGANy.py:249,:258) and its adjoint */
+int gn_upsample2_fwd(const float* x, float* y, int B, int L, int C, void* stream);
+int gn_upsample2_bwd(const float* dy, float* dx, int B, int L, int C, void* stream);
+/* MyLayer (bbhMahoGANy.py:180-184): img[b,t,0] = x[b,t]; img[b,t,1] = event[t] - x[b,t];  adjoint dx = d0 - d1 */
+int gn_subtract_stack_fwd(const float* x, const float* event, float* img, int B, int n, void* stream);
+int gn_subtract_stack_bwd(const float* dimg, float* dx, int B, int n, void* stream);
+/* uniform(lo,hi) and normal(mean,std) fills from Philox (host RNG replacement for bbhMahoGANy.py:1161,1247,1277,1295) */
+int gn_fill_uniform(float* out, size_t n, float lo, float hi, uint64_t seed, uint64_t offset, void* stream);
+int gn_fill_normal(float* out, size_t n, float mean, float std, uint64_t seed, uint64_t offset, void* stream);
+/* out[i,:] = src[idx[i],:] (random.sample batch gather, bbhMahoGANy.py:1156-1157, :1244) */
+int gn_gather_rows(const float* src, const int64_t* idx, float* out, int rows, int width, void* stream);
+/* y[i] += a * x[i] */
+int gn_axpy(float* y, const float* x, float a, size_t n, void* stream);
+
+/* ---- BatchNormalization(momentum=0.99) (bbhMahoGANy.py:235 over 256*n_pix/2 features; :251,...,:284 over channels) ----
+ * x is viewed as (rows, C).  Statistics are accumulated in fp64: sums[0:C] = sum x, sums[C:2C] = sum x^2.
+ * Between gn_bn_stats and gn_bn_finalize a data-parallel caller all-reduces `sums` (SyncBN). */
+size_t gn_bn_stats_workspace(size_t rows, int C);
+int gn_bn_stats(const float* x, size_t rows, int C, double* sums, void* ws, size_t ws_bytes, void* stream);
+/* mean = S1/n, var = S2/n - mean^2 (biased); scale = gamma/sqrt(var+eps), shift = beta - mean*scale;
+ * moving_mean = moving_mean*m + mean*(1-m); moving_var = moving_var*m + var*n/(n-(1+eps))*(1-m)  (keras 2.2.4).
+ * save_mean/save_invstd are kept for the backward pass. */
+int gn_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
+                   float* moving_mean, float* moving_var, float* scale, float* shift,
+                   float* save_mean, float* save_invstd, int C, void* stream);
+/* inference phase: scale/shift from the moving statistics */
+int gn_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                       float eps, float* scale, float* shift, int C, void* stream);
+/* y = dropout(act(x*scale[c] + shift[c])) in one pass; mask may be NULL (no dropout / inference) */
+int gn_bn_apply(const float* x, const float* scale, const float* shift, const uint8_t* mask, float* y,
+                size_t rows, int C, int act, float act_param, float rate, void* stream);
+/* backward pass 1: g = dy * mask/(1-rate) * act'(y/(mask scale)), xhat = (x-mean)*invstd;
+ * dsums[0:C] = sum g, dsums[C:2C] = sum g*xhat (fp64).  A data-parallel caller all-reduces dsums. */
+int gn_bn_bwd_stats(const float* dy, const float* y, const float* x, const uint8_t* mask,
+                    const float* save_mean, const float* save_invstd, double* dsums, void* ws, size_t ws_bytes,
+                    size_t rows, int C, int act, float act_param, float rate, void* stream);
+/* backward pass 2: dx = gamma*invstd*(g - dsum/n - xhat*dsum_xhat/n); dgamma = dsums_local[C:2C], dbeta = dsums_local[0:C] */
+int gn_bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8_t* mask,
+                    const float* gamma, const float* save_mean, const float* save_invstd,
+                    const double* dsums_global, double count, const double* dsums_local, float* dx, float* dgamma, float* dbeta,
+                    size_t rows, int C, int act, float act_param, float rate, void* stream);
+
+/* ---- losses + metric (compile(loss='binary_crossentropy'|'mean_squared_error', metrics=['accuracy']),
+ *      bbhMahoGANy.py:1101-1119) ---------------------------------------------------------------------------
+ * p, y: (B, 1).  out[0] = loss (mean over the local B rows scaled by B/Bglobal), out[1] = #rows with round(p)==y;
+ * dp = dLoss/dp with the mean taken over Bglobal rows (data-parallel ranks pass the global batch size). */
+int gn_bce_loss(const float* p, const float* y, float* dp, float* out, int B, int Bglobal, void* stream);
+int gn_mse_loss(const float* p, const float* y, float* dp, float* out, int B, int Bglobal, void* stream);
+
+/* ---- Adam, keras form (bbhMahoGANy.py:1101,1107,1115,1119: Adam(lr=9e-5, beta_1=0.5)) ---------------------
+ * m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (host). */
+int gn_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, void* stream);
+
+/* ---- profiling hooks used by bench.py: accumulate HIP-event time of every MFMA conv / wgrad launch ---------- */
+int gn_prof_enable(int on);
+int gn_prof_reset(void);
+/* sums over launches since reset: out[0] = launches, out[1] = total ms, out[2] = total algorithmic FLOP */
+int gn_prof_collect(double* out3_host);
+
+/* ---- template synthesiser (gw_template_maker.py) --------------------------------------------------------- */
+/* Closed-form frequency-domain IMR chirp (this library's own model, NOT LAL IMRPhenomPv2; replaces the call at
+ * gw_template_maker.py:507-516) fused with whiten_data(...,'fd') (:243-286, :518-519):
+ *   out_hp/out_hc[(b, f)] complex128 interleaved (re,im), Nf = N/2+1 bins, bin f <-> f*df; zero below f_low and at DC.
+ *   scale[f] = sqrt(2*invpsd[f]/fs) precomputed by the caller from the PSD (0 where psd <= 0). */
+int gn_chirp_fd_whitened(const double* m1, const double* m2, const double* scale, double* out_hp, double* out_hc,
+                         int nb, int Nf, double df, double f_low, double dist_mpc, double iota, double phi0, void* stream);
+/* Batched inverse real FFT, numpy.fft.irfft(X, n=N) semantics (1/N normalisation, imaginary parts of DC/Nyquist
+ * ignored): X (nb, N/2+1) complex128 -> out (nb, N) float64.  N a power of two, 16 <= N <= 16384. */
+int gn_irfft_f64(const double* X, double* out, int nb, int N, void* stream);
+/* gen_bbh alignment (gw_template_maker.py:521-565) for a batch: given hp, hc = irfft(...) (nb, N):
+ *   ref = argmax_n (hp^2+hc^2)[(n - fs) mod N-rolled]  (first maximum, as numpy.argmax after np.roll(.,-fs));
+ *   out[b, n] = g * (Fp*hp + Fc*hc)_rolled[ref - idx[b] - peak_off + crop0 + n], n in [0, crop_len), 0 past the end.
+ *   ref_out[b] receives ref. */
+int gn_align_crop(const double* hp, const double* hc, const int32_t* idx, double* out, int32_t* ref_out,
+                  int nb, int N, int roll, int crop0, int crop_len, int peak_off, double Fp, double Fc, double g, void* stream);
+/* gen_noise (gw_template_maker.py:161-193) spectrum: X[b,f] = amp[f]*(xi_re + i xi_im), DC = 0 (Philox normals, re block then im block) */
+int gn_noise_fd(const double* amp, double* X, int nb, int Nf, uint64_t seed, uint64_t offset, void* stream);
+/* x *= s (fp64), used for N*df and gw_norm_constant scalings; and fp64 -> fp32 narrowing with scale */
+int gn_scale_f64(double* x, double s, size_t n, void* stream);
+int gn_f64_to_f32(const double* x, float* y, double s, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENNET_HIP_H */

@@ -17,6 +17,10 @@ import numpy as np
 
 BN_EPS = 1e-3          # keras BatchNormalization default epsilon
 K_EPS = 1e-7           # keras.backend.epsilon()
+# TF evaluates the BCE clip bounds in the tensor dtype (float32): clip_by_value(p, eps32, 1 - eps32) with
+# 1 - eps32 == 0.99999988 (one fp32 ulp below 1), not 0.9999999.  Restated with those fp32 constants.
+CLIP_LO = float(np.float32(K_EPS))
+CLIP_HI = float(np.float32(1.0) - np.float32(K_EPS))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -259,11 +263,11 @@ def dropout_fwd(x, mask, rate):
 def bce_loss(p, y):
     """keras binary_crossentropy (TF backend, from probabilities). p,y: (B,1). Returns (loss, dL/dp)."""
     B = p.shape[0]
-    pc = np.clip(p, K_EPS, 1 - K_EPS)
+    pc = np.clip(p, CLIP_LO, CLIP_HI)
     z = np.log(pc / (1 - pc))
     per = np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z)))
     loss = per.mean(axis=-1).mean()
-    inside = (p >= K_EPS) & (p <= 1 - K_EPS)
+    inside = (p >= CLIP_LO) & (p <= CLIP_HI)
     dz = (1.0 / (1.0 + np.exp(-z)) - y) / (B * p.shape[-1])
     dp = np.where(inside, dz / (pc * (1 - pc)), 0.0)
     return loss, dp

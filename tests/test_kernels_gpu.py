@@ -1,0 +1,289 @@
+"""GPU parity: every C-ABI kernel against the fp64 numpy oracle on seeded inputs.
+
+Tolerances (fp32 kernels vs fp64 oracle, stated per check): `tol * sum|a||b|`-style bounds are expressed as a relative
+error against the max magnitude of the oracle output; 2e-5 covers K <= 2560-term fp32 fmaf chains
+(v_mfma_f32_32x32x2_f32 is an exact k-ordered fmaf chain, ~1e-7 * sum|a b|).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import keras_ref as K
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def g(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev())
+
+
+def close(t, ref, rtol=RTOL, atol=0.0):
+    a = t.detach().cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(a - ref).max()
+    assert err <= rtol * scale + atol, 'max err %.3e vs scale %.3e (rel %.3e)' % (err, scale, err / scale)
+
+
+def f32(a):
+    return np.asarray(a, np.float32).astype(np.float64)
+
+
+CONV_CASES = [
+    # B, L, Cin, Cout, k, stride, padding
+    (2, 64, 16, 128, 5, 1, 'same'),       # one tile, exact channels
+    (3, 133, 64, 128, 5, 1, 'valid'),     # ragged M tile
+    (2, 150, 64, 128, 5, 2, 'valid'),     # stride 2 (de-interleaved slab)
+    (2, 77, 32, 64, 5, 2, 'same'),        # narrow-N tile config
+    (1, 300, 48, 192, 5, 1, 'same'),      # Cout not a multiple of the N tile, Cin = 3 chunks
+    (2, 40, 20, 72, 5, 2, 'same'),        # Cin not a multiple of KC
+    (2, 96, 1, 64, 5, 2, 'same'),         # small-Cin (point-estimator first layer)
+    (2, 96, 1, 64, 5, 1, 'same'),
+    (3, 50, 2, 512, 5, 2, 'same'),        # folded discriminator first layer
+    (2, 64, 256, 1, 5, 1, 'same'),        # small-Cout (generator output conv)
+    (2, 64, 128, 2, 5, 2, 'same'),
+]
+
+
+@pytest.mark.parametrize("B,L,Cin,Cout,k,s,padding", CONV_CASES)
+def test_conv1d_fwd_dgrad_wgrad(B, L, Cin, Cout, k, s, padding):
+    from gennet_amd import ops
+    rng = np.random.RandomState(B * 1000 + L + Cin + Cout)
+    x = f32(rng.randn(B, L, Cin)); w = f32(rng.randn(k, Cin, Cout) / np.sqrt(k * Cin)); b = f32(rng.randn(Cout))
+    Lout, pl = ops.conv_geometry(L, k, s, padding)
+    y_ref = K.conv1d_fwd(x, w, b, s, padding)
+    assert y_ref.shape[1] == Lout
+    for act, p in (('linear', 0.0), ('relu', 0.0), ('leaky', 0.2), ('tanh', 0.0)):
+        y = ops.conv1d_fwd(g(x), g(w), g(b), s, pl, Lout, act, p)
+        close(y, K.act_fwd(y_ref, act, p))
+    dy = f32(rng.randn(B, Lout, Cout))
+    dx_ref, dw_ref, db_ref = K.conv1d_bwd(x, w, dy, s, padding)
+    wt = ops.conv1d_transpose_w(g(w))
+    close(wt, np.transpose(w, (0, 2, 1)), 0.0)
+    dx = ops.conv1d_dgrad(g(dy), wt, L, s, pl)
+    close(dx, dx_ref)
+    dw, db = ops.conv1d_wgrad(g(x), g(dy), k, s, pl)
+    close(dw, dw_ref, 5e-5)
+    close(db, db_ref, 5e-5)
+
+
+def test_conv1d_mfma_exact_integers():
+    """A = small integers, B asymmetric integers: fp32 MFMA must be bit-exact (catches row/col swaps, tap mix-ups)."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(7)
+    B, L, Cin, Cout, k = 2, 140, 32, 128, 5
+    x = rng.randint(-3, 4, (B, L, Cin)).astype(np.float64)
+    w = rng.randint(-2, 3, (k, Cin, Cout)).astype(np.float64) + np.arange(Cout)[None, None, :] % 3
+    for s, padding in ((1, 'same'), (2, 'valid')):
+        Lout, pl = ops.conv_geometry(L, k, s, padding)
+        y = ops.conv1d_fwd(g(x), g(w), None, s, pl, Lout)
+        assert np.array_equal(y.cpu().numpy().astype(np.float64), K.conv1d_fwd(x, w, None, s, padding))
+        dy = rng.randint(-2, 3, (B, Lout, Cout)).astype(np.float64)
+        dx_ref, dw_ref, _ = K.conv1d_bwd(x, w, dy, s, padding)
+        dx = ops.conv1d_dgrad(g(dy), ops.conv1d_transpose_w(g(w)), L, s, pl)
+        assert np.array_equal(dx.cpu().numpy().astype(np.float64), dx_ref)
+        dw, _ = ops.conv1d_wgrad(g(x), g(dy), k, s, pl)
+        assert np.array_equal(dw.cpu().numpy().astype(np.float64), dw_ref)
+
+
+def test_conv2d_width2_fold_matches_conv2d():
+    from gennet_amd import ops
+    rng = np.random.RandomState(11)
+    B, H, Cin, Cout = 2, 48, 16, 32
+    x = f32(rng.randn(B, H, 2, Cin)); w = f32(rng.randn(5, 5, Cin, Cout) * 0.1); b = f32(rng.randn(Cout))
+    y_ref = K.conv2d_fwd(x, w, b, (2, 1), 'same')
+    wf, bf = ops.conv2d_w2_fold(g(w), g(b))
+    close(wf, K.fold_conv2d_w2(w), 0.0)
+    Lout, pl = ops.conv_geometry(H, 5, 2, 'same')
+    y = ops.conv1d_fwd(g(x.reshape(B, H, 2 * Cin)), wf, bf, 2, pl, Lout)
+    close(y.reshape(B, Lout, 2, Cout), y_ref)
+    dy = f32(rng.randn(*y_ref.shape))
+    dx_ref, dw_ref, db_ref = K.conv2d_bwd(x, w, dy, (2, 1), 'same')
+    dyf = g(dy.reshape(B, Lout, 2 * Cout))
+    dwf, dbf = ops.conv1d_wgrad(g(x.reshape(B, H, 2 * Cin)), dyf, 5, 2, pl)
+    dw, db = ops.conv2d_w2_unfold_grad(dwf, dbf, Cin, Cout)
+    close(dw, dw_ref, 5e-5); close(db, db_ref, 5e-5)
+    dx = ops.conv1d_dgrad(dyf, ops.conv1d_transpose_w(wf), H, 2, pl)
+    close(dx.reshape(B, H, 2, Cin), dx_ref)
+
+
+@pytest.mark.parametrize("B,n_in,n_out", [(5, 100, 512), (130, 100, 1024), (4, 64, 260)])
+def test_dense_large_out(B, n_in, n_out):
+    from gennet_amd import ops
+    rng = np.random.RandomState(B + n_out)
+    x = f32(rng.uniform(-1, 1, (B, n_in))); w = f32(rng.randn(n_in, n_out) * 0.1); b = f32(rng.randn(n_out))
+    close(ops.dense_fwd(g(x), g(w), g(b)), K.dense_fwd(x, w, b))
+    dy = f32(rng.randn(B, n_out))
+    dx_ref, dw_ref, db_ref = K.dense_bwd(x, w, dy)
+    dx, dw, db = ops.dense_bwd(g(x), g(w), g(dy), need_dx=True)
+    close(dx, dx_ref); close(dw, dw_ref, 5e-5); close(db, db_ref, 5e-5)
+    dx2, dw2, _ = ops.dense_bwd(g(x), g(w), g(dy), need_dx=False)
+    assert dx2 is None
+    close(dw2, dw_ref, 5e-5)
+
+
+@pytest.mark.parametrize("B,n_in,act,p", [(3, 4096, 'relu', 0.0), (7, 5000, 'relu_max', 1.0), (2, 1024, 'sigmoid', 0.0)])
+def test_dense_head(B, n_in, act, p):
+    from gennet_amd import ops
+    rng = np.random.RandomState(n_in)
+    x = f32(rng.randn(B, n_in)); w = f32(rng.randn(n_in, 1) / np.sqrt(n_in)); b = f32([0.3])
+    y_ref = K.act_fwd(K.dense_fwd(x, w, b), act, p)
+    close(ops.dense_fwd(g(x), g(w), g(b), act, p), y_ref)
+    dy = f32(rng.randn(B, 1))
+    dx_ref, dw_ref, db_ref = K.dense_bwd(x, w, dy)
+    dx, dw, db = ops.dense_bwd(g(x), g(w), g(dy))
+    close(dx, dx_ref); close(dw, dw_ref); close(db, db_ref)
+
+
+@pytest.mark.parametrize("act,p", [('relu', 0.0), ('relu_max', 1.0), ('leaky', 0.2), ('tanh', 0.0), ('sigmoid', 0.0), ('linear', 0.0)])
+def test_activations(act, p):
+    from gennet_amd import ops
+    rng = np.random.RandomState(3)
+    x = f32(rng.randn(1003) * 2)
+    y = ops.act_fwd(g(x), act, p)
+    y_ref = K.act_fwd(x, act, p)
+    close(y, y_ref, 1e-6)
+    dy = f32(rng.randn(1003))
+    close(ops.act_bwd(g(dy), y, act, p), K.act_bwd(dy, y.cpu().numpy().astype(np.float64), act, p), 1e-6)
+
+
+def test_dropout_mask_and_apply():
+    from gennet_amd import ops
+    n = 1 << 20
+    m = ops.dropout_mask((n,), 0.4, 1234, 0, dev())
+    keep = m.float().mean().item()
+    assert abs(keep - 0.6) < 3e-3                      # 1M Bernoulli draws: sigma = 5e-4
+    m2 = ops.dropout_mask((n,), 0.4, 1234, 0, dev())
+    assert torch.equal(m, m2)                          # counter-based: reproducible
+    m3 = ops.dropout_mask((n,), 0.4, 1234, n // 4, dev())
+    assert not torch.equal(m, m3)
+    x = torch.randn(n, device=dev())
+    y = ops.dropout_apply(x, m, 0.4)
+    close(y, x.cpu().numpy().astype(np.float64) * m.cpu().numpy() / 0.6, 1e-6)
+
+
+def test_upsample_and_subtract_stack():
+    from gennet_amd import ops
+    rng = np.random.RandomState(5)
+    x = f32(rng.randn(3, 10, 8))
+    close(ops.upsample2_fwd(g(x)), K.upsample1d_fwd(x), 0.0)
+    dy = f32(rng.randn(3, 20, 8))
+    close(ops.upsample2_bwd(g(dy)), K.upsample1d_bwd(dy), 1e-6)
+    xs = f32(rng.randn(4, 33, 1)); ev = f32(rng.randn(33, 1))
+    close(ops.subtract_stack_fwd(g(xs), g(ev)), K.mylayer_fwd(xs, ev), 1e-7)
+    dimg = f32(rng.randn(4, 33, 2, 1))
+    close(ops.subtract_stack_bwd(g(dimg)), K.mylayer_bwd(dimg), 1e-6)
+
+
+@pytest.mark.parametrize("shape", [(6, 50, 64), (37, 4096), (512, 8, 128)])
+@pytest.mark.parametrize("with_drop", [False, True])
+def test_batchnorm_train_fwd_bwd(shape, with_drop):
+    """BN + tanh (+ dropout) fused apply against the oracle chain; channel-BN (3-D) and feature-BN (2-D)."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(shape[0])
+    Cc = shape[-1]
+    x = f32(rng.randn(*shape) * 1.5 + 0.7); gamma = f32(rng.rand(Cc) + 0.5); beta = f32(rng.randn(Cc) * 0.1)
+    rows = x.size // Cc
+    rate = 0.2 if with_drop else 0.0
+    mask = (rng.rand(*shape) >= rate).astype(np.uint8) if with_drop else None
+    y_bn, cache, mean, var = K.bn_train_fwd(x, gamma, beta)
+    y_act = np.tanh(y_bn)
+    y_ref = K.dropout_fwd(y_act, mask, rate) if with_drop else y_act
+    mm0, mv0 = f32(rng.randn(Cc) * 0.1), f32(rng.rand(Cc) + 0.5)
+    mm_ref, mv_ref = K.bn_moving_update(mm0, mv0, mean, var, rows, 0.99)
+
+    x2 = g(x).reshape(rows, Cc)
+    sums = ops.bn_stats(x2)
+    close(sums[:Cc], x.reshape(rows, Cc).sum(0), 1e-6, 1e-3)
+    mm, mv = g(mm0), g(mv0)
+    scale, shift, smean, sinv = ops.bn_finalize(sums, rows, g(gamma), g(beta), K.BN_EPS, 0.99, mm, mv)
+    close(smean, mean, 1e-5, 1e-6); close(mm, mm_ref, 1e-5); close(mv, mv_ref, 1e-5)
+    mt = torch.tensor(mask.reshape(rows, Cc), device=dev()) if with_drop else None
+    y = ops.bn_apply(x2, scale, shift, mt, 'tanh', 0.0, rate)
+    close(y, y_ref.reshape(rows, Cc), 2e-5)
+
+    dy = f32(rng.randn(*shape))
+    d_act = dy * mask / (1 - rate) if with_drop else dy
+    d_bn = K.act_bwd(d_act, y_act, 'tanh')
+    dx_ref, dg_ref, db_ref = K.bn_train_bwd(d_bn, cache, gamma)
+    dy2 = g(dy).reshape(rows, Cc)
+    dsums = ops.bn_bwd_stats(dy2, y, x2, mt, smean, sinv, 'tanh', 0.0, rate)
+    dgamma = torch.empty(Cc, device=dev()); dbeta = torch.empty(Cc, device=dev())
+    dx = ops.bn_bwd_apply(dy2, y, x2, mt, g(gamma), smean, sinv, dsums, rows, dsums, dgamma, dbeta, 'tanh', 0.0, rate)
+    close(dgamma, dg_ref, 1e-4); close(dbeta, db_ref, 1e-4)
+    close(dx, dx_ref.reshape(rows, Cc), 1e-4)
+
+
+def test_batchnorm_infer():
+    from gennet_amd import ops
+    rng = np.random.RandomState(9)
+    x = f32(rng.randn(4, 30, 64)); gamma = f32(rng.rand(64) + 0.5); beta = f32(rng.randn(64)); mm = f32(rng.randn(64)); mv = f32(rng.rand(64) + 0.1)
+    scale, shift = ops.bn_infer_coeffs(g(gamma), g(beta), g(mm), g(mv), K.BN_EPS)
+    y = ops.bn_apply(g(x).reshape(-1, 64), scale, shift, None, 'tanh')
+    close(y, np.tanh(K.bn_infer_fwd(x, gamma, beta, mm, mv)).reshape(-1, 64))
+
+
+def test_losses():
+    from gennet_amd import ops
+    rng = np.random.RandomState(13)
+    B = 300
+    p = f32(rng.rand(B, 1)); p[:3, 0] = [0.0, 1.0, 0.5]; y = (rng.rand(B, 1) > 0.5).astype(np.float64)
+    l_ref, dp_ref = K.bce_loss(p, y)
+    dp, out = ops.loss('binary_crossentropy', g(p), g(y))
+    o = out.cpu().numpy()
+    assert abs(o[0] - l_ref) <= 5e-6 * abs(l_ref)
+    assert o[1] == np.sum(np.round(p) == y)
+    close(dp, dp_ref, 2e-5)
+    pm = f32(rng.randn(B, 1) * 3 + 25); ym = f32(rng.uniform(20, 35, (B, 1)))
+    l_ref, dp_ref = K.mse_loss(pm, ym)
+    dp, out = ops.loss('mean_squared_error', g(pm), g(ym))
+    assert abs(out.cpu().numpy()[0] - l_ref) <= 2e-6 * abs(l_ref)
+    close(dp, dp_ref, 1e-6)
+    # data-parallel form: local rows, global mean
+    dp2, out2 = ops.loss('mean_squared_error', g(pm[:100]), g(ym[:100]), Bglobal=B)
+    close(dp2, dp_ref[:100], 1e-6)
+
+
+def test_adam_keras_form():
+    from gennet_amd import ops
+    rng = np.random.RandomState(17)
+    n = 100003
+    p = f32(rng.randn(n)); m = np.zeros(n); v = np.zeros(n)
+    pt, mt, vt = g(p), g(m), g(v)
+    pr = p.copy()
+    for t in (1, 2, 3):
+        gr = f32(rng.randn(n) * 0.01)
+        pr, m, v = K.adam_step(pr, gr, m, v, t)
+        lr_t = 9e-5 * np.sqrt(1 - 0.999 ** t) / (1 - 0.5 ** t)
+        ops.adam_step(pt, g(gr), mt, vt, lr_t, 0.5, 0.999, 1e-7)
+    # (1 - beta_2) is evaluated in fp32 like TF does: 1 - 0.999f carries a 3e-5 relative error into v
+    close(pt, pr, 1e-6); close(mt, m, 1e-5); close(vt, v, 1e-4)
+
+
+def test_rng_fills_and_gather():
+    from gennet_amd import ops
+    u = ops.fill_uniform((1 << 20,), -1.0, 1.0, 42, 0, dev())
+    assert u.min().item() >= -1.0 and u.max().item() < 1.0
+    assert abs(u.mean().item()) < 3e-3 and abs(u.var().item() - 1 / 3) < 3e-3
+    z = ops.fill_normal((1 << 20,), 0.0, 1.0, 42, 0, dev())
+    assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1.0) < 5e-3
+    assert torch.isfinite(z).all()
+    src = torch.arange(50 * 7, dtype=torch.float32, device=dev()).reshape(50, 7)
+    idx = torch.tensor([3, 49, 0, 3], dtype=torch.int64, device=dev())
+    assert torch.equal(ops.gather_rows(src, idx), src[idx])
+
+
+def test_bad_arguments_raise_not_crash():
+    from gennet_amd import ops, _lib
+    x = torch.zeros((1, 8, 6), device=dev()); w = torch.zeros((5, 6, 10), device=dev())     # Cin % 4 != 0
+    with pytest.raises(_lib.GennetHipError):
+        ops.conv1d_fwd(x, w, None, 1, 2, 8)
+    with pytest.raises(_lib.GennetHipError):
+        ops.conv1d_fwd(torch.zeros((1, 8, 16)), torch.zeros((5, 16, 16)), None, 1, 2, 8)       # CPU tensors: no fallback

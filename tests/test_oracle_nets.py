@@ -125,7 +125,7 @@ def test_losses_match_torch():
     # clip region: probability saturated -> loss finite, gradient zero (TF clip_by_value)
     l2, dp2 = K.bce_loss(np.array([[1.0], [0.0]]), np.array([[0.0], [1.0]]))
     assert np.isfinite(l2) and np.all(dp2 == 0)
-    close(l2, -np.log(K.K_EPS), 1e-6)
+    close(l2, 0.5 * (-np.log(1 - K.CLIP_HI) - np.log(K.CLIP_LO)), 1e-9)
     l, d = K.mse_loss(p, y)
     pt = t64(p); lt = F.mse_loss(pt, torch.tensor(y)); lt.backward()
     close(l, lt.item()); close(d, pt.grad.numpy())
