@@ -1,0 +1,246 @@
+"""Host-side mirror of BBH_version/bbhMahoGANy.py: model builders, compile wiring and the two training loops.
+
+Function names, arguments and semantics follow the reference script; its module-level globals (bbhMahoGANy.py:84-113)
+become the fields of `Config`.  Everything numerical runs in the HIP kernels behind gennet_amd.ops.
+
+  generator_model                       bbhMahoGANy.py:212-295
+  signal_pe_model (two-branch)          :356-404   (the comb_pe_model=True branch is dead code in the reference: it reads an
+                                                    undefined `batchnorm`, :318 -- not provided)
+  signal_discriminator_model            :408-498   (active configuration num_lays=2, batchnorm=False, maxpool=False)
+  data_subtraction_model / MyLayer      :164-210
+  generator_after_subtracting_noise     :500-519
+  generator_containing_signal_discriminator :521-539
+  set_trainable                         :797-809
+  build_and_compile                     :1089-1119
+  pe_train_step / gan_train_step        :1153-1168 / :1241-1299
+"""
+import random as _pyrandom
+
+import numpy as np
+import torch
+
+from . import ops
+from .engine import Adam, Input, Model, Sequential, device, device_rng, to_device
+from .layers import (Activation, BatchNormalization, Conv1D, Conv2D, Dense, Dropout, Flatten, LeakyReLU, MyLayer, ReLU,
+                     Reshape, UpSampling1D)
+
+
+class Config(object):
+    """bbhMahoGANy.py:84-113 (only the fields the hot path reads)."""
+
+    def __init__(self, **kw):
+        self.n_pix = 1024
+        self.n_sig = 1.0
+        self.batch_size = 8
+        self.pe_batch_size = 8
+        self.lr = 9e-5
+        self.n_noise_real = 1
+        self.cnn_noise_frac = 1.0 / 8.0
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise TypeError('unknown config field %r' % k)
+            setattr(self, k, v)
+
+
+def generator_model(n_pix=1024):
+    """bbhMahoGANy.py:212-295."""
+    model = Sequential(name='generator')
+    act, momentum, drate, padding, weights, filtsize = 'tanh', 0.99, 0.2, 'same', 'glorot_uniform', 5
+    model.add(Dense(256 * 1 * int(n_pix / 2), kernel_initializer=weights, input_shape=(100,)))
+    model.add(BatchNormalization(momentum=momentum))
+    model.add(Activation(act))
+    model.add(Dropout(drate))
+    model.add(Reshape((int(n_pix / 2), 256)))
+    for i, (filters, strides, up) in enumerate(((64, 2, True), (128, 1, True), (256, 1, False), (512, 1, False), (1024, 1, False))):
+        if up:
+            model.add(UpSampling1D(size=2))
+        model.add(Conv1D(filters, filtsize, kernel_initializer=weights, strides=strides, padding=padding))
+        model.add(BatchNormalization(momentum=momentum))
+        model.add(Activation(act))
+        model.add(Dropout(drate))
+    model.add(Conv1D(1, filtsize, padding=padding))
+    model.add(Activation('linear'))
+    model._config = ('generator_model', n_pix)
+    return model
+
+
+def signal_pe_model(n_pix=1024):
+    """bbhMahoGANy.py:356-404: chirp-mass branch and inverse-mass-ratio branch sharing one input."""
+    inputs = Input(shape=(n_pix, 1))
+    act = 'relu'
+    mc_branch = Conv1D(64, 5, strides=2, padding='same')(inputs)
+    mc_branch = Activation(act)(mc_branch)
+    for filters in (128, 256, 512):
+        mc_branch = Conv1D(filters, 5, strides=2)(mc_branch)
+        mc_branch = Activation(act)(mc_branch)
+    mc_branch = Flatten()(mc_branch)
+    mc_branch = Dense(1)(mc_branch)
+    mc_branch = Activation('relu')(mc_branch)
+
+    q_branch = Conv1D(64, 5, strides=1, padding='same')(inputs)
+    q_branch = Activation(act)(q_branch)
+    for filters, strides in ((128, 1), (256, 1), (512, 2), (1024, 2)):
+        q_branch = Conv1D(filters, 5, strides=strides)(q_branch)
+        q_branch = Activation(act)(q_branch)
+    q_branch = Flatten()(q_branch)
+    q_branch = Dense(1)(q_branch)
+    q_branch = ReLU(max_value=1.0)(q_branch)
+    model = Model(inputs=inputs, outputs=[mc_branch, q_branch], name='pe net')
+    model._config = ('signal_pe_model', n_pix)
+    return model
+
+
+def signal_discriminator_model(n_pix=1024):
+    """bbhMahoGANy.py:408-498, active configuration."""
+    drate, alpha, padding, weights, filtsize, n_neuron_scale = 0.4, 0.2, 'same', 'glorot_uniform', (5, 5), 4
+    model = Sequential(name='signal_discriminator')
+    model.add(Conv2D(64 * n_neuron_scale, filtsize, kernel_initializer=weights, input_shape=(n_pix, 2, 1), strides=(2, 1), padding=padding))
+    model.add(LeakyReLU(alpha=alpha))
+    model.add(Dropout(drate))
+    model.add(Conv2D(128 * n_neuron_scale, filtsize, kernel_initializer=weights, strides=(2, 1), padding=padding))
+    model.add(LeakyReLU(alpha=alpha))
+    model.add(Dropout(drate))
+    model.add(Flatten())
+    model.add(Dense(1))
+    model.add(Activation('sigmoid'))
+    model._config = ('signal_discriminator_model', n_pix)
+    return model
+
+
+def data_subtraction_model(noise_signal, npix):
+    """bbhMahoGANy.py:190-210."""
+    model = Sequential(name='data_subtraction')
+    model.add(MyLayer(noise_signal, input_shape=(npix, 1)))
+    return model
+
+
+def generator_after_subtracting_noise(generator, data_subtraction):
+    """bbhMahoGANy.py:500-519."""
+    model = Sequential()
+    model.add(generator)
+    model.add(data_subtraction)
+    return model
+
+
+def generator_containing_signal_discriminator(generator, signal_discriminator):
+    """bbhMahoGANy.py:521-539."""
+    model = Sequential()
+    model.add(generator)
+    model.add(signal_discriminator)
+    return model
+
+
+def set_trainable(model, trainable):
+    """bbhMahoGANy.py:797-809."""
+    model.trainable = trainable
+    for layer in model.layers:
+        layer.trainable = trainable
+
+
+def model_from_config(cfg):
+    name, n_pix = cfg
+    return {'generator_model': generator_model, 'signal_pe_model': signal_pe_model,
+            'signal_discriminator_model': signal_discriminator_model}[name](n_pix)
+
+
+class Nets(object):
+    pass
+
+
+def build_and_compile(noise_signal, n_pix, lr=9e-5, do_pe=True, data_parallel=None):
+    """bbhMahoGANy.py:1089-1119, in the reference's order (the order fixes which weights each compiled model trains):
+    the combined model is compiled while the discriminator is frozen, the discriminator after it is unfrozen."""
+    nets = Nets()
+    nets.generator = generator_model(n_pix)
+    nets.signal_discriminator = signal_discriminator_model(n_pix)
+    nets.data_subtraction = data_subtraction_model(noise_signal, n_pix)
+    nets.signal_pe = signal_pe_model(n_pix) if do_pe else None
+    dp = data_parallel
+    nets.data_subtraction_on_generator = generator_after_subtracting_noise(nets.generator, nets.data_subtraction)
+    nets.data_subtraction_on_generator.compile(loss='binary_crossentropy', optimizer=Adam(lr=lr, beta_1=0.5), metrics=['accuracy'], data_parallel=dp)
+    nets.signal_discriminator_on_generator = generator_containing_signal_discriminator(nets.data_subtraction_on_generator, nets.signal_discriminator)
+    set_trainable(nets.signal_discriminator, False)
+    nets.signal_discriminator_on_generator.compile(loss='binary_crossentropy', optimizer=Adam(lr=lr, beta_1=0.5), metrics=['accuracy'], data_parallel=dp)
+    set_trainable(nets.signal_discriminator, True)
+    nets.signal_discriminator.compile(loss='binary_crossentropy', optimizer=Adam(lr=lr, beta_1=0.5), metrics=['accuracy'], data_parallel=dp)
+    if do_pe:
+        nets.signal_pe.compile(loss='mean_squared_error', optimizer=Adam(lr=lr, beta_1=0.5), metrics=['accuracy'], data_parallel=dp)
+    return nets
+
+
+# --------------------------------------------------------------------------------------------------------------
+# training steps.  The template bank, labels and event stay resident in HBM; batch selection uses the host python
+# `random` stream exactly like the reference, everything else (noise, latent vectors, assembly) happens on the device.
+# --------------------------------------------------------------------------------------------------------------
+class DeviceBank(object):
+    """signal_train_images (Ns, n_pix) and signal_train_pars (Ns, 2) = [mc, m2/m1] in HBM (bbhMahoGANy.py:1007-1014)."""
+
+    def __init__(self, images, pars):
+        self.images = to_device(np.asarray(images, np.float32)) if not isinstance(images, torch.Tensor) else images.to(device()).float().contiguous()
+        self.pars = to_device(np.asarray(pars, np.float32)) if not isinstance(pars, torch.Tensor) else pars.to(device()).float().contiguous()
+        self.n = self.images.shape[0]
+        self.n_pix = self.images.shape[1]
+
+    def sample(self, batch, rng=_pyrandom, rank=0, world=1):
+        """random.sample of `batch*world` distinct template indices (bbhMahoGANy.py:1156, :1244); rank r keeps rows
+        [r*batch, (r+1)*batch) so that the union over ranks equals the single-process batch."""
+        idx = rng.sample(range(self.n), batch * world)
+        idx = idx[rank * batch:(rank + 1) * batch]
+        it = torch.tensor(idx, dtype=torch.int64, device=device())
+        return it
+
+
+def pe_train_step(signal_pe, bank, batch, cnn_noise_frac=1.0 / 8.0, rng=_pyrandom, nprng=np.random, rank=0, world=1):
+    """One iteration of the CNN loop, bbhMahoGANy.py:1155-1165.  Noise N(0, sigma), sigma ~ U(0,5) drawn once per batch
+    on the host stream, is added to the first int(B*cnn_noise_frac) rows (the reference hard-codes the length 1024 at
+    :1161; here it is n_pix)."""
+    it = bank.sample(batch, rng, rank, world)
+    x = ops.gather_rows(bank.images, it)
+    y = ops.gather_rows(bank.pars, it)
+    n_noisy = int(batch * cnn_noise_frac)
+    sigma = float(nprng.uniform(0, 5))
+    if n_noisy > 0:
+        seed, off = device_rng().take(n_noisy * bank.n_pix)
+        noise = ops.fill_normal((n_noisy, bank.n_pix), 0.0, sigma, seed, off, device())
+        ops.axpy(x[:n_noisy], noise, 1.0)
+    return signal_pe.train_on_batch(x.reshape(batch, bank.n_pix, 1), [y[:, 0].contiguous(), y[:, 1].contiguous()])
+
+
+def assemble_discriminator_batch(real, noise, fake, event):
+    """bbhMahoGANy.py:1268-1289 on the device, vectorised (the reference's np.append loop is O(B^2) host copies):
+    real images [template | N(0,1) noise], fake images [G(z) | event - G(z)] in REVERSED sample order (:1271 prepends),
+    labels 1...1 0...0."""
+    B, n = real.shape[0], real.shape[1]
+    real2 = torch.stack([real.reshape(B, n), noise.reshape(B, n)], dim=2)
+    fake2 = ops.subtract_stack_fwd(fake.reshape(B, n, 1).contiguous(), event).reshape(B, n, 2)
+    fake2 = torch.flip(fake2, dims=[0])
+    sX = torch.cat([real2, fake2]).reshape(2 * B, n, 2, 1).contiguous()
+    sy = torch.cat([torch.ones(B, device=real.device), torch.zeros(B, device=real.device)])
+    return sX, sy
+
+
+def gan_train_step(nets, bank, event, batch, rng=_pyrandom, rank=0, world=1, predict_batch=32):
+    """One iteration of the GAN loop, bbhMahoGANy.py:1243-1299.  Returns [sg_loss, sg_acc, sd_loss, sd_acc] (:1299)."""
+    n = bank.n_pix
+    it = bank.sample(batch, rng, rank, world)
+    real = ops.gather_rows(bank.images, it)
+    seed, off = device_rng().take(batch * 100)
+    z = ops.fill_uniform((batch, 100), -1.0, 1.0, seed, off, device())
+    fake = nets.generator.predict_device(z, batch_size=predict_batch)                    # inference phase (:1248)
+    seed, off = device_rng().take(batch * n)
+    noise = ops.fill_normal((batch, n, 1), 0.0, 1.0, seed, off, device())
+    sX, sy = assemble_discriminator_batch(real, noise, fake, event)
+    sd_loss = nets.signal_discriminator.train_on_batch(sX, sy)
+    seed, off = device_rng().take(batch * 100)
+    z = ops.fill_uniform((batch, 100), -1.0, 1.0, seed, off, device())
+    sg_loss = nets.signal_discriminator_on_generator.train_on_batch(z, torch.ones(batch, device=device()))
+    return [sg_loss[0], sg_loss[1], sd_loss[0], sd_loss[1]]
+
+
+def posterior_samples(nets, n_samples=4000, predict_batch=32):
+    """bbhMahoGANy.py:1330-1343: generator.predict(U(-1,1)[n,100]) -> signal_pe.predict -> [mc (n,1), q (n,1)]."""
+    seed, off = device_rng().take(n_samples * 100)
+    z = ops.fill_uniform((n_samples, 100), -1.0, 1.0, seed, off, device())
+    wave = nets.generator.predict_device(z, batch_size=predict_batch)
+    pe = nets.signal_pe.predict_device(wave, batch_size=predict_batch)
+    return [p.cpu().numpy() for p in pe], wave.cpu().numpy()

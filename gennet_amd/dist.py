@@ -1,0 +1,57 @@
+"""Data parallelism: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" for CPU tests).
+
+The reference has no distributed code at all; this is the batch-sharded scheme of SURVEY section 8e:
+rank r trains on rows [r*B/N, (r+1)*B/N) of the global batch and three kinds of sums cross the ranks:
+  1. the flat gradient buffer of the compiled model, once per train_on_batch (one all-reduce: PE 19.7 MB, D 15.2 MB,
+     G 122 MB fp32 at n_pix = 2048) -- losses are already normalised by the GLOBAL batch size, so SUM is the reduction;
+  2. BatchNorm statistics (sum x, sum x^2) and their backward counterparts, fp64, in the generator only (SyncBN);
+  3. the loss / accuracy scalars.
+xGMI is point-to-point (7 links per GPU): a ring all-reduce of S bytes moves 2*(N-1)/N*S per GPU over one link, ~1.4 ms
+for the 122 MB generator gradient, against a >100 ms step -- so one large flat all-reduce per step is the right shape and
+bucketing/overlap would buy nothing here.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel(object):
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised; call gennet_amd.dist.init() first')
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_reduce_sum(self, t):
+        if self.world_size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def broadcast(self, t, src=0):
+        if self.world_size > 1:
+            dist.broadcast(t, src, group=self.group)
+        return t
+
+    def sync_model(self, model):
+        """Make every rank start from rank 0's weights (parameters and BN moving statistics)."""
+        for p in model.weights:
+            self.broadcast(p.data)
+
+
+def init(backend=None):
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
+    Returns a DataParallel, or None when WORLD_SIZE is 1 or unset."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return None
+    if not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=world)
+    return DataParallel()

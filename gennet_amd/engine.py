@@ -1,0 +1,759 @@
+"""Keras-style model engine over the HIP kernel library: Layer / Input / Sequential / Model, compile(),
+train_on_batch(), predict(), fit(), weight persistence.
+
+Mirrors the Keras 2.2.4 surface that BBH_version/bbhMahoGANy.py uses:
+  * Sequential().add(layer | model), functional Input(shape) -> Layer(...)(tensor) -> Model(inputs=, outputs=[...], name=)
+    (bbhMahoGANy.py:221-295, :357-404, :432-498, :516-518, :536-538)
+  * model.trainable / layer.trainable assignment with COLLECT-AT-COMPILE semantics (:797-809, :1104-1115)
+  * compile(loss=, optimizer=Adam(lr=, beta_1=), metrics=['accuracy']) (:1101-1119); one optimizer state per compiled model
+  * train_on_batch(x, y) -> [loss, *metrics] python floats, keras ordering for multi-output models (:1165, :1292, :1296)
+  * predict(x) -> ndarray | [ndarray] (default batch_size 32) (:1185, :1248, :1343); learning phase 1 in train_on_batch for
+    the WHOLE graph, 0 in predict
+  * save / save_weights / load_weights / load_model (:1135-1142, :1173, :1373-1375)
+
+Not a tracing compiler: a model is a flat list of nodes executed eagerly, one or two HIP kernels per node, with peephole
+fusions decided once per graph (conv+activation epilogue, BN+activation+dropout single pass).  Weights that a compiled
+model trains live in ONE flat fp32 buffer (plus one flat gradient buffer), so the optimizer is a single fused kernel
+and data-parallel training needs a single all-reduce per step.
+"""
+import pickle
+
+import numpy as np
+import torch
+
+from . import ops
+
+_DEVICE = None
+
+
+def device():
+    """The HIP device of this process: cuda:LOCAL_RANK (one process per GPU)."""
+    global _DEVICE
+    if _DEVICE is None:
+        import os
+        if not torch.cuda.is_available():
+            from ._lib import GennetHipError
+            raise GennetHipError('gennet_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU execution path')
+        idx = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(idx)
+        _DEVICE = torch.device('cuda', idx)
+    return _DEVICE
+
+
+def to_device(a, dtype=torch.float32):
+    if isinstance(a, torch.Tensor):
+        t = a.to(device=device(), dtype=dtype)
+    else:
+        t = torch.as_tensor(np.ascontiguousarray(np.asarray(a)), dtype=dtype).to(device())
+    return t.contiguous()
+
+
+_INIT_RNG = np.random.RandomState(12345)
+
+
+def set_init_seed(seed):
+    """Seed of the numpy RNG that draws initial weights (glorot_uniform)."""
+    global _INIT_RNG
+    _INIT_RNG = np.random.RandomState(seed)
+
+
+def glorot_uniform(shape):
+    """keras VarianceScaling(scale=1, mode='fan_avg', distribution='uniform')."""
+    if len(shape) == 2:
+        fi, fo = shape
+    else:
+        rec = int(np.prod(shape[:-2]))
+        fi, fo = rec * shape[-2], rec * shape[-1]
+    lim = np.sqrt(6.0 / (fi + fo))
+    return _INIT_RNG.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# parameters and flat groups
+# --------------------------------------------------------------------------------------------------------------
+class Param(object):
+    """A weight tensor.  The initial value stays on the host until the first device access, so graphs can be built,
+    planned and inspected (summary, count_params, get_weights) on a machine without a GPU; all arithmetic needs one."""
+
+    def __init__(self, name, value, trainable=True):
+        self.name = name
+        self.shape = tuple(value.shape)
+        self._host = np.ascontiguousarray(value, np.float32)
+        self._data = None
+        self.grad = None
+        self.trainable = trainable
+        self.group = None
+        self.offset = 0
+
+    @property
+    def data(self):
+        if self._data is None:
+            self._data = to_device(self._host)
+            self._host = None
+        return self._data
+
+    @data.setter
+    def data(self, t):
+        self._data = t
+        self._host = None
+
+    def numpy(self):
+        return self._host.copy() if self._data is None else self._data.detach().cpu().numpy().copy()
+
+    def assign(self, w):
+        w = np.ascontiguousarray(w, np.float32)
+        assert tuple(w.shape) == self.shape, '%s: %s vs %s' % (self.name, w.shape, self.shape)
+        if self._data is None:
+            self._host = w
+        else:
+            self._data.copy_(to_device(w))
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape)) if self.shape else 1
+
+
+class ParamGroup(object):
+    """Contiguous storage for a set of parameters: data, grad; every parameter starts on a 256-byte boundary."""
+    ALIGN = 64
+
+    def __init__(self, params):
+        off = 0
+        for p in params:
+            p.offset = off
+            off += -(-p.size // self.ALIGN) * self.ALIGN
+        self.numel = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=device())
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device())
+        for p in params:
+            self.data[p.offset:p.offset + p.size].copy_(p.data.reshape(-1))
+            p.data = self.data[p.offset:p.offset + p.size].view(p.shape)
+            p.grad = self.grad[p.offset:p.offset + p.size].view(p.shape)
+            p.group = self
+        self.params = list(params)
+
+
+def group_params(params):
+    fresh = [p for p in params if p.group is None]
+    if fresh:
+        ParamGroup(fresh)
+
+
+def segments(params):
+    """Maximal runs of adjacent parameters inside their groups: [(group, start, stop)]."""
+    spans = sorted(((id(p.group), p.offset, p) for p in params), key=lambda t: (t[0], t[1]))
+    segs = []
+    for _, off, p in spans:
+        end = off + -(-p.size // ParamGroup.ALIGN) * ParamGroup.ALIGN
+        if segs and segs[-1][0] is p.group and segs[-1][2] == off:
+            segs[-1][2] = end
+        else:
+            segs.append([p.group, off, end])
+    return [tuple(s) for s in segs]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# run context
+# --------------------------------------------------------------------------------------------------------------
+class PhiloxStream(object):
+    """Counter allocator for the device RNG: every consumer takes a disjoint counter range of one (seed) stream."""
+
+    def __init__(self, seed=0):
+        self.seed = int(seed)
+        self.offset = 0
+
+    def take(self, n_values):
+        off = self.offset
+        self.offset += (int(n_values) + 3) // 4
+        return self.seed, off
+
+
+_RNG = PhiloxStream(0)
+
+
+def set_device_seed(seed):
+    global _RNG
+    _RNG = PhiloxStream(seed)
+
+
+def device_rng():
+    return _RNG
+
+
+class RunContext(object):
+    def __init__(self, training, dp=None, dropout_masks=None, train_params=None):
+        self.training = training
+        self.dp = dp
+        self.dropout_masks = dropout_masks or {}
+        self.train_ids = None if train_params is None else set(id(p) for p in train_params)
+        self.tape = {}
+
+    def wants_grad(self, layer):
+        if self.train_ids is None:
+            return False
+        return any(id(p) in self.train_ids for p in layer.trainable_params())
+
+
+# --------------------------------------------------------------------------------------------------------------
+# layers: base class + symbolic tensors
+# --------------------------------------------------------------------------------------------------------------
+class SymTensor(object):
+    def __init__(self, shape, layer=None, inbound=()):
+        self.shape = tuple(shape)          # without the batch axis
+        self.layer = layer
+        self.inbound = tuple(inbound)
+
+
+def Input(shape=None, name=None):
+    return SymTensor(shape)
+
+
+_NAME_COUNTS = {}
+
+
+class Layer(object):
+    """Base layer.  Subclasses implement build(input_shape), compute_output_shape(input_shape),
+    forward(ctx, node, x) and backward(ctx, node, dy, need_dx, need_dw)."""
+
+    def __init__(self, input_shape=None, name=None, trainable=True, **kwargs):
+        base = name or self.__class__.__name__.lower()
+        if name is None:
+            _NAME_COUNTS[base] = _NAME_COUNTS.get(base, 0) + 1
+            name = '%s_%d' % (base, _NAME_COUNTS[base])
+        self.name = name
+        self.trainable = trainable
+        self.built = False
+        self.input_shape_arg = tuple(input_shape) if input_shape is not None else None
+        self.params = []
+        self.buffers = []
+
+    # -- keras-style weight bookkeeping
+    def add_weight(self, name, value, trainable=True):
+        p = Param('%s/%s' % (self.name, name), value, trainable)
+        (self.params if trainable else self.buffers).append(p)
+        return p
+
+    def trainable_params(self):
+        return self.params
+
+    @property
+    def trainable_weights(self):
+        return list(self.params) if self.trainable else []
+
+    @property
+    def non_trainable_weights(self):
+        return list(self.buffers) + ([] if self.trainable else list(self.params))
+
+    @property
+    def weights(self):
+        return list(self.params) + list(self.buffers)
+
+    def get_weights(self):
+        return [p.numpy() for p in self.weights]
+
+    def set_weights(self, ws):
+        assert len(ws) == len(self.weights), '%s expects %d arrays' % (self.name, len(self.weights))
+        for p, w in zip(self.weights, ws):
+            p.assign(w)
+
+    def count_params(self):
+        return sum(p.size for p in self.weights)
+
+    # -- shape protocol
+    def build(self, input_shape):
+        self.built = True
+
+    def compute_output_shape(self, input_shape):
+        return input_shape
+
+    def _ensure_built(self, input_shape):
+        if not self.built:
+            self.build(tuple(input_shape))
+            self.built = True
+
+    # -- functional API
+    def __call__(self, x):
+        self._ensure_built(x.shape)
+        return SymTensor(self.compute_output_shape(x.shape), self, (x,))
+
+    # -- execution
+    fusable_act = False      # can take an activation epilogue
+    fusable_drop = False     # can take a dropout epilogue
+    act_spec = None          # (kind, param) if this layer IS an activation
+    drop_rate = None         # rate if this layer IS a dropout
+
+    def forward(self, ctx, node, x):
+        raise NotImplementedError
+
+    def backward(self, ctx, node, dy, need_dx, need_dw):
+        raise NotImplementedError
+
+
+class Node(object):
+    __slots__ = ('layer', 'inbound', 'fused_act', 'fused_drop', 'absorbed', 'index', 'out_shape', 'owners')
+
+    def __init__(self, layer, inbound, out_shape, owners=()):
+        self.layer = layer
+        self.owners = tuple(owners)        # nested models this node was spliced in from (their .trainable also gates it)
+        self.inbound = list(inbound)       # indices: >= 0 node, < 0 graph input (-1 - k)
+        self.fused_act = None              # (kind, param) applied in this node's epilogue
+        self.fused_drop = None             # (rate, dropout layer) applied in this node's epilogue
+        self.absorbed = False              # this node's work happens inside its producer
+        self.index = -1
+        self.out_shape = out_shape
+
+
+# --------------------------------------------------------------------------------------------------------------
+# optimizer
+# --------------------------------------------------------------------------------------------------------------
+class Adam(object):
+    """keras.optimizers.Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=None, decay=0.0, **kwargs):
+        self.lr, self.beta_1, self.beta_2 = float(lr), float(beta_1), float(beta_2)
+        self.epsilon = 1e-7 if epsilon is None else float(epsilon)
+        if decay:
+            raise NotImplementedError('Adam(decay != 0) is not on the BBH hot path')
+        self.iterations = 0
+        self.state = None                  # [(group, start, stop, m, v)]
+
+    def bind(self, params):
+        self.state = []
+        for grp, a, b in segments(params):
+            n = b - a
+            self.state.append((grp, a, b, torch.zeros(n, dtype=torch.float32, device=device()), torch.zeros(n, dtype=torch.float32, device=device())))
+
+    def step(self):
+        self.iterations += 1
+        t = self.iterations
+        lr_t = self.lr * np.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        for grp, a, b, m, v in self.state:
+            ops.adam_step(grp.data[a:b], grp.grad[a:b], m, v, lr_t, self.beta_1, self.beta_2, self.epsilon)
+
+    def get_state(self):
+        return {'iterations': self.iterations, 'mv': [(m.cpu().numpy(), v.cpu().numpy()) for _, _, _, m, v in (self.state or [])],
+                'config': (self.lr, self.beta_1, self.beta_2, self.epsilon)}
+
+    def set_state(self, st):
+        self.iterations = st['iterations']
+        for (_, _, _, m, v), (mn, vn) in zip(self.state, st['mv']):
+            m.copy_(to_device(mn)); v.copy_(to_device(vn))
+
+
+def _get_optimizer(opt):
+    if isinstance(opt, str):
+        if opt.lower() == 'adam':
+            return Adam()
+        raise NotImplementedError('optimizer %r' % opt)
+    return opt
+
+
+LOSSES = ('binary_crossentropy', 'mean_squared_error')
+
+
+# --------------------------------------------------------------------------------------------------------------
+# models
+# --------------------------------------------------------------------------------------------------------------
+class Model(Layer):
+    """Functional model: Model(inputs=Input(...), outputs=[t1, t2], name=...).  Also the base of Sequential."""
+
+    def __init__(self, inputs=None, outputs=None, name=None, **kwargs):
+        Layer.__init__(self, name=name)
+        self.nodes = []
+        self.input_shapes = []
+        self.output_ids = []
+        self._planned = False
+        self.optimizer = None
+        self.loss = None
+        self.metrics = []
+        self._train_params = None
+        self.data_parallel = None
+        if inputs is not None:
+            self._from_symbolic(inputs, outputs)
+
+    # -- graph construction
+    def _from_symbolic(self, inputs, outputs):
+        ins = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
+        outs = list(outputs) if isinstance(outputs, (list, tuple)) else [outputs]
+        self.input_shapes = [t.shape for t in ins]
+        index = {}
+        for k, t in enumerate(ins):
+            index[id(t)] = -1 - k
+
+        def visit(t):
+            if id(t) in index:
+                return index[id(t)]
+            if t.layer is None:
+                raise ValueError('graph reaches an Input that is not listed in inputs=')
+            inb = [visit(s) for s in t.inbound]
+            idx = self._append(t.layer, inb, t.shape)
+            index[id(t)] = idx
+            return idx
+
+        self.output_ids = [visit(t) for t in outs]
+        self.built = True
+
+    def _append(self, layer, inbound, out_shape, owners=()):
+        """Append a leaf layer, or splice in a nested model's nodes (weights are shared with the nested model)."""
+        if isinstance(layer, Model):
+            assert len(layer.input_shapes) == 1 and len(layer.output_ids) == 1 and len(inbound) == 1, 'nested models must be 1-in / 1-out'
+            remap = {}
+            for n in layer.nodes:
+                inb = [inbound[0] if i < 0 else remap[i] for i in n.inbound]
+                remap[n.index] = self._append(n.layer, inb, n.out_shape, tuple(owners) + (layer,) + n.owners)
+            return remap[layer.output_ids[0]]
+        node = Node(layer, inbound, out_shape, owners)
+        node.index = len(self.nodes)
+        self.nodes.append(node)
+        self._planned = False
+        return node.index
+
+    @property
+    def layers(self):
+        seen, out = set(), []
+        for n in self.nodes:
+            if id(n.layer) not in seen:
+                seen.add(id(n.layer))
+                out.append(n.layer)
+        return out
+
+    @property
+    def output_shape(self):
+        shapes = [(None,) + tuple(self.nodes[i].out_shape) for i in self.output_ids]
+        return shapes[0] if len(shapes) == 1 else shapes
+
+    def compute_output_shape(self, input_shape):
+        return self.nodes[self.output_ids[0]].out_shape
+
+    # -- trainability (keras: model.trainable = False freezes; what counts is the value at compile time)
+    def trainable_params(self):
+        out = []
+        for l in self.layers:
+            out.extend(l.trainable_params())
+        return out
+
+    @property
+    def trainable_weights(self):
+        if not self.trainable:
+            return []
+        out = []
+        for l in self.layers:
+            out.extend(l.trainable_weights)
+        return out
+
+    @property
+    def non_trainable_weights(self):
+        out = []
+        for l in self.layers:
+            out.extend(l.non_trainable_weights if self.trainable else l.weights)
+        return out
+
+    @property
+    def weights(self):
+        out = []
+        for l in self.layers:
+            out.extend(l.weights)
+        return out
+
+    def get_weights(self):
+        return [w for l in self.layers for w in l.get_weights()]
+
+    def set_weights(self, ws):
+        ws = list(ws)
+        for l in self.layers:
+            n = len(l.weights)
+            l.set_weights(ws[:n])
+            ws = ws[n:]
+        assert not ws, 'too many weight arrays'
+
+    # -- planning: consumers, peephole fusions
+    def _plan(self):
+        for n in self.nodes:
+            n.fused_act, n.fused_drop, n.absorbed = None, None, False
+        consumers = {n.index: [] for n in self.nodes}
+        for n in self.nodes:
+            for i in n.inbound:
+                if i >= 0:
+                    consumers[i].append(n.index)
+        outs = set(self.output_ids)
+
+        def sole_consumer(i):
+            if i in outs or len(consumers[i]) != 1:
+                return None
+            return self.nodes[consumers[i][0]]
+
+        for n in self.nodes:
+            if n.absorbed:
+                continue
+            tail = n
+            if n.layer.fusable_act:
+                c = sole_consumer(tail.index)
+                if c is not None and c.layer.act_spec is not None:
+                    n.fused_act = c.layer.act_spec
+                    c.absorbed = True
+                    tail = c
+            if n.layer.fusable_drop:
+                c = sole_consumer(tail.index)
+                if c is not None and c.layer.drop_rate is not None:
+                    n.fused_drop = (c.layer.drop_rate, c.layer)
+                    c.absorbed = True
+        self._planned = True
+
+    # -- execution
+    def _forward(self, inputs, ctx):
+        if not self._planned:
+            self._plan()
+        vals = {}
+        for k, x in enumerate(inputs):
+            vals[-1 - k] = x
+        for n in self.nodes:
+            xs = [vals[i] for i in n.inbound]
+            if n.absorbed:
+                vals[n.index] = xs[0]
+                continue
+            vals[n.index] = n.layer.forward(ctx, n, xs[0] if len(xs) == 1 else xs)
+        return [vals[i] for i in self.output_ids]
+
+    def _backward(self, out_grads, ctx):
+        grads = {}
+        for i, g in zip(self.output_ids, out_grads):
+            grads[i] = g
+        for n in reversed(self.nodes):
+            dy = grads.pop(n.index, None)
+            if dy is None:
+                continue
+            if n.absorbed:
+                dx = dy
+            else:
+                need_dx = any(i >= 0 for i in n.inbound)
+                need_dw = ctx.wants_grad(n.layer)
+                if not need_dx and not need_dw:
+                    continue
+                dx = n.layer.backward(ctx, n, dy, need_dx, need_dw)
+            if dx is None:
+                continue
+            for i in n.inbound:
+                if i < 0:
+                    continue
+                if i in grads:
+                    grads[i] = ops.axpy(grads[i], dx, 1.0)
+                else:
+                    grads[i] = dx
+
+    # Model used as a layer inside another graph is expanded by _append, so forward/backward are never called on it.
+
+    # -- keras training surface
+    def compile(self, loss=None, optimizer=None, metrics=None, data_parallel=None, **kwargs):
+        """Collects the trainable weights NOW (keras semantics): later changes of .trainable do not affect this model."""
+        self.loss = loss
+        n_out = len(self.output_ids)
+        losses = list(loss) if isinstance(loss, (list, tuple)) else [loss] * n_out
+        for l in losses:
+            if l not in LOSSES:
+                raise NotImplementedError('loss %r: only %s run on the HIP path' % (l, LOSSES))
+        self._losses = losses
+        self.metrics = list(metrics or [])
+        for m in self.metrics:
+            if m not in ('accuracy', 'acc', 'binary_accuracy'):
+                raise NotImplementedError('metric %r' % (m,))
+        self.optimizer = _get_optimizer(optimizer)
+        params, seen = [], set()
+        if self.trainable:
+            for n in self.nodes:
+                if n.layer.trainable and all(o.trainable for o in n.owners):
+                    for p in n.layer.trainable_params():
+                        if id(p) not in seen:
+                            seen.add(id(p)); params.append(p)
+        self._train_params = params
+        self._bound = False                # flat grouping + optimizer state are created at the first device step
+        if data_parallel is not None:
+            self.data_parallel = data_parallel
+        return self
+
+    def _ensure_bound(self):
+        if not self._bound:
+            group_params(self._train_params)
+            self.optimizer.bind(self._train_params)
+            self._bound = True
+
+    @property
+    def metrics_names(self):
+        names = ['loss']
+        n_out = len(self.output_ids)
+        if n_out > 1:
+            names += ['out%d_loss' % k for k in range(n_out)]
+        for k in range(n_out):
+            if self.metrics:
+                names.append('acc' if n_out == 1 else 'out%d_acc' % k)
+        return names
+
+    def _prep_inputs(self, x):
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]
+        assert len(xs) == len(self.input_shapes), 'model expects %d input arrays' % len(self.input_shapes)
+        out = []
+        for a, shp in zip(xs, self.input_shapes):
+            t = to_device(a)
+            if tuple(t.shape[1:]) != tuple(shp):
+                t = t.reshape((t.shape[0],) + tuple(shp))
+            out.append(t)
+        return out
+
+    def _prep_targets(self, y, B):
+        n_out = len(self.output_ids)
+        ys = list(y) if (isinstance(y, (list, tuple)) and n_out > 1) else [y]
+        assert len(ys) == n_out, 'model has %d outputs' % n_out
+        return [to_device(a).reshape(B, 1) for a in ys]
+
+    def train_on_batch(self, x, y, dropout_masks=None):
+        """One optimizer step.  Returns [loss, (per-output losses,) (accuracies)] as python floats, keras order.
+        `dropout_masks` ({dropout layer name: uint8 keep mask}) is a testing hook that replaces the Philox draws."""
+        if self.optimizer is None:
+            raise RuntimeError('compile() the model before train_on_batch')
+        self._ensure_bound()
+        xs = self._prep_inputs(x)
+        B = xs[0].shape[0]
+        ys = self._prep_targets(y, B)
+        dp = self.data_parallel
+        world = dp.world_size if dp is not None else 1
+        masks = {k: to_device(v, torch.uint8) for k, v in (dropout_masks or {}).items()}
+        ctx = RunContext(True, dp, masks, self._train_params)
+        outs = self._forward(xs, ctx)
+        dps, stats = [], []
+        for p, t, kind in zip(outs, ys, self._losses):
+            d, o = ops.loss(kind, p.reshape(B, 1), t, B * world)
+            dps.append(d.reshape(p.shape)); stats.append(o)
+        for grp, a, b in segments(self._train_params):
+            grp.grad[a:b].zero_()
+        self._backward(dps, ctx)
+        stats = torch.stack(stats)
+        if dp is not None:
+            for grp, a, b in segments(self._train_params):
+                dp.all_reduce_sum(grp.grad[a:b])
+            dp.all_reduce_sum(stats)
+        self.optimizer.step()
+        st = stats.cpu().numpy().astype(np.float64)
+        losses = [float(v) for v in st[:, 0]]
+        res = [float(sum(losses))]
+        if len(losses) > 1:
+            res += losses
+        if self.metrics:
+            res += [float(h) / (B * world) for h in st[:, 1]]
+        return res
+
+    def predict_device(self, x, batch_size=32):
+        """predict() that keeps inputs and outputs in HBM (torch tensors): inference phase, chunks of batch_size."""
+        xs = self._prep_inputs(x)
+        B = xs[0].shape[0]
+        chunks = []
+        for s in range(0, B, batch_size):
+            ctx = RunContext(False)
+            chunks.append(self._forward([t[s:s + batch_size] for t in xs], ctx))
+        outs = [torch.cat([c[k] for c in chunks]) if len(chunks) > 1 else chunks[0][k] for k in range(len(self.output_ids))]
+        return outs if len(outs) > 1 else outs[0]
+
+    def predict(self, x, batch_size=32, verbose=0):
+        out = self.predict_device(x, batch_size)
+        if isinstance(out, list):
+            return [o.cpu().numpy() for o in out]
+        return out.cpu().numpy()
+
+    def fit(self, x, y, batch_size=32, epochs=1, verbose=0, shuffle=True, **kwargs):
+        """Minimal keras fit: epochs of shuffled mini-batches through train_on_batch; returns {'loss': [...]}."""
+        x = np.asarray(x)
+        n = x.shape[0]
+        ys = list(y) if (isinstance(y, (list, tuple)) and len(self.output_ids) > 1) else [y]
+        ys = [np.asarray(a) for a in ys]
+        hist = {'loss': []}
+        rng = np.random.RandomState(0)
+        for ep in range(epochs):
+            order = rng.permutation(n) if shuffle else np.arange(n)
+            tot, cnt = 0.0, 0
+            for s in range(0, n, batch_size):
+                idx = order[s:s + batch_size]
+                yy = [a[idx] for a in ys]
+                r = self.train_on_batch(x[idx], yy if len(yy) > 1 else yy[0])
+                tot += r[0] * len(idx); cnt += len(idx)
+            hist['loss'].append(tot / max(cnt, 1))
+            if verbose:
+                print('Epoch %d/%d - loss: %.6f' % (ep + 1, epochs, hist['loss'][-1]))
+        return hist
+
+    def summary(self, print_fn=None):
+        lines = ['_' * 65, '%-29s%-26s%s' % ('Layer (type)', 'Output Shape', 'Param #'), '=' * 65]
+        tot = 0
+        for n in self.nodes:
+            cnt = n.layer.count_params()
+            tot += cnt
+            lines.append('%-29s%-26s%d' % ('%s (%s)' % (n.layer.name, n.layer.__class__.__name__), str((None,) + tuple(n.out_shape)), cnt))
+        tr = sum(p.size for p in self.trainable_weights)
+        lines += ['=' * 65, 'Total params: {:,}'.format(tot), 'Trainable params: {:,}'.format(tr), 'Non-trainable params: {:,}'.format(tot - tr), '_' * 65]
+        s = '\n'.join(lines)
+        (print_fn or print)(s)
+
+    # -- persistence.  h5py is not available in this image, so the container is a pickle with the keras weight ORDER
+    #    and layouts ((k,Cin,Cout) kernels, (L,C)-major flatten); the Keras-HDF5 byte layout is SURVEY section 8f row n2.
+    def save_weights(self, filepath, overwrite=True):
+        import os
+        if os.path.exists(filepath) and not overwrite:
+            raise IOError('%s exists' % filepath)
+        with open(filepath, 'wb') as f:
+            pickle.dump({'format': 'gennet_amd-weights-1', 'names': [p.name for p in self.weights], 'weights': self.get_weights()}, f, protocol=2)
+
+    def load_weights(self, filepath):
+        with open(filepath, 'rb') as f:
+            blob = pickle.load(f)
+        self.set_weights(blob['weights'])
+
+    def save(self, filepath, overwrite=True):
+        import os
+        if os.path.exists(filepath) and not overwrite:
+            raise IOError('%s exists' % filepath)
+        blob = {'format': 'gennet_amd-model-1', 'config': getattr(self, '_config', None), 'weights': self.get_weights(),
+                'loss': self.loss, 'metrics': self.metrics, 'optimizer': self.optimizer.get_state() if self.optimizer and self.optimizer.state is not None else None}
+        with open(filepath, 'wb') as f:
+            pickle.dump(blob, f, protocol=2)
+
+
+class Sequential(Model):
+    def __init__(self, layers=None, name=None):
+        Model.__init__(self, name=name)
+        for l in (layers or []):
+            self.add(l)
+
+    def add(self, layer):
+        if not self.nodes:
+            shp = layer.input_shape_arg if not isinstance(layer, Model) else (layer.input_shapes[0] if layer.input_shapes else None)
+            if shp is None:
+                raise ValueError('the first layer of a Sequential needs input_shape=')
+            self.input_shapes = [tuple(shp)]
+            prev, prev_shape = -1, tuple(shp)
+        else:
+            prev = self.output_ids[0]
+            prev_shape = self.nodes[prev].out_shape
+        if isinstance(layer, Model):
+            out_shape = layer.nodes[layer.output_ids[0]].out_shape
+        else:
+            layer._ensure_built(prev_shape)
+            out_shape = tuple(layer.compute_output_shape(prev_shape))
+        idx = self._append(layer, [prev], out_shape)
+        self.output_ids = [idx]
+        self.built = True
+        return self
+
+
+def load_model(filepath, custom_objects=None):
+    """keras.models.load_model counterpart for files written by Model.save (needs the builder config, see bbh.py)."""
+    with open(filepath, 'rb') as f:
+        blob = pickle.load(f)
+    cfg = blob.get('config')
+    if cfg is None:
+        raise ValueError('%s holds weights but no model config; rebuild the model and use load_weights' % filepath)
+    from . import bbh
+    model = bbh.model_from_config(cfg)
+    model.set_weights(blob['weights'])
+    if blob.get('loss') is not None and blob.get('optimizer') is not None:
+        lr, b1, b2, eps = blob['optimizer']['config']
+        model.compile(loss=blob['loss'], optimizer=Adam(lr=lr, beta_1=b1, beta_2=b2, epsilon=eps), metrics=blob['metrics'])
+        model._ensure_bound()
+        model.optimizer.set_state(blob['optimizer'])
+    return model

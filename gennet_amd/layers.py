@@ -1,0 +1,360 @@
+"""Keras-style layers used by BBH_version/bbhMahoGANy.py, executing on the HIP kernel library (gennet_amd.ops).
+
+Layer list and defaults follow bbhMahoGANy.py:33-40 and SURVEY Appendix B: channels_last, glorot_uniform kernels, zero
+biases, BatchNormalization(axis=-1, epsilon=1e-3, gamma=1, beta=0, moving_mean=0, moving_variance=1).
+Layers that the reference imports but never places on the hot path are not provided; asking for an unsupported
+configuration raises instead of silently running something else.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .engine import Layer, Model, device, device_rng, glorot_uniform
+
+_ACT_NAMES = {'relu': ('relu', 0.0), 'tanh': ('tanh', 0.0), 'sigmoid': ('sigmoid', 0.0), 'linear': ('linear', 0.0), None: ('linear', 0.0)}
+
+
+def _check_init(kernel_initializer):
+    if kernel_initializer not in (None, 'glorot_uniform'):
+        raise NotImplementedError('kernel_initializer %r (only glorot_uniform is used on the hot path)' % (kernel_initializer,))
+
+
+class Dense(Layer):
+    """bbhMahoGANy.py:234 (100 -> 256*n_pix/2, MFMA GEMM), :377,:399,:494 (flatten -> 1 heads, streaming dot product)."""
+    fusable_act = True
+
+    def __init__(self, units, activation=None, kernel_initializer='glorot_uniform', use_bias=True, **kw):
+        Layer.__init__(self, **kw)
+        _check_init(kernel_initializer)
+        if not use_bias:
+            raise NotImplementedError('Dense(use_bias=False)')
+        self.units = int(units)
+        self.activation = _ACT_NAMES[activation]
+
+    def build(self, input_shape):
+        assert len(input_shape) == 1, 'Dense expects (batch, features); Flatten first'
+        self.kernel = self.add_weight('kernel', glorot_uniform((input_shape[0], self.units)))
+        self.bias = self.add_weight('bias', np.zeros(self.units, np.float32))
+
+    def compute_output_shape(self, input_shape):
+        return (self.units,)
+
+    def _act(self, node):
+        a = node.fused_act or self.activation
+        if node.fused_act is not None and self.activation[0] != 'linear':
+            raise NotImplementedError('Dense(activation=...) followed by another activation layer')
+        return a
+
+    def forward(self, ctx, node, x):
+        a = self._act(node)
+        y = ops.dense_fwd(x, self.kernel.data, self.bias.data, a[0], a[1])
+        ctx.tape[node.index] = (x, y, a)
+        return y
+
+    def backward(self, ctx, node, dy, need_dx, need_dw):
+        x, y, a = ctx.tape.pop(node.index)
+        dy = dy.contiguous()
+        if a[0] != 'linear':
+            dy = ops.act_bwd(dy, y, a[0], a[1], inplace=True)
+        if need_dw:
+            dx, _, _ = ops.dense_bwd(x, self.kernel.data, dy, need_dx, self.kernel.grad, self.bias.grad)
+            return dx
+        # frozen layer: data gradient only (scratch weight-gradient buffers are not needed on the small-output path)
+        dx, _, _ = ops.dense_bwd(x, self.kernel.data, dy, True)
+        return dx
+
+
+class Conv1D(Layer):
+    """bbhMahoGANy.py:250-292, :362-394."""
+    fusable_act = True
+
+    def __init__(self, filters, kernel_size, strides=1, padding='valid', activation=None, kernel_initializer='glorot_uniform', use_bias=True, **kw):
+        Layer.__init__(self, **kw)
+        _check_init(kernel_initializer)
+        if not use_bias:
+            raise NotImplementedError('Conv1D(use_bias=False)')
+        self.filters = int(filters)
+        self.k = int(kernel_size[0] if isinstance(kernel_size, (tuple, list)) else kernel_size)
+        self.stride = int(strides[0] if isinstance(strides, (tuple, list)) else strides)
+        if padding not in ('same', 'valid'):
+            raise NotImplementedError('padding %r' % (padding,))
+        self.padding = padding
+        self.activation = _ACT_NAMES[activation]
+
+    def build(self, input_shape):
+        L, Cin = input_shape
+        self.kernel = self.add_weight('kernel', glorot_uniform((self.k, Cin, self.filters)))
+        self.bias = self.add_weight('bias', np.zeros(self.filters, np.float32))
+
+    def compute_output_shape(self, input_shape):
+        return (ops.conv_geometry(input_shape[0], self.k, self.stride, self.padding)[0], self.filters)
+
+    def forward(self, ctx, node, x):
+        a = node.fused_act or self.activation
+        Lout, pl = ops.conv_geometry(x.shape[1], self.k, self.stride, self.padding)
+        y = ops.conv1d_fwd(x, self.kernel.data, self.bias.data, self.stride, pl, Lout, a[0], a[1])
+        ctx.tape[node.index] = (x, y, a, pl)
+        return y
+
+    def backward(self, ctx, node, dy, need_dx, need_dw):
+        x, y, a, pl = ctx.tape.pop(node.index)
+        dy = dy.contiguous()
+        if a[0] != 'linear':
+            dy = ops.act_bwd(dy, y, a[0], a[1], inplace=True)
+        if need_dw:
+            ops.conv1d_wgrad(x, dy, self.k, self.stride, pl, self.kernel.grad, self.bias.grad)
+        if need_dx:
+            return ops.conv1d_dgrad(dy, ops.conv1d_transpose_w(self.kernel.data), x.shape[1], self.stride, pl)
+        return None
+
+
+class Conv2D(Layer):
+    """bbhMahoGANy.py:439,:447: Conv2D(C, (5,5), strides=(2,1), padding='same') on a width-2 image (n, 2, Cin).
+    Executed as the exactly equivalent Conv1D over H with (w,c)-interleaved channels (SURVEY section 2.2); the dead
+    width taps kw in {0,4} receive zero gradient, as they do in the reference."""
+    fusable_act = True
+
+    def __init__(self, filters, kernel_size, strides=(1, 1), padding='valid', activation=None, kernel_initializer='glorot_uniform', use_bias=True, **kw):
+        Layer.__init__(self, **kw)
+        _check_init(kernel_initializer)
+        self.filters = int(filters)
+        self.kh, self.kw = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        self.sh, self.sw = (strides, strides) if isinstance(strides, int) else tuple(strides)
+        self.padding = padding
+        self.activation = _ACT_NAMES[activation]
+        if self.kw != 5 or self.sw != 1 or padding != 'same' or not use_bias:
+            raise NotImplementedError('Conv2D is implemented for the hot-path case only: kernel (kh,5), strides (sh,1), padding "same", width-2 input')
+
+    def build(self, input_shape):
+        H, W, Cin = input_shape
+        if W != 2:
+            raise NotImplementedError('Conv2D is implemented for width-2 images (got width %d)' % W)
+        self.kernel = self.add_weight('kernel', glorot_uniform((self.kh, self.kw, Cin, self.filters)))
+        self.bias = self.add_weight('bias', np.zeros(self.filters, np.float32))
+
+    def compute_output_shape(self, input_shape):
+        return (ops.conv_geometry(input_shape[0], self.kh, self.sh, 'same')[0], 2, self.filters)
+
+    def forward(self, ctx, node, x):
+        a = node.fused_act or self.activation
+        B, H, W, Cin = x.shape
+        Lout, pl = ops.conv_geometry(H, self.kh, self.sh, 'same')
+        wf, bf = ops.conv2d_w2_fold(self.kernel.data, self.bias.data)
+        xf = x.reshape(B, H, 2 * Cin)
+        y = ops.conv1d_fwd(xf, wf, bf, self.sh, pl, Lout, a[0], a[1])
+        ctx.tape[node.index] = (xf, y, a, pl, wf, Cin)
+        return y.reshape(B, Lout, 2, self.filters)
+
+    def backward(self, ctx, node, dy, need_dx, need_dw):
+        xf, y, a, pl, wf, Cin = ctx.tape.pop(node.index)
+        dy = dy.contiguous().reshape(y.shape)
+        if a[0] != 'linear':
+            dy = ops.act_bwd(dy, y, a[0], a[1], inplace=True)
+        if need_dw:
+            dwf, dbf = ops.conv1d_wgrad(xf, dy, self.kh, self.sh, pl)
+            ops.conv2d_w2_unfold_grad(dwf, dbf, Cin, self.filters, self.kernel.grad, self.bias.grad)
+        if need_dx:
+            dx = ops.conv1d_dgrad(dy, ops.conv1d_transpose_w(wf), xf.shape[1], self.sh, pl)
+            return dx.reshape(xf.shape[0], xf.shape[1], 2, Cin)
+        return None
+
+
+class BatchNormalization(Layer):
+    """bbhMahoGANy.py:235,:251,:260,:268,:276,:284 (momentum=0.99).  Train phase: batch mean / biased variance (fp64
+    accumulation), moving statistics updated with keras' n/(n-(1+eps)) variance correction; inference: moving statistics.
+    A following Activation and Dropout run in the same pass (one read, one write).  Under data parallelism the
+    statistics are all-reduced (SyncBN) so that N ranks x B/N rows reproduce a single-device batch of B."""
+    fusable_act = True
+    fusable_drop = True
+
+    def __init__(self, axis=-1, momentum=0.99, epsilon=1e-3, **kw):
+        Layer.__init__(self, **kw)
+        if axis != -1:
+            raise NotImplementedError('BatchNormalization(axis=%r)' % (axis,))
+        self.momentum, self.epsilon = float(momentum), float(epsilon)
+
+    def build(self, input_shape):
+        C = input_shape[-1]
+        self.gamma = self.add_weight('gamma', np.ones(C, np.float32))
+        self.beta = self.add_weight('beta', np.zeros(C, np.float32))
+        self.moving_mean = self.add_weight('moving_mean', np.zeros(C, np.float32), trainable=False)
+        self.moving_variance = self.add_weight('moving_variance', np.ones(C, np.float32), trainable=False)
+
+    def forward(self, ctx, node, x):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        act = node.fused_act or ('linear', 0.0)
+        if not ctx.training:
+            scale, shift = ops.bn_infer_coeffs(self.gamma.data, self.beta.data, self.moving_mean.data, self.moving_variance.data, self.epsilon)
+            return ops.bn_apply(x2, scale, shift, None, act[0], act[1]).reshape(x.shape)
+        sums = ops.bn_stats(x2)
+        count = x2.shape[0]
+        if ctx.dp is not None:
+            ctx.dp.all_reduce_sum(sums)
+            count *= ctx.dp.world_size
+        scale, shift, smean, sinv = ops.bn_finalize(sums, count, self.gamma.data, self.beta.data, self.epsilon, self.momentum,
+                                                    self.moving_mean.data, self.moving_variance.data)
+        mask, rate = None, 0.0
+        if node.fused_drop is not None:
+            rate, drop_layer = node.fused_drop
+            mask = drop_layer.make_mask(ctx, x2.shape)
+        y = ops.bn_apply(x2, scale, shift, mask, act[0], act[1], rate)
+        ctx.tape[node.index] = (x2, y, mask, smean, sinv, count, act, rate)
+        return y.reshape(x.shape)
+
+    def backward(self, ctx, node, dy, need_dx, need_dw):
+        x2, y, mask, smean, sinv, count, act, rate = ctx.tape.pop(node.index)
+        dy2 = dy.contiguous().reshape(x2.shape)
+        local = ops.bn_bwd_stats(dy2, y, x2, mask, smean, sinv, act[0], act[1], rate)
+        glob = local
+        if ctx.dp is not None:
+            glob = local.clone()
+            ctx.dp.all_reduce_sum(glob)
+        if need_dw:
+            dgamma, dbeta = self.gamma.grad, self.beta.grad
+        else:
+            dgamma = torch.empty_like(self.gamma.data); dbeta = torch.empty_like(self.beta.data)
+        dx = ops.bn_bwd_apply(dy2, y, x2, mask, self.gamma.data, smean, sinv, glob, count, local, dgamma, dbeta, act[0], act[1], rate)
+        return dx.reshape(dy.shape)
+
+
+class Activation(Layer):
+    def __init__(self, activation, **kw):
+        Layer.__init__(self, **kw)
+        if activation not in _ACT_NAMES:
+            raise NotImplementedError('Activation(%r)' % (activation,))
+        self.act_spec = _ACT_NAMES[activation]
+
+    def forward(self, ctx, node, x):
+        y = x if self.act_spec[0] == 'linear' else ops.act_fwd(x.contiguous(), self.act_spec[0], self.act_spec[1])
+        ctx.tape[node.index] = y
+        return y
+
+    def backward(self, ctx, node, dy, need_dx, need_dw):
+        y = ctx.tape.pop(node.index)
+        if self.act_spec[0] == 'linear':
+            return dy
+        return ops.act_bwd(dy.contiguous(), y, self.act_spec[0], self.act_spec[1])
+
+
+class LeakyReLU(Activation):
+    def __init__(self, alpha=0.3, **kw):
+        Layer.__init__(self, **kw)
+        self.act_spec = ('leaky', float(alpha))
+
+
+class ReLU(Activation):
+    """keras.layers.ReLU(max_value=...) (bbhMahoGANy.py:400: ReLU(max_value=1.0))."""
+
+    def __init__(self, max_value=None, negative_slope=0.0, threshold=0.0, **kw):
+        Layer.__init__(self, **kw)
+        if negative_slope or threshold:
+            raise NotImplementedError('ReLU(negative_slope/threshold)')
+        self.act_spec = ('relu', 0.0) if max_value is None else ('relu_max', float(max_value))
+
+
+class Dropout(Layer):
+    """Inverted dropout, active in the training phase only (which keras applies to the WHOLE graph in train_on_batch,
+    including layers of frozen sub-models: bbhMahoGANy.py:1296 keeps D's Dropout(0.4) active during the G step)."""
+
+    def __init__(self, rate, **kw):
+        Layer.__init__(self, **kw)
+        self.rate = float(rate)
+        self.drop_rate = self.rate
+
+    def make_mask(self, ctx, shape):
+        inj = ctx.dropout_masks.get(self.name)
+        if inj is not None:
+            return inj.reshape(shape).contiguous()
+        n = int(np.prod(shape))
+        seed, off = device_rng().take(n)
+        return ops.dropout_mask(shape, self.rate, seed, off, device())
+
+    def forward(self, ctx, node, x):
+        if not ctx.training or self.rate == 0.0:
+            ctx.tape[node.index] = None
+            return x
+        mask = self.make_mask(ctx, x.shape)
+        ctx.tape[node.index] = mask
+        return ops.dropout_apply(x.contiguous(), mask, self.rate)
+
+    def backward(self, ctx, node, dy, need_dx, need_dw):
+        mask = ctx.tape.pop(node.index)
+        if mask is None:
+            return dy
+        return ops.dropout_apply(dy.contiguous(), mask, self.rate)
+
+
+class Reshape(Layer):
+    def __init__(self, target_shape, **kw):
+        Layer.__init__(self, **kw)
+        self.target_shape = tuple(int(v) for v in target_shape)
+
+    def compute_output_shape(self, input_shape):
+        assert int(np.prod(input_shape)) == int(np.prod(self.target_shape))
+        return self.target_shape
+
+    def forward(self, ctx, node, x):
+        ctx.tape[node.index] = x.shape
+        return x.reshape((x.shape[0],) + self.target_shape)
+
+    def backward(self, ctx, node, dy, need_dx, need_dw):
+        return dy.reshape(ctx.tape.pop(node.index))
+
+
+class Flatten(Layer):
+    """Row-major flatten of channels-last activations: feature index = t*C + c (keras order, SURVEY Appendix B.7)."""
+
+    def compute_output_shape(self, input_shape):
+        return (int(np.prod(input_shape)),)
+
+    def forward(self, ctx, node, x):
+        ctx.tape[node.index] = x.shape
+        return x.reshape(x.shape[0], -1)
+
+    def backward(self, ctx, node, dy, need_dx, need_dw):
+        return dy.reshape(ctx.tape.pop(node.index))
+
+
+class UpSampling1D(Layer):
+    """bbhMahoGANy.py:249,:258."""
+
+    def __init__(self, size=2, **kw):
+        Layer.__init__(self, **kw)
+        if size != 2:
+            raise NotImplementedError('UpSampling1D(size=%r)' % (size,))
+
+    def compute_output_shape(self, input_shape):
+        return (2 * input_shape[0], input_shape[1])
+
+    def forward(self, ctx, node, x):
+        return ops.upsample2_fwd(x.contiguous())
+
+    def backward(self, ctx, node, dy, need_dx, need_dw):
+        return ops.upsample2_bwd(dy.contiguous())
+
+
+class MyLayer(Layer):
+    """bbhMahoGANy.py:164-188: stack([x, const - x], axis=2): (B, n_pix, 1) -> (B, n_pix, 2, 1), const = measured data h(t)."""
+
+    def __init__(self, const, **kw):
+        Layer.__init__(self, **kw)
+        self._const_host = np.asarray(const, np.float32).reshape(-1)
+        self._const = None
+
+    @property
+    def const(self):
+        if self._const is None:
+            from .engine import to_device
+            self._const = to_device(self._const_host)
+        return self._const
+
+    def compute_output_shape(self, input_shape):
+        return (input_shape[0], 2, 1)
+
+    def forward(self, ctx, node, x):
+        assert x.shape[1] == self.const.numel()
+        return ops.subtract_stack_fwd(x.contiguous(), self.const)
+
+    def backward(self, ctx, node, dy, need_dx, need_dw):
+        return ops.subtract_stack_bwd(dy.contiguous())

@@ -1,0 +1,230 @@
+"""GPU parity of the three BBH networks against the fp64 oracle (oracle/nets_ref.py), through the Keras-style surface.
+
+Identical initial weights (oracle draws them, rounded to fp32), identical inputs, injected dropout masks.  Tolerances
+(stated per assert): loss 1e-5 relative for one train_on_batch; gradients / weights after Adam steps 1e-4 relative to the
+largest entry of each tensor (SURVEY section 7 suggested bounds).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import keras_ref as K
+from oracle import nets_ref as N
+
+pytestmark = pytest.mark.gpu
+
+
+def f32(a):
+    return np.asarray(a, np.float32).astype(np.float64)
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def load_stack_into_layers(stack, layers):
+    """Copy oracle Stack parameters (and BN moving statistics) into the trainable layers of a gennet_amd model."""
+    from gennet_amd.engine import to_device
+    with_params = [l for l in layers if l.weights]
+    specs = [(li, s) for li, s in enumerate(stack.spec) if s[0] in ('dense', 'conv1d', 'conv2d', 'bn')]
+    assert len(with_params) == len(specs)
+    for l, (li, s) in zip(with_params, specs):
+        ps = [stack.params[i] for i in stack.pidx[li]]
+        for p, v in zip(l.params, ps):
+            p.data.copy_(to_device(v.astype(np.float32)))
+        if s[0] == 'bn':
+            l.moving_mean.data.copy_(to_device(stack.state[li][0].astype(np.float32)))
+            l.moving_variance.data.copy_(to_device(stack.state[li][1].astype(np.float32)))
+
+
+def round_stack(stack):
+    for p in stack.params:
+        p[...] = f32(p)
+
+
+def stack_masks(stack, x, rng):
+    """Keep masks for the dropout layers of a Stack, by walking shapes with an inference pass."""
+    masks = {}
+    h = x
+    for li, s in enumerate(stack.spec):
+        one = N.Stack.__new__(N.Stack)
+        one.spec = [s]; one.params = [stack.params[i] for i in stack.pidx[li]]; one.pidx = [list(range(len(one.params)))]
+        one.state = {0: stack.state[li]} if li in stack.state else {}
+        if s[0] == 'drop':
+            masks[li] = (rng.rand(*h.shape) >= s[1]).astype(np.float64)
+        h = one.forward(h, False)
+    return masks
+
+
+def masks_by_name(stack, masks, layers):
+    from gennet_amd.layers import Dropout
+    drops = [l for l in layers if isinstance(l, Dropout)]
+    idx = [li for li, s in enumerate(stack.spec) if s[0] == 'drop']
+    assert len(drops) == len(idx)
+    return {l.name: masks[li].astype(np.uint8) for l, li in zip(drops, idx)}
+
+
+@pytest.mark.parametrize("n_pix,B", [(128, 6), (256, 5)])
+def test_pe_train_on_batch_matches_oracle(n_pix, B):
+    from gennet_amd import bbh
+    from gennet_amd.engine import Adam
+    rng = np.random.RandomState(n_pix)
+    ref = N.PENet(n_pix, rng)
+    round_stack(ref.mc); round_stack(ref.q)
+    ref.mc.params[-1][...] = 25.0; ref.q.params[-1][...] = 0.6      # heads start inside the active range of relu / relu(max 1)
+    model = bbh.signal_pe_model(n_pix)
+    layers = model.layers
+    n_mc = len([s for s in ref.mc.spec if s[0] in ('dense', 'conv1d')])
+    with_params = [l for l in layers if l.weights]
+    load_stack_into_layers(ref.mc, with_params[:n_mc])
+    load_stack_into_layers(ref.q, with_params[n_mc:])
+    model.compile(loss='mean_squared_error', optimizer=Adam(lr=9e-5, beta_1=0.5), metrics=['accuracy'])
+
+    x = f32(rng.randn(B, n_pix, 1)); y_mc = f32(rng.uniform(20, 35, B)); y_q = f32(rng.uniform(0.5, 1, B))
+    p_ref = ref.predict(x)
+    p = model.predict(x)
+    assert rel(p[0], p_ref[0]) < 2e-5 and rel(p[1], p_ref[1]) < 2e-5
+    for step in range(3):
+        out_ref = ref.train_on_batch(x, y_mc, y_q)
+        out = model.train_on_batch(x, [y_mc, y_q])
+        assert len(out) == 5                                          # [total, mc_loss, q_loss, mc_acc, q_acc]
+        for a, b in zip(out[:3], out_ref[:3]):
+            assert abs(a - b) <= 1e-5 * abs(b) + 1e-7, (step, out, out_ref)
+        assert out[3:] == pytest.approx(out_ref[3:])
+        if step == 0:
+            grads = [p_.grad.cpu().numpy() for l in with_params for p_ in l.params]
+            for gq, gr in zip(grads, ref.last_grads):
+                assert rel(gq, gr) < 1e-4
+    # Adam normalises every element's step to ~lr, so an element whose gradient is tiny relative to its tensor's maximum carries
+    # the gradient's ABSOLUTE error at full weight: bound = 1e-4 relative + 1 % of the step budget (3 steps x lr)
+    ws = [p_.data.cpu().numpy() for l in with_params for p_ in l.params]
+    for w, wr in zip(ws, ref.mc.params + ref.q.params):
+        assert np.abs(w - wr).max() <= 1e-4 * np.abs(wr).max() + 0.01 * 3 * 9e-5
+
+
+def _build_gan(n_pix, rng):
+    from gennet_amd import bbh
+    event = f32(rng.randn(n_pix, 1))
+    ref = N.GAN(n_pix, event, rng)
+    round_stack(ref.G); round_stack(ref.D)
+    for st in (ref.G, ref.D):
+        for p in st.params:
+            if p.ndim == 1:
+                p[...] = f32(p + 0.05 * rng.randn(*p.shape))
+    nets = bbh.build_and_compile(event, n_pix, do_pe=False)
+    load_stack_into_layers(ref.G, nets.generator.layers)
+    load_stack_into_layers(ref.D, nets.signal_discriminator.layers)
+    return ref, nets, event
+
+
+def test_gan_iteration_matches_oracle():
+    """One full GAN iteration (bbhMahoGANy.py:1241-1299) with injected masks: D step on [real | fake], then G step through the
+    frozen D; then a second iteration to exercise the moving statistics and both Adam states."""
+    from gennet_amd import bbh
+    from gennet_amd.engine import to_device
+    n_pix, B = 64, 4
+    rng = np.random.RandomState(3)
+    ref, nets, event = _build_gan(n_pix, rng)
+    ev_dev = to_device(event.reshape(-1))
+    G, D, DG = nets.generator, nets.signal_discriminator, nets.signal_discriminator_on_generator
+    # the combined model trains exactly the generator's weights; the discriminator model its own
+    assert set(id(p) for p in DG._train_params) == set(id(p) for l in G.layers for p in l.params)
+    assert set(id(p) for p in D._train_params) == set(id(p) for l in D.layers for p in l.params)
+    for it in range(2):
+        z = f32(rng.uniform(-1, 1, (B, 100)))
+        fake_ref = ref.generate(z)
+        fake = G.predict(z)
+        assert rel(fake, fake_ref) < 5e-5
+        real = f32(rng.randn(B, n_pix)); noise = f32(rng.randn(B, n_pix, 1))
+        sX_ref, sy = ref.assemble_d_batch(real, noise, fake_ref)
+        sX, syd = bbh.assemble_discriminator_batch(to_device(real), to_device(noise), to_device(fake_ref), ev_dev)
+        assert rel(sX.cpu().numpy(), sX_ref) < 1e-6
+        assert syd.cpu().numpy().tolist() == sy
+        d_masks = stack_masks(ref.D, sX_ref, rng)
+        out_ref = ref.d_train_on_batch(sX_ref, sy, d_masks)
+        out = D.train_on_batch(sX_ref, sy, dropout_masks=masks_by_name(ref.D, d_masks, D.layers))
+        assert abs(out[0] - out_ref[0]) <= 2e-5 * abs(out_ref[0]) and out[1] == pytest.approx(out_ref[1])
+        dgr = [p.grad.cpu().numpy() for l in D.layers for p in l.params]
+        for gq, gr in zip(dgr, ref.last_d_grads):
+            assert rel(gq, gr) < 2e-4
+        assert np.all(dgr[0][:, 0] == 0) and np.all(dgr[0][:, 4] == 0)      # dead width taps of the 5x5 kernel
+
+        z2 = f32(rng.uniform(-1, 1, (B, 100)))
+        g_masks = stack_masks(ref.G, z2, rng)
+        img_shape_probe = K.mylayer_fwd(ref.G.forward(z2, False), ref.event)
+        d_masks2 = stack_masks(ref.D, img_shape_probe, rng)
+        out_ref = ref.g_train_on_batch(z2, [1] * B, g_masks, d_masks2)
+        names = dict(masks_by_name(ref.G, g_masks, G.layers)); names.update(masks_by_name(ref.D, d_masks2, D.layers))
+        d_before = [p.data.clone() for l in D.layers for p in l.params]
+        out = DG.train_on_batch(z2, [1] * B, dropout_masks=names)
+        assert abs(out[0] - out_ref[0]) <= 2e-5 * abs(out_ref[0]) and out[1] == pytest.approx(out_ref[1])
+        ggr = [p.grad.cpu().numpy() for l in G.layers for p in l.params]
+        gmax = max(np.abs(gr).max() for gr in ref.last_g_grads)
+        for k, (gq, gr) in enumerate(zip(ggr, ref.last_g_grads)):
+            # biases feeding a BatchNorm have an exactly-zero gradient in exact arithmetic: absolute floor 1e-6 of the largest gradient
+            assert np.abs(gq - gr).max() <= 3e-4 * np.abs(gr).max() + 1e-6 * gmax, (k, rel(gq, gr))
+        for a, b in zip(d_before, [p.data for l in D.layers for p in l.params]):
+            assert torch.equal(a, b)                                          # D frozen as of compile time
+    # weights and BN moving statistics after two iterations
+    for st, model in ((ref.G, G), (ref.D, D)):
+        ws = [p.data.cpu().numpy() for l in model.layers for p in l.params]
+        for w, wr in zip(ws, st.params):
+            assert np.abs(w - wr).max() <= 2e-4 * np.abs(wr).max() + 0.02 * 2 * 9e-5      # see the Adam note in the PE test
+    bns = [l for l in G.layers if hasattr(l, 'moving_mean')]
+    bn_idx = [li for li, s in enumerate(ref.G.spec) if s[0] == 'bn']
+    for l, li in zip(bns, bn_idx):
+        assert rel(l.moving_mean.data.cpu().numpy(), ref.G.state[li][0]) < 1e-4 or np.abs(ref.G.state[li][0]).max() < 1e-6
+        assert rel(l.moving_variance.data.cpu().numpy(), ref.G.state[li][1]) < 1e-4
+
+
+def test_unfused_layers_match_fused_epilogues():
+    """Standalone Activation / Dropout kernels (graph where fusion is impossible) equal the fused epilogue path."""
+    from gennet_amd.engine import Adam, Input, Model, Sequential
+    from gennet_amd.layers import Activation, Conv1D, Dense, Dropout, Flatten
+    rng = np.random.RandomState(21)
+    x = f32(rng.randn(3, 40, 1))
+    inp = Input(shape=(40, 1))
+    c = Conv1D(16, 5, padding='same', name='c_shared')
+    h = c(inp)
+    a = Activation('tanh')(h)          # h has two consumers below -> the activation cannot be fused into the conv
+    f1 = Flatten()(a); f2 = Flatten()(h)
+    o1 = Dense(1)(f1); o2 = Dense(1)(f2)
+    m = Model(inputs=inp, outputs=[o1, o2])
+    m._plan()
+    assert all(n.fused_act is None for n in m.nodes if n.layer is c)
+    w, b = c.get_weights()
+    y1, y2 = m.predict(x)
+    d1, d2 = [l for l in m.layers if isinstance(l, Dense)]
+    hh = K.conv1d_fwd(x, f32(w), f32(b), 1, 'same')
+    r1 = K.dense_fwd(np.tanh(hh).reshape(3, -1), f32(d1.get_weights()[0]), f32(d1.get_weights()[1]))
+    r2 = K.dense_fwd(hh.reshape(3, -1), f32(d2.get_weights()[0]), f32(d2.get_weights()[1]))
+    assert rel(y1, r1) < 2e-5 and rel(y2, r2) < 2e-5
+    m.compile(loss='mean_squared_error', optimizer=Adam(lr=1e-3), metrics=['accuracy'])
+    out = m.train_on_batch(x, [np.zeros(3), np.zeros(3)])
+    assert np.isfinite(out).all()
+
+
+def test_save_load_roundtrip(tmp_path):
+    from gennet_amd import bbh
+    from gennet_amd.engine import Adam, load_model
+    rng = np.random.RandomState(5)
+    m = bbh.signal_pe_model(128)
+    m.compile(loss='mean_squared_error', optimizer=Adam(lr=9e-5, beta_1=0.5), metrics=['accuracy'])
+    x = f32(rng.randn(4, 128, 1))
+    m.train_on_batch(x, [np.full(4, 30.0), np.full(4, 0.8)])
+    path = str(tmp_path / 'signal_pe.h5')
+    m.save(path, True)
+    m2 = load_model(path)
+    for a, b in zip(m.predict(x), m2.predict(x)):
+        assert np.array_equal(a, b)
+    r1 = m.train_on_batch(x, [np.full(4, 30.0), np.full(4, 0.8)])
+    r2 = m2.train_on_batch(x, [np.full(4, 30.0), np.full(4, 0.8)])
+    assert r1 == r2                                                       # optimizer state restored bit-for-bit
+    g = bbh.generator_model(64)
+    wpath = str(tmp_path / 'generator.h5')
+    g.save_weights(wpath, True)
+    g2 = bbh.generator_model(64)
+    g2.load_weights(wpath)
+    z = f32(rng.uniform(-1, 1, (3, 100)))
+    assert np.array_equal(g.predict(z), g2.predict(z))
