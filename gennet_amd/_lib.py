@@ -45,7 +45,7 @@ _SIGS = {
     'gn_adam_step': [vp, vp, vp, vp, sz, f32, f32, f32, f32, vp],
     'gn_prof_enable': [i32],
     'gn_prof_reset': [],
-    'gn_prof_collect': [vp],
+    'gn_prof_collect': [i32, vp],
     'gn_chirp_fd_whitened': [vp, vp, vp, vp, vp, i32, i32, f64, f64, f64, f64, f64, vp],
     'gn_irfft_f64': [vp, vp, i32, i32, vp],
     'gn_align_crop': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f64, f64, f64, vp],

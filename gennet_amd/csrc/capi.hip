@@ -29,6 +29,7 @@ int check_launch(const char* what) {
 struct ProfRec {
   hipEvent_t a, b;
   double flop;
+  int kind;
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -53,12 +54,12 @@ void prof_begin(hipStream_t s) {
   (void)hipEventRecord(g_cur, s);
 }
 
-void prof_end(hipStream_t s, double flop) {
+void prof_end(hipStream_t s, double flop, int kind) {
   if (!g_prof_on) return;
   hipEvent_t b = get_event();
   (void)hipEventRecord(b, s);
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof.push_back({g_cur, b, flop});
+  g_prof.push_back({g_cur, b, flop, kind});
 }
 
 static void fwd_taps(ConvTaps* t, int k, int stride, int pad_left) {
@@ -142,17 +143,19 @@ int gn_prof_reset(void) {
   g_prof.clear();
   return GN_OK;
 }
-int gn_prof_collect(double* out) {
+int gn_prof_collect(int kind, double* out) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  double ms = 0, flop = 0;
+  double ms = 0, flop = 0, cnt = 0;
   for (auto& r : g_prof) {
+    if (kind >= 0 && r.kind != kind) continue;
+    cnt += 1;
     if (hipEventSynchronize(r.b) != hipSuccess) { set_error("prof: event sync failed"); return GN_ELAUNCH; }
     float t = 0;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) { set_error("prof: elapsed failed"); return GN_ELAUNCH; }
     ms += t;
     flop += r.flop;
   }
-  out[0] = (double)g_prof.size();
+  out[0] = cnt;
   out[1] = ms;
   out[2] = flop;
   return GN_OK;

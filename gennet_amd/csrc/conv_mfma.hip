@@ -152,7 +152,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
   }
   prof_begin(s);
   hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, KC>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles);
-  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout);
+  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0);
   return check_launch("conv_mfma");
 }
 
@@ -304,7 +304,7 @@ static int launch_wgrad(WgradArgs a, float* dw, hipStream_t s) {
   dim3 grid(cdiv(a.Cin, TC), cdiv(a.Cout, TN), splits);
   prof_begin(s);
   hipLaunchKernelGGL((wgrad_mfma_kernel<WAVES_C, WAVES_N, NTAPS, KT>), grid, dim3(64 * WAVES_C * WAVES_N), lds, s, a);
-  prof_end(s, 2.0 * a.B * (double)a.M * NTAPS * a.Cin * a.Cout);
+  prof_end(s, 2.0 * a.B * (double)a.M * NTAPS * a.Cin * a.Cout, 1);
   int rc = check_launch("wgrad_mfma");
   if (rc) return rc;
   const size_t n = (size_t)NTAPS * a.Cin * a.Cout;

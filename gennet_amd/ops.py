@@ -308,8 +308,9 @@ def prof_reset():
     _lib.call('gn_prof_reset')
 
 
-def prof_collect():
+def prof_collect(kind=-1):
+    """kind 0: conv_mfma_kernel (forward + data gradient), 1: wgrad_mfma_kernel, -1: both."""
     import ctypes
     out = (ctypes.c_double * 3)()
-    _lib.call('gn_prof_collect', ctypes.cast(out, ctypes.c_void_p))
+    _lib.call('gn_prof_collect', int(kind), ctypes.cast(out, ctypes.c_void_p))
     return {'launches': int(out[0]), 'ms': out[1], 'flop': out[2]}
