@@ -47,7 +47,9 @@ _SIGS = {
     'gn_prof_reset': [],
     'gn_prof_collect': [i32, vp],
     'gn_chirp_fd_whitened': [vp, vp, vp, vp, vp, i32, i32, f64, f64, f64, f64, f64, vp],
-    'gn_irfft_f64': [vp, vp, i32, i32, vp],
+    'gn_irfft_f64': [vp, vp, vp, i32, i32, vp],
+    'gn_rfft_f64': [vp, vp, vp, i32, i32, vp],
+    'gn_mul_f64': [vp, vp, sz, sz, i32, vp],
     'gn_align_crop': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f64, f64, f64, vp],
     'gn_noise_fd': [vp, vp, i32, i32, u64, u64, vp],
     'gn_scale_f64': [vp, f64, sz, vp],

@@ -1,0 +1,364 @@
+"""Host-side mirror of BBH_version/gw_template_maker.py: the waveform + noise batch synthesiser and its ts/pars files.
+
+Same function names, argument meaning and return shapes as the reference (SURVEY section 8b "Synth surface"); the reference's
+per-template python loop (gw_template_maker.py:676, one LAL call + two irFFTs + three discarded spline fits per template,
+serial) becomes batched HIP kernels: FD chirp + PSD whitening -> batched irFFT (whole transform in LDS) -> argmax-align,
+antenna combination and 1-s crop, all fp64 like numpy, nothing touching host memory until the bank is pickled.
+
+The frequency-domain waveform is NOT LAL's IMRPhenomPv2 (LALSuite cannot be reproduced offline): `gn_chirp_fd_whitened` is
+this project's own closed-form non-spinning inspiral-merger-ringdown chirp (PhenomA functional form).  Everything
+downstream of h~(f) follows the reference sample for sample, including the integer alignment arithmetic of :554.
+
+Random draws that define the bank (masses, the five discarded angles, idx, the final permutation) stay on the host numpy
+legacy stream in the reference's order, so a seeded run selects exactly the reference's parameters.
+"""
+import pickle
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import device
+
+safe = 2                       # gw_template_maker.py:54
+gw_tmp = True                  # :56
+event_time = '1126259462'      # :62
+PEAK_OFFSET = 11               # :554 (comment there: "use 21 if sampling at 2kHz") -- a parameter of gen_bbh / sim_data here
+F_LOW, DIST_MPC = 40.0, 410.0  # :495, :500
+RA, DEC, IOTA, PHI, PSI = 2.21535724066, -1.23649695537, 2.5, 1.5, 1.75    # :433-437
+
+
+class bbhparams(object):
+    """gw_template_maker.py:69-85 (the trainer's copy, bbhMahoGANy.py:129-144, adds fmin; readers use .mc, .m1, .m2 only)."""
+
+    def __init__(self, mc, M, eta, m1, m2, ra, dec, iota, phi, psi, idx, snr, SNR):
+        self.mc, self.M, self.eta, self.m1, self.m2 = mc, M, eta, m1, m2
+        self.ra, self.dec, self.iota, self.phi, self.psi = ra, dec, iota, phi, psi
+        self.idx, self.snr, self.SNR = idx, snr, SNR
+
+
+# --------------------------------------------------------------------------------------------------- small host helpers
+def tukey(M, alpha=0.5):
+    """gw_template_maker.py:87-113."""
+    n = np.arange(M)
+    width = int(np.floor(alpha * (M - 1) / 2.0))
+    w = np.ones(M)
+    w[:width + 1] = 0.5 * (1 + np.cos(np.pi * (-1 + 2.0 * n[:width + 1] / alpha / (M - 1))))
+    w[M - width - 1:] = 0.5 * (1 + np.cos(np.pi * (-2.0 / alpha + 1 + 2.0 * n[M - width - 1:] / alpha / (M - 1))))
+    return w
+
+
+def convert_beta(beta, fs, T_obs):
+    """gw_template_maker.py:133-159."""
+    newbeta = np.array([(beta[0] + 0.5 * safe - 0.5), (beta[1] + 0.5 * safe - 0.5)]) / safe
+    return int(T_obs * fs * newbeta[0]), int(T_obs * fs * newbeta[1])
+
+
+def _whiten_scale(psd, sample_rate):
+    """sqrt(2*invpsd/fs), invpsd = 0 where psd <= 0, and 0 at DC (whiten_data sets xf[0] = 0): :273-279."""
+    psd = np.asarray(psd, np.float64)
+    inv = np.zeros(psd.size)
+    pos = psd > 0.0
+    inv[pos] = 1.0 / psd[pos]
+    s = np.sqrt(2.0 * inv / sample_rate)
+    s[0] = 0.0
+    return s
+
+
+def _gmst_rad(gps):
+    utc = gps - 17.0
+    t = ((utc / 86400.0 + 2444244.5) - 2451545.0) / 36525.0
+    sec = 67310.54841 + (876600.0 * 3600.0 + 8640184.812866) * t + 0.093104 * t * t - 6.2e-6 * t ** 3
+    return (sec % 86400.0) * (2.0 * np.pi / 86400.0)
+
+
+_LHO_X = np.array([-0.22389266154, 0.79983062746, 0.55690487831])
+_LHO_Y = np.array([-0.91397818574, 0.02609403989, -0.40492342125])
+
+
+def antenna_response(gps, ra, dec, psi, det='H1'):
+    """Stand-in for pylal.antenna.response (:612): F+, Fx of LIGO Hanford from the detector tensor (not LAL-verified)."""
+    if det != 'H1':
+        raise NotImplementedError('detector %r (the reference fixes H1)' % det)
+    D = 0.5 * (np.outer(_LHO_X, _LHO_X) - np.outer(_LHO_Y, _LHO_Y))
+    gha = _gmst_rad(gps) - ra
+    cg, sg, cd, sd, cp, sp = np.cos(gha), np.sin(gha), np.cos(dec), np.sin(dec), np.cos(psi), np.sin(psi)
+    X = np.array([-cp * sg - sp * cg * sd, -cp * cg + sp * sg * sd, sp * cd])
+    Y = np.array([sp * sg - cp * cg * sd, sp * cg + cp * sg * sd, cp * cd])
+    return X @ D @ X - Y @ D @ Y, X @ D @ Y + Y @ D @ X
+
+
+# --------------------------------------------------------------------------------------------------- device plumbing
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _d64(a):
+    return torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(device())
+
+
+_TW = {}
+
+
+def twiddles(N):
+    """exp(+2 pi i k / N), k < N/2, fp64, built once on the host and cached in HBM."""
+    key = (N, device().index)
+    if key not in _TW:
+        k = np.arange(N // 2)
+        w = np.exp(2j * np.pi * k / N)
+        _TW[key] = _d64(np.stack([w.real, w.imag], axis=1))
+    return _TW[key]
+
+
+def irfft(X, N):
+    """X: (nb, N/2+1, 2) fp64 device tensor (re, im) -> (nb, N) fp64."""
+    nb = X.shape[0]
+    out = torch.empty((nb, N), dtype=torch.float64, device=X.device)
+    _lib.call('gn_irfft_f64', X.data_ptr(), out.data_ptr(), twiddles(N).data_ptr(), nb, N, _s())
+    return out
+
+
+def rfft(x):
+    nb, N = x.shape
+    X = torch.empty((nb, N // 2 + 1, 2), dtype=torch.float64, device=x.device)
+    _lib.call('gn_rfft_f64', x.data_ptr(), X.data_ptr(), twiddles(N).data_ptr(), nb, N, _s())
+    return X
+
+
+def _mul(x, w, complex_x):
+    _lib.call('gn_mul_f64', x.data_ptr(), w.data_ptr(), x.numel(), w.numel(), 1 if complex_x else 0, _s())
+    return x
+
+
+# --------------------------------------------------------------------------------------------------- reference surface
+def whiten_data(data, duration, sample_rate, psd, flag='td'):
+    """gw_template_maker.py:243-286.  numpy in / numpy out; arithmetic on the device."""
+    scale = _d64(_whiten_scale(psd, sample_rate))
+    if flag == 'td':
+        N = int(duration * sample_rate)
+        x = _d64(np.asarray(data, np.float64).reshape(1, N))
+        _mul(x, _d64(tukey(N, alpha=1.0 / 8.0)), False)
+        X = _mul(rfft(x), scale, True)
+        return irfft(X, N).cpu().numpy().reshape(N)
+    xf = np.asarray(data, np.complex128)
+    X = _d64(np.stack([xf.real, xf.imag], axis=1).reshape(1, xf.size, 2))
+    _mul(X, scale, True)
+    o = X.cpu().numpy().reshape(xf.size, 2)
+    return o[:, 0] + 1j * o[:, 1]
+
+
+def gen_noise(fs, T_obs, psd):
+    """gw_template_maker.py:161-193: the 2*Nf standard normals come from the legacy numpy stream (re block, then im block),
+    exactly as in the reference; spectrum scaling and the irFFT run on the device."""
+    N = T_obs * fs
+    Nf = N // 2 + 1
+    df = 1.0 / T_obs
+    psd = np.asarray(psd, np.float64)
+    amp = np.sqrt(0.25 * T_obs * psd)
+    amp[psd == 0.0] = 0.0
+    amp[0] = 0.0
+    re = np.random.normal(0, 1, Nf)
+    im = np.random.normal(0, 1, Nf)
+    X = _d64(np.stack([re, im], axis=1).reshape(1, Nf, 2))
+    _mul(X, _d64(amp), True)
+    x = irfft(X, N)
+    _lib.call('gn_scale_f64', x.data_ptr(), float(N), x.numel(), _s())      # x = N*irfft(.)*df, two multiplies like numpy
+    _lib.call('gn_scale_f64', x.data_ptr(), float(df), x.numel(), _s())
+    return x.cpu().numpy().reshape(N)
+
+
+def gen_noise_device(fs, T_obs, psd, nb, seed, offset=0):
+    """nb coloured-noise realisations drawn on the device (Philox normals): (nb, N) fp64 tensor in HBM.  Same spectrum
+    construction as gen_noise; the random stream differs from numpy's by construction (statistical parity only)."""
+    N = T_obs * fs
+    Nf = N // 2 + 1
+    psd = np.asarray(psd, np.float64)
+    amp = np.sqrt(0.25 * T_obs * psd)
+    amp[psd == 0.0] = 0.0
+    X = torch.empty((nb, Nf, 2), dtype=torch.float64, device=device())
+    _lib.call('gn_noise_fd', _d64(amp).data_ptr(), X.data_ptr(), nb, Nf, int(seed), int(offset), _s())
+    x = irfft(X, N)
+    _lib.call('gn_scale_f64', x.data_ptr(), float(N) * (1.0 / T_obs), x.numel(), _s())
+    return x
+
+
+def gen_masses(m_min=5.0, M_max=100.0, mdist='astro'):
+    """gw_template_maker.py:289-339 ('astro' and 'hunt_constrain'; 'gh' / 'metric' are not on the hot path)."""
+    log_m_max = np.log(M_max - m_min)
+    while True:
+        m12 = np.exp(np.log(m_min) + np.random.uniform(0, 1, 2) * (log_m_max - np.log(m_min)))
+        eta = m12[0] * m12[1] / (m12[0] + m12[1]) ** 2
+        mc = np.sum(m12) * eta ** (3.0 / 5.0)
+        flag = (np.sum(m12) < M_max) and np.all(m12 > m_min) and (m12[0] >= m12[1])
+        if mdist == 'hunt_constrain':
+            flag = flag and (m12[1] / m12[0] >= 0.5) and (mc >= 20.0) and (mc <= 35.0)
+        elif mdist != 'astro':
+            raise NotImplementedError('mass distribution %r' % (mdist,))
+        if flag:
+            return m12, mc, eta
+
+
+def gen_par(fs, T_obs, mdist='astro', beta=[0.75, 0.95], gw_tmp=False):
+    """gw_template_maker.py:372-460 (same RNG consumption: masses, five discarded rand(), one randint unless low == high)."""
+    m12, mc, eta = gen_masses(5.0, 100.0, mdist=mdist)
+    M = np.sum(m12)
+    for _ in range(5):              # iota, psi, phi, ra, dec are drawn and then overwritten by constants (:403-416 vs :433-437)
+        np.random.rand()
+    if gw_tmp:
+        beta = [0.5, 0.5]
+    low_idx, high_idx = convert_beta(beta, fs, T_obs)
+    idx = low_idx if low_idx == high_idx else int(np.random.randint(low_idx, high_idx, 1)[0])
+    if gw_tmp:
+        m1, m2 = 36.0, 29.0
+        eta = m1 * m2 / (m1 + m2) ** 2
+        M = m1 + m2
+        return bbhparams(M * eta ** (3.0 / 5.0), M, eta, m1, m2, RA, DEC, IOTA, PHI, PSI, idx, None, None)
+    return bbhparams(mc, M, eta, m12[0], m12[1], RA, DEC, IOTA, PHI, PSI, idx, None, None)
+
+
+class Synth(object):
+    """Batched gen_bbh for one (fs, T_obs, psd): keeps the whitening scale and FFT twiddles in HBM."""
+
+    def __init__(self, fs, T_obs, psd, det='H1', peak_off=PEAK_OFFSET, f_low=F_LOW, dist_mpc=DIST_MPC):
+        self.fs, self.T_obs = int(fs), int(T_obs)
+        self.N = self.fs * self.T_obs
+        self.Nf = self.N // 2 + 1
+        self.scale = _d64(_whiten_scale(psd, fs))
+        assert self.scale.numel() == self.Nf, 'psd must have N/2+1 = %d bins' % self.Nf
+        self.Fp, self.Fc = antenna_response(float(event_time), RA, DEC, PSI, det)
+        self.peak_off, self.f_low, self.dist_mpc = int(peak_off), float(f_low), float(dist_mpc)
+        twiddles(self.N)
+
+    def series(self, m1, m2, iota=IOTA, phi=PHI):
+        """Whitened time-domain polarisations irfft(whiten(h~)) (un-rolled): two (nb, N) fp64 device tensors."""
+        m1 = _d64(np.atleast_1d(m1)); m2 = _d64(np.atleast_1d(m2))
+        nb = m1.numel()
+        hp = torch.empty((nb, self.Nf, 2), dtype=torch.float64, device=device())
+        hc = torch.empty_like(hp)
+        _lib.call('gn_chirp_fd_whitened', m1.data_ptr(), m2.data_ptr(), self.scale.data_ptr(), hp.data_ptr(), hc.data_ptr(), nb, self.Nf,
+                  1.0 / self.T_obs, self.f_low, self.dist_mpc, float(iota), float(phi), _s())
+        return irfft(hp, self.N), irfft(hc, self.N), (hp, hc)
+
+    def align(self, hp_t, hc_t, idx, crop0, crop_len, Fp, Fc, g=1.0):
+        nb = hp_t.shape[0]
+        idx_t = torch.as_tensor(np.ascontiguousarray(np.atleast_1d(idx), np.int32)).to(device())
+        out = torch.empty((nb, crop_len), dtype=torch.float64, device=device())
+        ref = torch.empty((nb,), dtype=torch.int32, device=device())
+        _lib.call('gn_align_crop', hp_t.data_ptr(), hc_t.data_ptr(), idx_t.data_ptr(), out.data_ptr(), ref.data_ptr(), nb, self.N, self.fs,
+                  int(crop0), int(crop_len), self.peak_off, float(Fp), float(Fc), float(g), _s())
+        return out, ref
+
+    def templates(self, m1, m2, idx, g=1.0, chunk=4096):
+        """Central 1-s crops [1.5 fs, 2.5 fs) of the detector strain for a batch of (m1, m2, idx): (nb, fs) fp64 device tensor
+        and the reference indices (nb,) int32.  (gen_bbh + the crop of sim_data :695; the Tukey window equals 1.0 there.)"""
+        m1 = np.atleast_1d(np.asarray(m1, np.float64)); m2 = np.atleast_1d(np.asarray(m2, np.float64)); idx = np.atleast_1d(idx)
+        outs, refs = [], []
+        c0 = int((self.T_obs / 2) * self.fs - self.fs / 2)
+        for s in range(0, m1.size, chunk):
+            hp_t, hc_t, _ = self.series(m1[s:s + chunk], m2[s:s + chunk])
+            o, r = self.align(hp_t, hc_t, idx[s:s + chunk], c0, self.fs, self.Fp, self.Fc, g)
+            outs.append(o); refs.append(r)
+        return torch.cat(outs), torch.cat(refs)
+
+
+def make_bbh(hp, hc, fs, ra, dec, psi, det):
+    """gw_template_maker.py:577-630: antenna combination.  The reference also fits and evaluates three time-shift splines and
+    then returns the UN-shifted series (:621-630); only what it returns is computed here."""
+    Fp, Fc = antenna_response(float(event_time), ra, dec, psi, det)
+    return hp * Fp + hc * Fc, hp, hc
+
+
+def gen_bbh(fs, T_obs, psds, dets=['H1'], beta=[0.75, 0.95], par=None, gw_tmp=False, peak_off=PEAK_OFFSET):
+    """gw_template_maker.py:462-575 for one template: returns (ts, hp, hc, ts), each (1, N): the windowed, slid series."""
+    syn = Synth(fs, T_obs, psds, dets[0], peak_off)
+    hp_t, hc_t, _ = syn.series([par.m1], [par.m2], par.iota, par.phi)
+    N = syn.N
+    tw = tukey(int((16.0 / 15.0) * N / safe), alpha=1.0 / 8.0)
+    win = np.zeros(N)
+    a = int((N - tw.size) / 2)
+    win[a:a + tw.size] = tw
+    win_d = _d64(win)
+    Fp, Fc = antenna_response(float(event_time), par.ra, par.dec, par.psi, dets[0])
+    outs = []
+    for fp, fc in ((Fp, Fc), (1.0, 0.0), (0.0, 1.0)):
+        o, _ = syn.align(hp_t, hc_t, [par.idx], 0, N, fp, fc)
+        outs.append(_mul(o, win_d, False).cpu().numpy().reshape(1, N))
+    return outs[0], outs[1], outs[2], outs[0]
+
+
+def sim_data(fs, T_obs, psds, dets=['H1'], Nnoise=25, size=1000, mdist='astro', beta=[0.75, 0.95], peak_off=PEAK_OFFSET, to_host=True):
+    """gw_template_maker.py:632-740 with Nnoise = 0 (what main() passes, :806; the Nnoise > 0 branch of the reference would
+    raise on an array psd, :687) and do_time_grid = False.  Returns ([ts (size, 1, fs), yval], pars): size-1 random
+    templates shuffled by np.random.permutation, then the GW150914-like (36, 29) template appended last."""
+    if Nnoise > 0:
+        raise NotImplementedError('sim_data(Nnoise > 0): the reference ships noise-free templates (Nnoise = 0)')
+    n_rand = size - 1 if gw_tmp else size
+    pars = [gen_par(fs, T_obs, mdist=mdist, beta=beta, gw_tmp=False) for _ in range(n_rand)]
+    syn = Synth(fs, T_obs, psds, dets[0], peak_off)
+    ts, _ = syn.templates([p.m1 for p in pars], [p.m2 for p in pars], [p.idx for p in pars])
+    perm = np.random.permutation(n_rand)
+    pars = [pars[i] for i in perm]
+    ts = ts[torch.as_tensor(perm).to(ts.device)]
+    if gw_tmp:
+        p = gen_par(fs, T_obs, mdist=mdist, beta=beta, gw_tmp=True)
+        ev, _ = syn.templates([p.m1], [p.m2], [p.idx])
+        ts = torch.cat([ts, ev])
+        pars.append(p)
+    yval = np.ones(len(pars), dtype=int)
+    ts = ts.reshape(len(pars), 1, int(fs))
+    return [ts.cpu().numpy() if to_host else ts, yval], pars
+
+
+# --------------------------------------------------------------------------------------------------- file layout
+class _ParsPickler(pickle.Pickler):
+    pass
+
+
+def save_ts_pars(basename, event_name, i, sample_num, tag, ts, pars):
+    """Writes <basename><event>_ts_<i>_<sample_num>Samp<tag>.sav and ..._params_... (gw_template_maker.py:842-850), pickle
+    protocol 2 (what py2 cPickle.HIGHEST_PROTOCOL is).  bbhparams instances are pickled as `__main__.bbhparams`, the name the
+    reference writer (run as a script) stores and the reference reader (bbhMahoGANy.py:129, :972-973) resolves."""
+    ts_path = '%s%s_ts_%s_%sSamp%s.sav' % (basename, event_name, i, sample_num, tag)
+    par_path = '%s%s_params_%s_%sSamp%s.sav' % (basename, event_name, i, sample_num, tag)
+    with open(ts_path, 'wb') as f:
+        pickle.dump([np.asarray(ts[0], np.float64), np.asarray(ts[1])], f, protocol=2)
+    old = bbhparams.__module__
+    import sys
+    main_mod = sys.modules['__main__']
+    had = getattr(main_mod, 'bbhparams', None)
+    try:
+        bbhparams.__module__ = '__main__'
+        setattr(main_mod, 'bbhparams', bbhparams)
+        with open(par_path, 'wb') as f:
+            pickle.dump(list(pars), f, protocol=2)
+    finally:
+        bbhparams.__module__ = old
+        if had is None:
+            delattr(main_mod, 'bbhparams')
+        else:
+            setattr(main_mod, 'bbhparams', had)
+    return ts_path, par_path
+
+
+class _RefUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if name == 'bbhparams':
+            return bbhparams
+        return pickle.Unpickler.find_class(self, module, name)
+
+
+def load_ts_pars(ts_path, par_path):
+    """Reads the two files (py2 cPickle or ours): returns ([ts, yval], [bbhparams])."""
+    with open(ts_path, 'rb') as f:
+        ts = pickle.load(f, encoding='latin1')
+    with open(par_path, 'rb') as f:
+        pars = _RefUnpickler(f, encoding='latin1').load()
+    return ts, list(pars)
+
+
+def training_arrays(ts, pars):
+    """bbhMahoGANy.py:1007-1014, :1036, :1053-1055: images (Ns-1, n_pix), labels [[mc, m2/m1]], with the last (event-like)
+    template split off as the event."""
+    images = np.reshape(ts[0], (ts[0].shape[0], ts[0].shape[2]))
+    labels = np.array([[k.mc, (k.m2 / k.m1)] for k in pars])
+    return images[:-1], labels[:-1], images[-1], labels[-1]

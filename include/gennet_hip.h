@@ -152,9 +152,12 @@ int gn_prof_collect(int kind, double* out3_host);
  *   scale[f] = sqrt(2*invpsd[f]/fs) precomputed by the caller from the PSD (0 where psd <= 0). */
 int gn_chirp_fd_whitened(const double* m1, const double* m2, const double* scale, double* out_hp, double* out_hc,
                          int nb, int Nf, double df, double f_low, double dist_mpc, double iota, double phi0, void* stream);
-/* Batched inverse real FFT, numpy.fft.irfft(X, n=N) semantics (1/N normalisation, imaginary parts of DC/Nyquist
- * ignored): X (nb, N/2+1) complex128 -> out (nb, N) float64.  N a power of two, 16 <= N <= 16384. */
-int gn_irfft_f64(const double* X, double* out, int nb, int N, void* stream);
+/* Batched real FFTs with numpy semantics (np.fft.irfft at gw_template_maker.py:191,:283,:521-522,:775-777; np.fft.rfft
+ * at :268).  irfft: X (nb, N/2+1) complex128 -> out (nb, N) float64, 1/N normalisation, imaginary parts of DC/Nyquist
+ * ignored.  rfft: x (nb, N) -> X (nb, N/2+1).  N a power of two, 16 <= N <= 16384.
+ * twiddle: N/2 complex128 values exp(+2*pi*i*k/N), k = 0..N/2-1, computed once by the caller (fp64 on the host). */
+int gn_irfft_f64(const double* X, double* out, const double* twiddle, int nb, int N, void* stream);
+int gn_rfft_f64(const double* x, double* X, const double* twiddle, int nb, int N, void* stream);
 /* gen_bbh alignment (gw_template_maker.py:521-565) for a batch: given hp, hc = irfft(...) (nb, N):
  *   ref = argmax_n (hp^2+hc^2)[(n - fs) mod N-rolled]  (first maximum, as numpy.argmax after np.roll(.,-fs));
  *   out[b, n] = g * (Fp*hp + Fc*hc)_rolled[ref - idx[b] - peak_off + crop0 + n], n in [0, crop_len), 0 past the end.
@@ -165,6 +168,9 @@ int gn_align_crop(const double* hp, const double* hc, const int32_t* idx, double
 int gn_noise_fd(const double* amp, double* X, int nb, int Nf, uint64_t seed, uint64_t offset, void* stream);
 /* x *= s (fp64), used for N*df and gw_norm_constant scalings; and fp64 -> fp32 narrowing with scale */
 int gn_scale_f64(double* x, double s, size_t n, void* stream);
+/* x[i] *= w[e % period], e = i (real x) or i/2 (complex_x: interleaved re/im): whiten_data's xf *= sqrt(2*invpsd/fs)
+ * (:276) and the Tukey window of the 'td' path (:267-268) over a batch */
+int gn_mul_f64(double* x, const double* w, size_t n, size_t period, int complex_x, void* stream);
 int gn_f64_to_f32(const double* x, float* y, double s, size_t n, void* stream);
 
 #ifdef __cplusplus

@@ -1,0 +1,150 @@
+"""CPU-only checks (no compute calls): the C-ABI library loads and exports every symbol include/gennet_hip.h declares, host logic of
+the Keras-style engine (graph construction, peephole fusion plan, collect-at-compile trainability, flat parameter segments),
+the host helpers of the synthesiser against the reference's golden vectors, and the ts/pars file layout."""
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(ROOT, 'tests', 'golden', 'synth_golden.npz'))
+
+
+def test_library_exports_every_declared_symbol():
+    from gennet_amd import _lib, build
+    build.build(verbose=False)
+    hdr = open(os.path.join(ROOT, 'include', 'gennet_hip.h')).read()
+    declared = set(re.findall(r'\b(gn_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 45
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    L.gn_version.restype = ctypes.c_int
+    assert L.gn_version() >= 100
+
+
+def test_no_cpu_fallback_in_product_path():
+    """ops refuse CPU tensors, and nothing under gennet_amd/ imports the oracle."""
+    import torch
+    from gennet_amd import _lib, ops
+    with pytest.raises(_lib.GennetHipError):
+        ops.act_fwd(torch.zeros(8), 'relu')
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'gennet_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f
+
+
+def test_graphs_fusion_plan_and_param_counts():
+    from gennet_amd import bbh
+    n_pix = 2048
+    G_ = bbh.generator_model(n_pix); D = bbh.signal_discriminator_model(n_pix); P = bbh.signal_pe_model(n_pix)
+    # SURVEY Appendix A parameter counts @2048
+    assert sum(p.size for l in P.layers for p in l.params) == 4928514
+    assert sum(p.size for l in D.layers for p in l.params) == 3808257
+    assert sum(p.size for p in G_.weights) == 31095745 + 7936             # incl. BN moving statistics (Appendix A generator table)
+    assert sum(p.size for l in G_.layers for p in l.params) == 30575425   # trainable ("G ~30.6 M trainable")
+    assert P.output_shape == [(None, 1), (None, 1)] and G_.output_shape == (None, n_pix, 1) and D.output_shape == (None, 1)
+    shapes = [n.out_shape for n in P.nodes if n.layer.__class__.__name__ == 'Conv1D']
+    assert shapes == [(1024, 64), (510, 128), (253, 256), (125, 512), (2048, 64), (2044, 128), (2040, 256), (1018, 512), (507, 1024)]
+    G_._plan()
+    bn = [n for n in G_.nodes if n.layer.__class__.__name__ == 'BatchNormalization']
+    assert len(bn) == 6 and all(n.fused_act == ('tanh', 0.0) and n.fused_drop[0] == 0.2 for n in bn)
+    assert sum(n.absorbed for n in G_.nodes) == 13                     # 6 x (Activation + Dropout) + the final linear Activation
+    D._plan()
+    convs = [n for n in D.nodes if n.layer.__class__.__name__ == 'Conv2D']
+    assert all(n.fused_act == ('leaky', 0.2) for n in convs)
+
+
+def test_collect_at_compile_trainability():
+    """bbhMahoGANy.py:1104-1115: the combined model is compiled while D is frozen -> trains G only; D compiled after unfreezing."""
+    from gennet_amd import bbh
+    nets = bbh.build_and_compile(np.zeros((64, 1), np.float32), 64)
+    g_ids = set(id(p) for l in nets.generator.layers for p in l.params)
+    d_ids = set(id(p) for l in nets.signal_discriminator.layers for p in l.params)
+    assert set(id(p) for p in nets.signal_discriminator_on_generator._train_params) == g_ids
+    assert set(id(p) for p in nets.data_subtraction_on_generator._train_params) == g_ids
+    assert set(id(p) for p in nets.signal_discriminator._train_params) == d_ids
+    assert all(l.trainable for l in nets.signal_discriminator.layers)
+    # three compiled models share the generator's weight objects but own separate optimizers
+    assert nets.signal_discriminator_on_generator.optimizer is not nets.data_subtraction_on_generator.optimizer
+    # freezing the nested model object alone (without touching its layers) also counts
+    g = bbh.generator_model(64); d = bbh.signal_discriminator_model(64)
+    comb = bbh.generator_containing_signal_discriminator(bbh.generator_after_subtracting_noise(g, bbh.data_subtraction_model(np.zeros(64), 64)), d)
+    d.trainable = False
+    comb.compile(loss='binary_crossentropy', optimizer='adam')
+    assert set(id(p) for p in comb._train_params) == set(id(p) for l in g.layers for p in l.params)
+
+
+def test_segments_merge_adjacent_params():
+    from gennet_amd.engine import ParamGroup, segments
+
+    class P(object):
+        def __init__(self, size):
+            self.size, self.group, self.offset = size, None, 0
+
+    ps = [P(10), P(64), P(65)]
+    grp = object()
+    off = 0
+    for p in ps:
+        p.group, p.offset = grp, off
+        off += -(-p.size // ParamGroup.ALIGN) * ParamGroup.ALIGN
+    assert segments(ps) == [(grp, 0, 64 + 64 + 128)]
+    assert segments([ps[0], ps[2]]) == [(grp, 0, 64), (grp, 128, 256)]
+
+
+def test_conv_geometry_tf_rules():
+    from gennet_amd import ops
+    assert ops.conv_geometry(2048, 5, 1, 'same') == (2048, 2)
+    assert ops.conv_geometry(2048, 5, 2, 'same') == (1024, 1)
+    assert ops.conv_geometry(2044, 5, 1, 'valid') == (2040, 0)
+    assert ops.conv_geometry(1018, 5, 2, 'valid') == (507, 0)
+
+
+def test_unsupported_configurations_raise():
+    from gennet_amd.layers import Conv2D, Dense, UpSampling1D
+    with pytest.raises(NotImplementedError):
+        Conv2D(8, (3, 3), padding='same')
+    with pytest.raises(NotImplementedError):
+        UpSampling1D(size=3)
+    with pytest.raises(NotImplementedError):
+        Dense(4, kernel_initializer='he_normal')
+
+
+def test_synth_host_helpers_match_reference_golden():
+    from gennet_amd import templates as T
+    for key, (M, alpha) in {'tukey_2184': (2184, 1 / 8.), 'tukey_4369': (4369, 1 / 8.), 'tukey_8738': (8738, 1 / 8.), 'tukey_64_half': (64, 0.5)}.items():
+        assert np.array_equal(T.tukey(M, alpha), G[key])
+    for fs, b0, b1, lo, hi in G['convert_beta']:
+        assert T.convert_beta([b0, b1], int(fs), 4) == (int(lo), int(hi))
+    np.random.seed(1)
+    acc = np.array([np.concatenate([m12, [mc, eta]]) for m12, mc, eta in (T.gen_masses(5.0, 100.0, 'hunt_constrain') for _ in range(200))])
+    assert np.array_equal(acc, G['hunt_seed1'])
+    assert np.array_equal(np.random.uniform(0, 1, 3), G['hunt_seed1_next_uniform'])
+    s = T._whiten_scale(G['wh_psd'], 256)
+    assert np.array_equal(G['wh_fd_in'] * s, G['wh_fd_out'])
+
+
+def test_ts_pars_file_layout_roundtrip(tmp_path):
+    """[ts (Ns,1,fs) f64, yval], list of __main__.bbhparams, pickle protocol 2, reference file names."""
+    from gennet_amd import templates as T
+    rng = np.random.RandomState(0)
+    ts = [rng.randn(5, 1, 64), np.ones(5, dtype=int)]
+    pars = [T.bbhparams(30.0 + i, 60.0, 0.25, 33.0 + i, 27.0, T.RA, T.DEC, T.IOTA, T.PHI, T.PSI, 100 + i, None, None) for i in range(5)]
+    base = str(tmp_path) + '/'
+    tp, pp = T.save_ts_pars(base, 'gw150914', 0, 50000, '_srate-1024hz_oversamp', ts, pars)
+    assert tp.endswith('gw150914_ts_0_50000Samp_srate-1024hz_oversamp.sav') and pp.endswith('gw150914_params_0_50000Samp_srate-1024hz_oversamp.sav')
+    raw = open(pp, 'rb').read()
+    assert raw[:2] == b'\x80\x02' and b'__main__' in raw and b'bbhparams' in raw
+    ts2, pars2 = T.load_ts_pars(tp, pp)
+    assert np.array_equal(ts2[0], ts[0]) and ts2[0].dtype == np.float64 and ts2[0].shape == (5, 1, 64)
+    assert [(p.mc, p.m1, p.m2, p.idx) for p in pars2] == [(p.mc, p.m1, p.m2, p.idx) for p in pars]
+    images, labels, ev, evl = T.training_arrays(ts2, pars2)
+    assert images.shape == (4, 64) and labels.shape == (4, 2) and np.array_equal(ev, ts[0][-1, 0])
+    assert np.allclose(labels[:, 1], [27.0 / (33.0 + i) for i in range(4)])
+    assert T.bbhparams.__module__ == 'gennet_amd.templates'

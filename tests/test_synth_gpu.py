@@ -1,0 +1,215 @@
+"""GPU parity of the template synthesiser (gennet_amd/templates.py + csrc/synth.hip).
+
+Against (i) the golden vectors produced by the reference's own numpy functions (tests/golden/synth_golden.npz) and
+(ii) the fp64 oracle (oracle/synth_ref.py).  Bars: sample indices (ref_idx, crop placement, parameter draws) bit-exact;
+everything downstream of h~(f) <= 1e-12 relative (fp64 FFT butterfly order differs from pocketfft's); the closed-form
+chirp itself <= 1e-9 relative (phase ~1e3 rad amplifies last-bit differences of cbrt/pow/sincos between libm and the device).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth_ref as S
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'synth_golden.npz'))
+
+
+def rel(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def dev64(a):
+    from gennet_amd.engine import device
+    return torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(device())
+
+
+def c2dev(z):
+    return dev64(np.stack([z.real, z.imag], axis=-1))
+
+
+@pytest.mark.parametrize("N", [16, 64, 1024, 4096, 8192, 16384])
+def test_irfft_rfft_match_numpy(N):
+    from gennet_amd import templates as T
+    rng = np.random.RandomState(N)
+    nb = 3
+    X = rng.randn(nb, N // 2 + 1) + 1j * rng.randn(nb, N // 2 + 1)        # DC / Nyquist carry imaginary parts that must be ignored
+    x = T.irfft(c2dev(X), N).cpu().numpy()
+    assert rel(x, np.fft.irfft(X, N)) < 1e-13
+    xr = rng.randn(nb, N)
+    Xf = T.rfft(dev64(xr)).cpu().numpy()
+    assert rel(Xf[..., 0] + 1j * Xf[..., 1], np.fft.rfft(xr)) < 1e-13
+    # round trip at full size: irfft(rfft(x)) == x
+    assert rel(T.irfft(T.rfft(dev64(xr)), N).cpu().numpy(), xr) < 1e-13
+
+
+def test_whiten_data_matches_reference_golden():
+    from gennet_amd import templates as T
+    psd = G['wh_psd']
+    out = T.whiten_data(G['wh_fd_in'], 4, 256, psd, 'fd')
+    assert np.array_equal(out, G['wh_fd_out'])                              # one multiply per component: bit-exact
+    assert rel(T.whiten_data(G['wh_td_in'], 4, 256, psd, 'td'), G['wh_td_out']) < 1e-12
+
+
+def test_gen_noise_matches_reference_golden():
+    from gennet_amd import templates as T
+    np.random.seed(7)
+    x = T.gen_noise(256, 4, G['noise_psd'].copy())
+    assert rel(x, G['noise_out']) < 1e-12
+    nxt = np.random.normal(0, 1, 3)                                          # stream position: exactly 2*Nf normals consumed
+    np.random.seed(7)
+    np.random.normal(0, 1, 513); np.random.normal(0, 1, 513)
+    assert np.array_equal(nxt, np.random.normal(0, 1, 3))
+
+
+def test_gen_noise_device_statistics():
+    """Philox path: coloured noise with std ~ sqrt(psd*fs/2) (SURVEY Appendix D identity), DC-free, reproducible."""
+    from gennet_amd import templates as T
+    fs, Tobs = 1024, 4
+    Nf = fs * Tobs // 2 + 1
+    psd = np.full(Nf, 2.0e-3)
+    x = T.gen_noise_device(fs, Tobs, psd, 64, seed=5).cpu().numpy()
+    assert abs(x.std() - np.sqrt(2.0e-3 * fs / 2)) < 0.01 * np.sqrt(2.0e-3 * fs / 2)
+    assert abs(x.mean()) < 5e-3
+    x2 = T.gen_noise_device(fs, Tobs, psd, 64, seed=5).cpu().numpy()
+    assert np.array_equal(x, x2)
+
+
+@pytest.mark.parametrize("fs", [1024, 2048])
+def test_chirp_kernel_matches_oracle_model(fs):
+    from gennet_amd import templates as T
+    Tobs = 4
+    Nf = fs * Tobs // 2 + 1
+    psd = S.analytic_psd(Nf, 1.0 / Tobs)
+    syn = T.Synth(fs, Tobs, psd)
+    m1 = np.array([36.0, 30.1, 45.3, 22.0]); m2 = np.array([29.0, 20.2, 24.9, 21.5])
+    _, _, (hp, hc) = syn.series(m1, m2)
+    hp = hp.cpu().numpy(); hc = hc.cpu().numpy()
+    sc = S.whiten_scale(psd, fs); sc[0] = 0
+    for b in range(4):
+        rp, rc = S.chirp_fd(m1[b], m2[b], Nf, 1.0 / Tobs)
+        assert rel(hp[b, :, 0] + 1j * hp[b, :, 1], rp * sc) < 1e-9
+        assert rel(hc[b, :, 0] + 1j * hc[b, :, 1], rc * sc) < 1e-9
+        assert np.all(hp[b, rp == 0] == 0)                                  # band edges identical
+
+
+@pytest.mark.parametrize("fs", [256, 1024, 2048])
+def test_align_crop_bit_exact_indexing_given_same_spectra(fs):
+    """Downstream of h~(f): feed the ORACLE's whitened spectra to the device irFFT + align/crop; ref_idx must be exact and the
+    crop must equal the oracle's to 1e-12."""
+    from gennet_amd import templates as T
+    Tobs = 4
+    N = fs * Tobs; Nf = N // 2 + 1
+    psd = S.analytic_psd(Nf, 1.0 / Tobs)
+    syn = T.Synth(fs, Tobs, psd)
+    np.random.seed(fs)
+    pars = [S.gen_par(fs, Tobs) for _ in range(6)]
+    sp = [S.chirp_fd(p.m1, p.m2, Nf, 1.0 / Tobs) for p in pars]
+    whp = np.array([S.whiten_data(a, Tobs, fs, psd, 'fd') for a, _ in sp]); whc = np.array([S.whiten_data(b, Tobs, fs, psd, 'fd') for _, b in sp])
+    hp_t = T.irfft(c2dev(whp), N); hc_t = T.irfft(c2dev(whc), N)
+    Fp, Fc = S.antenna_response(S.EVENT_TIME, S.RA, S.DEC, S.PSI)
+    assert (syn.Fp, syn.Fc) == (Fp, Fc)
+    out, ref = syn.align(hp_t, hc_t, [p.idx for p in pars], int(1.5 * fs), fs, Fp, Fc)
+    out = out.cpu().numpy(); ref = ref.cpu().numpy()
+    for b, p in enumerate(pars):
+        crop, ref_idx = S.align_crop(np.fft.irfft(whp[b], N), np.fft.irfft(whc[b], N), p.idx, fs, Fp, Fc)
+        assert ref[b] == ref_idx
+        assert rel(out[b], crop) < 1e-12
+
+
+def test_align_python_slice_semantics_edge_cases():
+    """start = ref_idx - idx - 11 < 0 (python slices from the end) and start near N (zero fill), on crafted series."""
+    from gennet_amd import templates as T
+    fs, Tobs = 64, 4
+    N = fs * Tobs
+    psd = np.ones(N // 2 + 1)
+    syn = T.Synth(fs, Tobs, psd)
+    rng = np.random.RandomState(2)
+    hp = rng.randn(3, N); hc = rng.randn(3, N)
+    peaks = [5, N - 3, 100]                    # rolled-frame peak positions
+    for b, pk in enumerate(peaks):
+        hp[b, (pk + fs) % N] = 50.0            # roll by -fs moves sample s to s - fs
+    idxs = [40, 10, 100]
+    out, ref = syn.align(dev64(hp), dev64(hc), idxs, 0, N, 0.3, -0.7)
+    out = out.cpu().numpy(); ref = ref.cpu().numpy()
+    for b in range(3):
+        hp_r = np.roll(hp[b], -fs); hc_r = np.roll(hc[b], -fs)
+        ri = int(np.argmax(hp_r ** 2 + hc_r ** 2))
+        assert ref[b] == ri == peaks[b]
+        tmp = (hp_r * 0.3 + hc_r * -0.7)[int(ri - idxs[b] - 11):]
+        ts = np.zeros(N); ts[:min(len(tmp), N)] = tmp[:N]
+        assert np.array_equal(out[b], ts)
+
+
+def test_argmax_first_maximum_tie_break():
+    from gennet_amd import templates as T
+    fs, Tobs = 64, 4
+    N = fs * Tobs
+    syn = T.Synth(fs, Tobs, np.ones(N // 2 + 1))
+    hp = np.zeros((1, N)); hc = np.zeros((1, N))
+    hp[0, 200] = 2.0; hp[0, 90] = -2.0; hc[0, 150] = 2.0                    # three equal maxima of hp^2 + hc^2
+    _, ref = syn.align(dev64(hp), dev64(hc), [0], 0, N, 1.0, 1.0)
+    assert ref.cpu().numpy()[0] == int(np.argmax(np.roll(hp[0], -fs) ** 2 + np.roll(hc[0], -fs) ** 2))
+
+
+def test_sim_data_seeded_matches_oracle():
+    """Whole synthesiser, seed 1 (gw_template_maker.py:128): identical parameter draws (exact), identical shuffle, event-like
+    template last; time series to 1e-9 (limited by the chirp evaluation, see module docstring)."""
+    from gennet_amd import templates as T
+    fs, Tobs, size = 1024, 4, 12
+    psd = S.analytic_psd(fs * Tobs // 2 + 1, 1.0 / Tobs)
+    np.random.seed(1)
+    (ts_ref, y_ref), par_ref = S.sim_data(fs, Tobs, psd, size, 'hunt_constrain', (0.45, 0.55))
+    next_ref = np.random.uniform(0, 1, 2)
+    np.random.seed(1)
+    (ts, y), par = T.sim_data(fs, Tobs, psd, ['H1'], 0, size, 'hunt_constrain', [0.45, 0.55])
+    assert np.array_equal(np.random.uniform(0, 1, 2), next_ref)             # same number of host RNG draws consumed
+    assert ts.shape == (size, 1, fs) and ts.dtype == np.float64 and np.array_equal(y, y_ref)
+    for a, b in zip(par, par_ref):
+        assert (a.mc, a.M, a.eta, a.m1, a.m2, a.idx, a.ra, a.dec, a.iota, a.phi, a.psi) == (b.mc, b.M, b.eta, b.m1, b.m2, b.idx, b.ra, b.dec, b.iota, b.phi, b.psi)
+    assert (par[-1].m1, par[-1].m2, par[-1].idx) == (36.0, 29.0, 2048)
+    assert rel(ts, ts_ref) < 1e-9
+
+
+def test_gen_bbh_single_template_surface():
+    from gennet_amd import templates as T
+    fs, Tobs = 512, 4
+    N = fs * Tobs
+    psd = S.analytic_psd(N // 2 + 1, 1.0 / Tobs)
+    np.random.seed(4)
+    p = T.gen_par(fs, Tobs, mdist='hunt_constrain', beta=[0.45, 0.55])
+    ts, hp, hc, ts2 = T.gen_bbh(fs, Tobs, psd, ['H1'], [0.45, 0.55], p)
+    assert ts.shape == hp.shape == hc.shape == (1, N) and ts is ts2
+    crop, _ = S.gen_bbh(fs, Tobs, psd, p)
+    assert rel(ts[0, int(1.5 * fs):int(2.5 * fs)], crop) < 1e-9
+    Fp, Fc = T.antenna_response(float(T.event_time), p.ra, p.dec, p.psi)
+    mid = slice(int(1.5 * fs), int(2.5 * fs))
+    assert rel(ts[0, mid], hp[0, mid] * Fp + hc[0, mid] * Fc) < 1e-13
+    ht, _, _ = T.make_bbh(hp, hc, fs, p.ra, p.dec, p.psi, 'H1')
+    assert np.array_equal(ht, hp * Fp + hc * Fc)
+
+
+def test_full_size_property_envelope_peak_lands_on_idx():
+    """BASELINE size (fs = 2048, N = 8192), size-independent property: after the slide the envelope hp^2 + hc^2 peaks exactly at
+    crop-relative sample idx + 11 - 1.5 fs ([830, 1239) at 2 kHz)."""
+    from gennet_amd import templates as T
+    fs, Tobs = 2048, 4
+    psd = S.analytic_psd(fs * Tobs // 2 + 1, 1.0 / Tobs)
+    syn = T.Synth(fs, Tobs, psd)
+    np.random.seed(9)
+    pars = [T.gen_par(fs, Tobs, mdist='hunt_constrain', beta=[0.45, 0.55]) for _ in range(256)]
+    idx = np.array([p.idx for p in pars])
+    hp_t, hc_t, _ = syn.series([p.m1 for p in pars], [p.m2 for p in pars])
+    c0 = int(1.5 * fs)
+    a, ref = syn.align(hp_t, hc_t, idx, c0, fs, 1.0, 0.0)
+    b, _ = syn.align(hp_t, hc_t, idx, c0, fs, 0.0, 1.0)
+    env = (a * a + b * b).cpu().numpy()
+    assert np.array_equal(env.argmax(axis=1), idx + 11 - c0)
+    assert idx.min() >= 3891 and idx.max() < 4300
+    ts, ref2 = syn.templates([p.m1 for p in pars], [p.m2 for p in pars], idx)
+    assert torch.equal(ref, ref2) and ts.shape == (256, fs) and torch.isfinite(ts).all()
