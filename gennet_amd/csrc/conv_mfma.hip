@@ -20,8 +20,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int KC>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvArgs a, int m_tiles, int n_tiles) {
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KC, int NTAPS>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_kernel(ConvArgs a, int m_tiles, int n_tiles) {
   constexpr int TM = WAVES_M * WM * 32;
   constexpr int TN = WAVES_N * WN * 32;
   constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -41,8 +41,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvA
   const int b = rest / m_tiles;
   const int m0 = m_tile * TM, n0 = n_tile * TN;
 
-  const int is = a.t.in_stride, ntaps = a.t.ntaps;
+  const int is = a.t.in_stride;
+  constexpr int ntaps = NTAPS;   // compile-time: the tap loop is fully unrolled so LDS reads pipeline across taps
   int minoff = a.t.off[0], maxoff = a.t.off[0];
+#pragma unroll
   for (int j = 1; j < ntaps; ++j) {
     minoff = min(minoff, a.t.off[j]);
     maxoff = max(maxoff, a.t.off[j]);
@@ -50,8 +52,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvA
   const int R = is * (TM - 1) + (maxoff - minoff) + 1;
   const int Rper = (R + is - 1) / is;
   const int slab_floats = (is * Rper * RS + 3) & ~3;
-  float* slab = smem;
-  float* wl = smem + slab_floats;
+  const int buf_floats = slab_floats + ntaps * KC * TN;       // one stage: [slab | weights]; two stages in LDS
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -64,29 +65,91 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvA
   const int t_base = is * m0 + minoff;
   const float* xb = a.x + (size_t)b * a.Lin * a.Cin;
 
-  for (int c0 = 0; c0 < a.Cin; c0 += KC) {
-    // ---- stage the input slab: R rows x KC channels (zero outside the sequence / past Cin)
-    for (int id = tid; id < R * (KC / 4); id += NT) {
-      const int r = id / (KC / 4), c4 = id % (KC / 4);
-      const int t = t_base + r, c = c0 + 4 * c4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t >= 0 && t < a.Lin && c < a.Cin) v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.Cin + c);
-      const int lr = (is == 1) ? r : ((r & 1) * Rper + (r >> 1));
-      float* d = slab + lr * RS + 4 * c4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    // ---- stage the weight tile: [tap][KC][TN]
-    for (int id = tid; id < ntaps * KC * (TN / 4); id += NT) {
-      const int n4 = id % (TN / 4);
-      const int kk = (id / (TN / 4)) % KC;
-      const int j = id / ((TN / 4) * KC);
-      const int c = c0 + kk, n = n0 + 4 * n4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < a.Cin && n < a.Cout) v = *reinterpret_cast<const float4*>(a.w + ((size_t)a.t.widx[j] * a.Cin + c) * a.Cout + n);
-      *reinterpret_cast<float4*>(wl + (j * KC + kk) * TN + 4 * n4) = v;
-    }
-    __syncthreads();
+  // Software pipeline, ONE barrier per K-chunk: registers hold chunk c+1 (its global loads were issued a whole MFMA block
+  // earlier); at the top of chunk c they are written to the OTHER LDS stage, the loads of chunk c+2 are issued into the same
+  // registers, then the MFMA block of chunk c runs from the current stage.  LDS writes and global loads execute beside the
+  // matrix pipe (separate issue ports, 64-cycle MFMAs leave the slots free).  S_ITEMS / W_ITEMS float4 per thread, static
+  // indexing so they stay in VGPRs.
+  constexpr int S_ITEMS = ((2 * (TM - 1) + 5) * (KC / 4) + NT - 1) / NT;
+  constexpr int W_ITEMS = (NTAPS * KC * (TN / 4) + NT - 1) / NT;
+  float4 sreg[S_ITEMS], wreg[W_ITEMS];
+  const int s_count = R * (KC / 4);
+  constexpr int w_count = NTAPS * KC * (TN / 4);
 
+  // Per-thread staging addresses are chunk-invariant: computed once here, so the per-chunk staging code is one 64-bit add,
+  // one select and one load (or LDS store) per item.  Items that are never valid point at the tensor base with limit 0;
+  // an item is live for chunk c0 iff c0 < lim (only the last, partial chunk of a Cin that is not a multiple of KC differs).
+  const float* sp[S_ITEMS];
+  int slim[S_ITEMS], sl[S_ITEMS];
+#pragma unroll
+  for (int it = 0; it < S_ITEMS; ++it) {
+    const int id = tid + it * NT;
+    const int r = id / (KC / 4), c4 = id % (KC / 4);
+    const int t = t_base + r;
+    const bool ok = id < s_count && t >= 0 && t < a.Lin && 4 * c4 < a.Cin;
+    sp[it] = ok ? xb + (size_t)t * a.Cin + 4 * c4 : a.x;
+    slim[it] = ok ? a.Cin - 4 * c4 : 0;
+    const int lr = (is == 1) ? r : ((r & 1) * Rper + (r >> 1));
+    sl[it] = id < s_count ? lr * RS + 4 * c4 : -1;
+  }
+  const float* wp[W_ITEMS];
+  int wlim[W_ITEMS];
+#pragma unroll
+  for (int it = 0; it < W_ITEMS; ++it) {
+    const int id = tid + it * NT;
+    const int n4 = id % (TN / 4);
+    const int kk = (id / (TN / 4)) % KC;
+    const int j = id / ((TN / 4) * KC);
+    const int n = n0 + 4 * n4;
+    const bool ok = id < w_count && kk < a.Cin && n < a.Cout;
+    wp[it] = ok ? a.w + ((size_t)a.t.widx[j < NTAPS ? j : 0] * a.Cin + kk) * a.Cout + n : a.w;
+    wlim[it] = ok ? a.Cin - kk : 0;
+  }
+
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int it = 0; it < S_ITEMS; ++it) {
+      const bool ok = c0 < slim[it];
+      const float4 v = *reinterpret_cast<const float4*>(sp[it] + (ok ? c0 : 0));
+      sreg[it] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);   // per-component: a float4 select goes through scratch
+    }
+#pragma unroll
+    for (int it = 0; it < W_ITEMS; ++it) {
+      const bool ok = c0 < wlim[it];
+      const float4 v = *reinterpret_cast<const float4*>(wp[it] + (ok ? (size_t)c0 * a.Cout : (size_t)0));
+      wreg[it] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+  };
+  auto store_chunk = [&](float* stage) {
+    float* wl = stage + slab_floats;
+#pragma unroll
+    for (int it = 0; it < S_ITEMS; ++it) {
+      if (sl[it] >= 0) {
+        float* d = stage + sl[it];
+        d[0] = sreg[it].x; d[1] = sreg[it].y; d[2] = sreg[it].z; d[3] = sreg[it].w;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < W_ITEMS; ++it) {
+      const int id = tid + it * NT;
+      if (id < w_count) *reinterpret_cast<float4*>(wl + id * 4) = wreg[it];   // [tap][KC][TN] is exactly id order
+    }
+  };
+
+  const int n_chunks = (a.Cin + KC - 1) / KC;
+  load_chunk(0);
+  store_chunk(smem);
+  if (n_chunks > 1) load_chunk(KC);
+  __syncthreads();
+
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    float* cur = smem + (ch & 1) * buf_floats;
+    if (ch + 1 < n_chunks) store_chunk(smem + ((ch + 1) & 1) * buf_floats);   // stage last read during chunk ch-1 (barrier below)
+    if (ch + 2 < n_chunks) load_chunk((ch + 2) * KC);
+    const float* slab = cur;
+    const float* wl = cur + slab_floats;
+
+#pragma unroll
     for (int j = 0; j < ntaps; ++j) {
       const int d = a.t.off[j] - minoff;
       const int rowbase = (is == 1) ? d : ((d & 1) * Rper + (d >> 1));
@@ -105,7 +168,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvA
           for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
       }
     }
-    __syncthreads();
+    __syncthreads();   // (a) stage `cur` is free to be overwritten at ch+1; (b) the stores into the other stage are visible
   }
 
   // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -127,7 +190,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvA
   }
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int KC>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KC, int NTAPS>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WAVES_M * WM * 32, TN = WAVES_N * WN * 32;
   const int is = a.t.in_stride;
@@ -139,7 +202,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
   const int R = is * (TM - 1) + (maxoff - minoff) + 1;
   const int Rper = (R + is - 1) / is;
   const int slab_floats = (is * Rper * (KC + 1) + 3) & ~3;
-  const size_t lds = sizeof(float) * ((size_t)slab_floats + (size_t)a.t.ntaps * KC * TN);
+  const size_t lds = 2 * sizeof(float) * ((size_t)slab_floats + (size_t)a.t.ntaps * KC * TN);   // two pipeline stages
   if (lds > 64 * 1024) {
     set_error("conv_mfma: LDS tile %zu B exceeds 64 KiB (ntaps=%d, in_stride=%d)", lds, a.t.ntaps, is);
     return GN_EINVAL;
@@ -151,7 +214,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     return GN_EINVAL;
   }
   prof_begin(s);
-  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, KC>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles);
+  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles);
   prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0);
   return check_launch("conv_mfma");
 }
@@ -166,12 +229,21 @@ int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s) {
     set_error("conv_mfma: in_stride %d unsupported", a.t.in_stride);
     return GN_EINVAL;
   }
-  if (a.t.ntaps < 1 || a.t.ntaps > 8) {
-    set_error("conv_mfma: ntaps %d unsupported", a.t.ntaps);
+  if (a.t.ntaps < 1 || a.t.ntaps > 5) {
+    set_error("conv_mfma: ntaps %d unsupported (1..5)", a.t.ntaps);
     return GN_EINVAL;
   }
-  if (a.Cout <= 64) return launch_conv<2, 2, 4, 1, 16>(a, s);  // 256 x 64 tile
-  return launch_conv<2, 2, 2, 2, 16>(a, s);                    // 128 x 128 tile
+  const bool narrow = a.Cout <= 64;   // 256 x 64 tile instead of 128 x 128
+#define GN_CONV(NT_)                                                        \
+  return narrow ? launch_conv<2, 2, 4, 1, 8, NT_>(a, s) : launch_conv<2, 2, 2, 2, 8, NT_>(a, s)
+  switch (a.t.ntaps) {
+    case 1: GN_CONV(1);
+    case 2: GN_CONV(2);
+    case 3: GN_CONV(3);
+    case 4: GN_CONV(4);
+    default: GN_CONV(5);
+  }
+#undef GN_CONV
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -208,36 +280,73 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N) void wgrad_mfma_kernel(Wgra
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int b_lo = split * a.b_per_split, b_hi = min(a.B, b_lo + a.b_per_split);
-  for (int b = b_lo; b < b_hi; ++b) {
+  const int cpb = (a.M + KT - 1) / KT;                     // K-chunks per batch element
+  const int n_chunks = (b_hi - b_lo) * cpb;
+
+  // register-staged pipeline over the K-chunks (b, m0): loads of chunk i+1 fly during the MFMA block of chunk i
+  constexpr int S_ITEMS = ((2 * (KT - 1) + 5) * (TC / 4) + NT - 1) / NT;
+  constexpr int D_ITEMS = (KT * (TN / 4) + NT - 1) / NT;
+  float4 sreg[S_ITEMS], dreg[D_ITEMS];
+  const int s_count = R * (TC / 4);
+
+  auto load_chunk = [&](int ch) {
+    const int b = b_lo + ch / cpb, m0 = (ch % cpb) * KT;
     const float* xb = a.x + (size_t)b * a.Lin * a.Cin;
     const float* dyb = a.dy + (size_t)b * a.M * a.Cout;
-    for (int m0 = 0; m0 < a.M; m0 += KT) {
-      const int t_base = is * m0 + minoff;
-      for (int id = tid; id < R * (TC / 4); id += NT) {
-        const int r = id / (TC / 4), c4 = id % (TC / 4);
-        const int t = t_base + r, c = c0 + 4 * c4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < a.Lin && c < a.Cin) v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.Cin + c);
-        *reinterpret_cast<float4*>(slab + r * TC + 4 * c4) = v;
+    const int t_base = is * m0 + minoff;
+#pragma unroll
+    for (int it = 0; it < S_ITEMS; ++it) {
+      const int id = tid + it * NT;
+      const int r = id / (TC / 4), c4 = id % (TC / 4);
+      const int t = t_base + r, c = c0 + 4 * c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (id < s_count && t >= 0 && t < a.Lin && c < a.Cin) v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.Cin + c);
+      sreg[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < D_ITEMS; ++it) {
+      const int id = tid + it * NT;
+      const int r = id / (TN / 4), n4 = id % (TN / 4);
+      const int m = m0 + r, n = n0 + 4 * n4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (id < KT * (TN / 4) && m < a.M && n < a.Cout) v = *reinterpret_cast<const float4*>(dyb + (size_t)m * a.Cout + n);
+      dreg[it] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int it = 0; it < S_ITEMS; ++it) {
+      const int id = tid + it * NT;
+      if (id < s_count) *reinterpret_cast<float4*>(slab + id * 4) = sreg[it];          // [R][TC] is id order
+    }
+#pragma unroll
+    for (int it = 0; it < D_ITEMS; ++it) {
+      const int id = tid + it * NT;
+      if (id < KT * (TN / 4)) *reinterpret_cast<float4*>(dyl + id * 4) = dreg[it];     // [KT][TN] is id order
+    }
+  };
+
+  if (n_chunks > 0) {
+    load_chunk(0);
+    store_chunk();
+  }
+  __syncthreads();
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const bool has_next = ch + 1 < n_chunks;
+    if (has_next) load_chunk(ch + 1);
+    const float* bp = dyl + h * TN + wn * 32 + i32;
+#pragma unroll
+    for (int q = 0; q < KT / 2; ++q) {
+      const float bv = bp[2 * q * TN];
+#pragma unroll
+      for (int j = 0; j < NTAPS; ++j) {
+        const float av = slab[(is * (2 * q + h) + (a.off[j] - minoff)) * TC + wc * 32 + i32];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
       }
-      for (int id = tid; id < KT * (TN / 4); id += NT) {
-        const int r = id / (TN / 4), n4 = id % (TN / 4);
-        const int m = m0 + r, n = n0 + 4 * n4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < a.M && n < a.Cout) v = *reinterpret_cast<const float4*>(dyb + (size_t)m * a.Cout + n);
-        *reinterpret_cast<float4*>(dyl + r * TN + 4 * n4) = v;
-      }
+    }
+    if (has_next) {
       __syncthreads();
-      const float* bp = dyl + h * TN + wn * 32 + i32;
-#pragma unroll
-      for (int q = 0; q < KT / 2; ++q) {
-        const float bv = bp[2 * q * TN];
-#pragma unroll
-        for (int j = 0; j < NTAPS; ++j) {
-          const float av = slab[(is * (2 * q + h) + (a.off[j] - minoff)) * TC + wc * 32 + i32];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
-        }
-      }
+      store_chunk();
       __syncthreads();
     }
   }

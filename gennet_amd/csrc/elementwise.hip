@@ -302,25 +302,29 @@ __global__ __launch_bounds__(256) void colred_kernel(ColRedArgs a) {
   }
 }
 
-__global__ void colred_final_kernel(const double* __restrict__ part, double* __restrict__ out, size_t n, int chunks) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double s = part[i];
-  for (int k = 1; k < chunks; ++k) s += part[(size_t)k * n + i];
-  out[i] = s;
-}
-__global__ void colred_final_f32_kernel(const double* __restrict__ part, float* __restrict__ out, size_t n, int chunks) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double s = part[i];
-  for (int k = 1; k < chunks; ++k) s += part[(size_t)k * n + i];
-  out[i] = (float)s;
+// sum the chunk partials: block = 32 columns x 8 chunk lanes; lane l adds chunks l, l+8, ... then the 8 lane sums are added in
+// lane order (fixed order -> bitwise reproducible)
+template <typename OUT>
+__global__ __launch_bounds__(256) void colred_final_kernel(const double* __restrict__ part, OUT* __restrict__ out, size_t n, int chunks) {
+  const int col = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const size_t i = (size_t)blockIdx.x * 32 + col;
+  double s = 0.0;
+  if (i < n)
+    for (int k = lane; k < chunks; k += 8) s += part[(size_t)k * n + i];
+  __shared__ double red[8][33];
+  red[lane][col] = s;
+  __syncthreads();
+  if (lane == 0 && i < n) {
+    double t = red[0][col];
+    for (int l = 1; l < 8; ++l) t += red[l][col];
+    out[i] = (OUT)t;
+  }
 }
 
 static int colred_chunks(size_t rows, int C) {
   const int NQ = C / 4, NQc = NQ < 256 ? NQ : 256, RL = 256 / NQc;
   const int gx = (NQ + NQc - 1) / NQc;
-  int chunks = (2048 + gx - 1) / gx;
+  int chunks = (1024 + gx - 1) / gx;
   const size_t max_chunks = (rows + (size_t)RL * 4 - 1) / ((size_t)RL * 4);
   if ((size_t)chunks > max_chunks) chunks = (int)max_chunks;
   if (chunks < 1) chunks = 1;
@@ -345,8 +349,8 @@ int colred_run(int mode, ColRedArgs a, void* ws, size_t ws_bytes, double* out_f6
   int rc = check_launch("colred");
   if (rc) return rc;
   const size_t n = (size_t)NV * a.C;
-  if (out_f32) hipLaunchKernelGGL(colred_final_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const double*)ws, out_f32, n, chunks);
-  else hipLaunchKernelGGL(colred_final_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const double*)ws, out_f64, n, chunks);
+  if (out_f32) hipLaunchKernelGGL(colred_final_kernel<float>, dim3(cdiv(n, 32)), dim3(256), 0, s, (const double*)ws, out_f32, n, chunks);
+  else hipLaunchKernelGGL(colred_final_kernel<double>, dim3(cdiv(n, 32)), dim3(256), 0, s, (const double*)ws, out_f64, n, chunks);
   return check_launch("colred_final");
 }
 
