@@ -182,12 +182,15 @@ class DeviceBank(object):
         self.n_pix = self.images.shape[1]
 
     def sample(self, batch, rng=_pyrandom, rank=0, world=1):
-        """random.sample of `batch*world` distinct template indices (bbhMahoGANy.py:1156, :1244); rank r keeps rows
-        [r*batch, (r+1)*batch) so that the union over ranks equals the single-process batch."""
-        idx = rng.sample(range(self.n), batch * world)
-        idx = idx[rank * batch:(rank + 1) * batch]
-        it = torch.tensor(idx, dtype=torch.int64, device=device())
-        return it
+        return torch.tensor(sample_indices(self.n, batch, rng, rank, world), dtype=torch.int64, device=device())
+
+
+def sample_indices(n, batch, rng=_pyrandom, rank=0, world=1):
+    """random.sample of `batch*world` distinct template indices (bbhMahoGANy.py:1156, :1244) from the host stream that every
+    rank advances identically; rank r keeps rows [r*batch, (r+1)*batch), so the union over ranks is exactly the batch a
+    single process would have drawn for the global batch size."""
+    idx = rng.sample(range(n), batch * world)
+    return idx[rank * batch:(rank + 1) * batch]
 
 
 def pe_train_step(signal_pe, bank, batch, cnn_noise_frac=1.0 / 8.0, rng=_pyrandom, nprng=np.random, rank=0, world=1):

@@ -1,0 +1,4 @@
+from ...engine import Input  # noqa: F401
+from ...layers import (Activation, BatchNormalization, Conv1D, Conv2D, Dense, Dropout, Flatten, LeakyReLU, MyLayer, ReLU,  # noqa: F401
+                       Reshape, UpSampling1D)
+from . import advanced_activations, convolutional, core, normalization  # noqa: F401

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""Counterpart of bbhMahoGANy.main() (bbhMahoGANy.py:959-1382) on the gennet_amd engine: load the ts/pars template files,
+train the CNN point-estimator, then the generator/discriminator pair, periodically pushing generator draws through the CNN
+and pickling the posterior samples.  File names, data preparation and loop bodies follow the reference; the plotting /
+KDE-overlap reporting block (:541-957, :1176-1231, :1302-1359) is host-side reporting and is out of scope.
+
+Single GPU:  python scripts/bbh_train.py --templates templates/ --tag _srate-1024hz_oversamp --n-pix 1024
+8 GPUs:      python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/bbh_train.py ...
+             (batch sizes are per GPU; the global batch is sharded as in SURVEY 8e)
+"""
+import argparse
+import os
+import pickle
+import random
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--templates', default='templates/')
+    ap.add_argument('--event-name', default='gw150914')
+    ap.add_argument('--training-num', type=int, default=50000)
+    ap.add_argument('--tag', default='_srate-1024hz_oversamp')
+    ap.add_argument('--n-pix', type=int, default=1024)
+    ap.add_argument('--batch-size', type=int, default=8)
+    ap.add_argument('--pe-batch-size', type=int, default=8)
+    ap.add_argument('--pe-iter', type=int, default=500000)
+    ap.add_argument('--max-iter', type=int, default=500000)
+    ap.add_argument('--cadence', type=int, default=100)
+    ap.add_argument('--lr', type=float, default=9e-5)
+    ap.add_argument('--event-scale', type=float, default=817.98, help='bbhMahoGANy.py:1028-1029 scales the event by this literal')
+    ap.add_argument('--out', default='.')
+    args = ap.parse_args()
+
+    from gennet_amd import bbh, dist, engine, templates as T
+    dp = dist.init()
+    rank, world = (dp.rank, dp.world_size) if dp else (0, 1)
+    engine.set_init_seed(1)
+    engine.set_device_seed(1000 + rank)
+    random.seed(1); np.random.seed(1)
+
+    base = '%s%s' % (args.templates, args.event_name)
+    ts, par = T.load_ts_pars('%s_ts_0_%sSamp%s.sav' % (base, args.training_num, args.tag), '%s_params_0_%sSamp%s.sav' % (base, args.training_num, args.tag))
+    images, labels, _, signal_pars = T.training_arrays(ts, par)                       # :1007-1014, :1036, :1053-1055
+    with open('data/%s0%s.sav' % (args.event_name, args.tag), 'rb') as f:            # :1027-1028
+        noise_signal = np.reshape(pickle.load(f, encoding='latin1') * args.event_scale, (args.n_pix, 1))
+
+    nets = bbh.build_and_compile(noise_signal, args.n_pix, lr=args.lr, data_parallel=dp)
+    if dp:
+        for m in (nets.generator, nets.signal_discriminator, nets.signal_pe):
+            dp.sync_model(m)
+    bank = bbh.DeviceBank(images, labels)
+    event = engine.to_device(noise_signal.reshape(-1))
+    os.makedirs(os.path.join(args.out, 'best_models'), exist_ok=True)
+    os.makedirs(os.path.join(args.out, 'GAN_posterior_samples'), exist_ok=True)
+
+    for i in range(args.pe_iter):                                                     # :1153-1173
+        pe_loss = bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch_size, rank=rank, world=world)
+        if i % 5000 == 0 and i > 0 and rank == 0:
+            nets.signal_pe.save(os.path.join(args.out, 'best_models/signal_pe.h5'), True)
+        if i % 1000 == 0 and rank == 0:
+            print('%d: [PE loss: %f, acc: %f]' % (i, pe_loss[0], pe_loss[1]), flush=True)
+    print('Completed CNN PE')
+
+    for i in range(args.max_iter):                                                    # :1241-1382
+        l = bbh.gan_train_step(nets, bank, event, args.batch_size, rank=rank, world=world)
+        if i % args.cadence == 0 and i > 0 and rank == 0:
+            print('%d: [sD loss: %f, acc: %f]  [sG loss: %f, acc: %f]' % (i, l[2], l[3], l[0], l[1]), flush=True)
+            pe_samples, waves = bbh.posterior_samples(nets, 4000)                     # :1330-1343
+            with open(os.path.join(args.out, 'gan_pe_samples.sav'), 'wb') as f:
+                pickle.dump(pe_samples, f, protocol=2)
+            with open(os.path.join(args.out, 'gan_pe_waveforms.sav'), 'wb') as f:
+                pickle.dump(waves, f, protocol=2)
+            nets.generator.save_weights(os.path.join(args.out, 'generator.h5'), True)
+            nets.signal_discriminator.save_weights(os.path.join(args.out, 'discriminator.h5'), True)
+            nets.signal_discriminator_on_generator.save_weights(os.path.join(args.out, 'signal_dis_on_gen.h5'), True)
+            with open(os.path.join(args.out, 'GAN_posterior_samples/posterior_samples_%05d.sav' % i), 'wb') as f:
+                pickle.dump(pe_samples, f)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,78 @@
+"""Data-parallel path: world_size-2 gloo runs against the single-process run of the same global batch.
+
+CPU test (runs everywhere): the communication layer gennet_amd.dist over gloo, driving the oracle's arithmetic -- gradient
+SUM with global-batch loss normalisation, SyncBN forward/backward sums, rank-sliced host sampling.
+GPU test: the real HIP path, 2 ranks x B/2 on one MI355X (gloo over CUDA tensors) vs 1 rank x B; tolerance = fp32
+reduction-order noise (1e-5 on losses; weights 1e-4 relative + 2 % of the Adam step budget, see test_nets_gpu.py).
+"""
+import os
+import pickle
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, 'tests', 'dp_worker.py')
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(mode, out, world):
+    env = dict(os.environ)
+    env.pop('RANK', None); env.pop('WORLD_SIZE', None); env.pop('LOCAL_RANK', None)
+    if world == 1:
+        cmd = [sys.executable, WORKER, mode, out]
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+               '--master-port', str(free_port()), WORKER, mode, out]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    return [pickle.load(open('%s.%d' % (out, k), 'rb')) for k in range(world)]
+
+
+def test_dp_math_over_gloo_cpu(tmp_path):
+    one = launch('cpu', str(tmp_path / 'one'), 1)[0]
+    two = launch('cpu', str(tmp_path / 'two'), 2)
+    for r in two:
+        assert np.abs(r['pe_grads'] - one['pe_grads']).max() <= 1e-12 * np.abs(one['pe_grads']).max()
+        lo, hi = r['bn']['rows']
+        full = one['bn']
+        assert np.allclose(r['bn']['mean'], full['mean'], rtol=1e-13) and np.allclose(r['bn']['var'], full['var'], rtol=1e-12)
+        assert np.allclose(r['bn']['y'], full['y'][lo * 12:hi * 12], rtol=1e-12, atol=1e-14)
+        assert np.allclose(r['bn']['dx'], full['dx'][lo * 12:hi * 12], rtol=1e-11, atol=1e-13)
+        assert np.allclose(r['bn']['dsum'], full['dsum'], rtol=1e-12)
+    # local parameter-gradient sums add up to the global ones (what the flat gradient all-reduce then produces)
+    assert np.allclose(two[0]['bn']['dgamma_local'] + two[1]['bn']['dgamma_local'], one['bn']['dsum'][5:], rtol=1e-12)
+    # host sampling: every rank advanced the stream identically; the slices tile the single-process draw
+    assert two[0]['next'] == two[1]['next']
+    import random
+    random.seed(1)
+    for k in range(3):
+        full_draw = random.sample(range(1000), 8)
+        assert two[0]['idx'][k] + two[1]['idx'][k] == full_draw
+
+
+@pytest.mark.gpu
+def test_two_ranks_equal_one_rank_on_gpu(tmp_path):
+    one = launch('gpu', str(tmp_path / 'one'), 1)[0]
+    two = launch('gpu', str(tmp_path / 'two'), 2)
+    for r in two:
+        for a, b in zip(r['losses'], one['losses']):
+            assert len(a) == len(b)
+            for u, v in zip(a, b):
+                assert abs(u - v) <= 1e-5 * abs(v) + 1e-7, (r['losses'], one['losses'])
+        for name in ('G', 'D', 'PE'):
+            for w, wr in zip(r['weights'][name], one['weights'][name]):
+                assert np.abs(w - wr).max() <= 1e-4 * np.abs(wr).max() + 0.02 * 2 * 9e-5, name
+    for name in ('G', 'D', 'PE'):
+        for w0, w1 in zip(two[0]['weights'][name], two[1]['weights'][name]):
+            assert np.array_equal(w0, w1)                   # replicas stay bit-identical
