@@ -15,6 +15,7 @@ vp, i32, f32, f64, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_uin
 
 _SIGS = {
     'gn_conv1d_fwd': [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    'gn_conv1d_fwd_dropout': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp],
     'gn_conv1d_transpose_w': [vp, vp, i32, i32, i32, vp],
     'gn_conv1d_dgrad': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'gn_conv1d_wgrad': [vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -24,6 +25,7 @@ _SIGS = {
     'gn_dense_bwd': [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp],
     'gn_act_fwd': [vp, vp, sz, i32, f32, vp],
     'gn_act_bwd': [vp, vp, vp, sz, i32, f32, vp],
+    'gn_act_dropout_bwd': [vp, vp, vp, vp, sz, i32, f32, f32, vp],
     'gn_dropout_mask': [vp, sz, f32, u64, u64, vp],
     'gn_dropout_apply': [vp, vp, vp, sz, f32, vp],
     'gn_upsample2_fwd': [vp, vp, i32, i32, i32, vp],

@@ -176,6 +176,21 @@ int gn_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, i
   return conv_dispatch(a, (hipStream_t)stream);
 }
 
+int gn_conv1d_fwd_dropout(const float* x, const float* w, const float* bias, const uint8_t* mask, float* y, int B, int L, int Cin, int Cout, int k, int stride,
+                          int pad_left, int Lout, int act, float act_param, float rate, void* stream) {
+  GN_REQUIRE(x && w && y && mask, "conv1d_fwd_dropout: null pointer");
+  GN_REQUIRE(B >= 0 && L > 0 && Cin > 0 && Cout > 4 && Cout % 4 == 0 && k >= 1 && k <= 5 && stride >= 1 && Lout > 0 && pad_left >= 0, "conv1d_fwd_dropout: bad shape");
+  GN_REQUIRE(rate >= 0.f && rate < 1.f, "conv1d_fwd_dropout: bad rate %f", rate);
+  if (B == 0) return GN_OK;
+  ConvArgs a = {};
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.B = B; a.Lin = L; a.Cin = Cin; a.Cout = Cout; a.M = Lout; a.Ly = Lout;
+  fwd_taps(&a.t, k, stride, pad_left);
+  a.act = act; a.act_param = act_param;
+  a.mask = mask; a.keep_scale = 1.0f / (1.0f - rate);
+  return conv_dispatch(a, (hipStream_t)stream);
+}
+
 int gn_conv1d_transpose_w(const float* w, float* wt, int k, int Cin, int Cout, void* stream) {
   GN_REQUIRE(w && wt && k >= 1 && Cin > 0 && Cout > 0, "transpose_w: bad arguments");
   return transpose_w(w, wt, k, Cin, Cout, (hipStream_t)stream);
@@ -309,6 +324,10 @@ int gn_act_fwd(const float* x, float* y, size_t n, int act, float p, void* strea
 int gn_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float p, void* stream) {
   GN_REQUIRE(dy && y && dx, "act_bwd: null pointer");
   return act_bwd(dy, y, dx, n, act, p, (hipStream_t)stream);
+}
+int gn_act_dropout_bwd(const float* dy, const float* y, const uint8_t* mask, float* dx, size_t n, int act, float p, float rate, void* stream) {
+  GN_REQUIRE(dy && y && mask && dx && rate >= 0.f && rate < 1.f, "act_dropout_bwd: bad arguments");
+  return act_dropout_bwd(dy, y, mask, dx, n, act, p, rate, (hipStream_t)stream);
 }
 int gn_dropout_mask(uint8_t* mask, size_t n, float rate, uint64_t seed, uint64_t offset, void* stream) {
   GN_REQUIRE(mask && rate >= 0.f && rate < 1.f, "dropout_mask: bad arguments");

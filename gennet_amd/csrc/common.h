@@ -39,6 +39,9 @@ struct ConvArgs {
   ConvTaps t;
   int act;
   float act_param;
+  int dbg;  // timing-experiment switches (GN_CONV_DBG), 0 in production
+  const uint8_t* mask;  // optional dropout keep-mask, same shape as y: y = mask ? act(.) * keep_scale : 0 (fused Dropout)
+  float keep_scale;
 };
 
 struct WgradArgs {
@@ -91,6 +94,7 @@ int dense_small_bwd(const float* x, const float* w, const float* dy, float* dx, 
 // elementwise.hip
 int act_fwd(const float* x, float* y, size_t n, int act, float p, hipStream_t s);
 int act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float p, hipStream_t s);
+int act_dropout_bwd(const float* dy, const float* y, const uint8_t* mask, float* dx, size_t n, int act, float p, float rate, hipStream_t s);
 int dropout_mask(uint8_t* mask, size_t n, float rate, uint64_t seed, uint64_t offset, hipStream_t s);
 int dropout_apply(const float* x, const uint8_t* mask, float* y, size_t n, float rate, hipStream_t s);
 int upsample2_fwd(const float* x, float* y, int B, int L, int C, hipStream_t s);

@@ -12,6 +12,7 @@
 // Tile: block = WAVES_M x WAVES_N waves, each wave WM x WN MFMA tiles of 32x32 -> TM x TN outputs per block.
 // LDS: slab rows padded to KC+1 words (stride-17 -> conflict-free ds_read_b32 across the 32 M-lanes); for in_stride 2
 // the slab is de-interleaved by row parity so the lane stride stays KC+1.  Weight tile [tap][KC][TN], N contiguous.
+#include <stdlib.h>
 #include "common.h"
 
 namespace gn {
@@ -106,18 +107,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_kernel(Co
     wlim[it] = ok ? a.Cin - kk : 0;
   }
 
+  // Validity is applied when the registers are WRITTEN TO LDS, not when they are loaded: a select on freshly loaded data would
+  // make the compiler wait for the prefetch immediately.  smask / wmask remember which items of the in-flight chunk are live.
+  unsigned smask = 0, wmask = 0;
   auto load_chunk = [&](int c0) {
+    smask = 0; wmask = 0;
+    if (!(a.dbg & 8))
 #pragma unroll
     for (int it = 0; it < S_ITEMS; ++it) {
       const bool ok = c0 < slim[it];
-      const float4 v = *reinterpret_cast<const float4*>(sp[it] + (ok ? c0 : 0));
-      sreg[it] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);   // per-component: a float4 select goes through scratch
+      smask |= (ok ? 1u : 0u) << it;
+      sreg[it] = *reinterpret_cast<const float4*>(sp[it] + (ok ? c0 : 0));   // always an in-bounds global address; zeroed at STORE time
     }
+    if (!(a.dbg & 16))
 #pragma unroll
     for (int it = 0; it < W_ITEMS; ++it) {
       const bool ok = c0 < wlim[it];
-      const float4 v = *reinterpret_cast<const float4*>(wp[it] + (ok ? (size_t)c0 * a.Cout : (size_t)0));
-      wreg[it] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+      wmask |= (ok ? 1u : 0u) << it;
+      wreg[it] = *reinterpret_cast<const float4*>(wp[it] + (ok ? (size_t)c0 * a.Cout : (size_t)0));
     }
   };
   auto store_chunk = [&](float* stage) {
@@ -126,13 +133,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_kernel(Co
     for (int it = 0; it < S_ITEMS; ++it) {
       if (sl[it] >= 0) {
         float* d = stage + sl[it];
-        d[0] = sreg[it].x; d[1] = sreg[it].y; d[2] = sreg[it].z; d[3] = sreg[it].w;
+        const bool ok = (smask >> it) & 1u;
+        d[0] = ok ? sreg[it].x : 0.f; d[1] = ok ? sreg[it].y : 0.f; d[2] = ok ? sreg[it].z : 0.f; d[3] = ok ? sreg[it].w : 0.f;
       }
     }
 #pragma unroll
     for (int it = 0; it < W_ITEMS; ++it) {
       const int id = tid + it * NT;
-      if (id < w_count) *reinterpret_cast<float4*>(wl + id * 4) = wreg[it];   // [tap][KC][TN] is exactly id order
+      if (id < w_count) {                                                      // [tap][KC][TN] is exactly id order
+        const bool ok = (wmask >> it) & 1u;
+        *reinterpret_cast<float4*>(wl + id * 4) = make_float4(ok ? wreg[it].x : 0.f, ok ? wreg[it].y : 0.f, ok ? wreg[it].z : 0.f, ok ? wreg[it].w : 0.f);
+      }
     }
   };
 
@@ -144,8 +155,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_kernel(Co
 
   for (int ch = 0; ch < n_chunks; ++ch) {
     float* cur = smem + (ch & 1) * buf_floats;
-    if (ch + 1 < n_chunks) store_chunk(smem + ((ch + 1) & 1) * buf_floats);   // stage last read during chunk ch-1 (barrier below)
-    if (ch + 2 < n_chunks) load_chunk((ch + 2) * KC);
+    if (ch + 1 < n_chunks && !(a.dbg & 1)) store_chunk(smem + ((ch + 1) & 1) * buf_floats);   // stage last read during chunk ch-1 (barrier below)
+    if (ch + 2 < n_chunks && !(a.dbg & 2)) load_chunk((ch + 2) * KC);
     const float* slab = cur;
     const float* wl = cur + slab_floats;
 
@@ -168,11 +179,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_kernel(Co
           for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
       }
     }
-    __syncthreads();   // (a) stage `cur` is free to be overwritten at ch+1; (b) the stores into the other stage are visible
+    if (!(a.dbg & 4)) __syncthreads();   // (a) stage `cur` is free to be overwritten at ch+1; (b) the stores into the other stage are visible
   }
 
   // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* yb = a.y + (size_t)b * a.Ly * a.Cout;
+  const uint8_t* mb = a.mask ? a.mask + (size_t)b * a.Ly * a.Cout : nullptr;
 #pragma unroll
   for (int nt = 0; nt < WN; ++nt) {
     const int n = n0 + wn * WN * 32 + nt * 32 + i32;
@@ -184,7 +196,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_kernel(Co
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         const int m = m0 + wm * WM * 32 + mt * 32 + row;
-        if (m < a.M) yb[(size_t)(a.t.out_stride * m + a.t.out_off) * a.Cout + n] = act_apply(acc[mt][nt][r] + bias, a.act, a.act_param);
+        if (m < a.M) {
+          const size_t o = (size_t)(a.t.out_stride * m + a.t.out_off) * a.Cout + n;
+          float v = act_apply(acc[mt][nt][r] + bias, a.act, a.act_param);
+          if (mb) v = mb[o] ? v * a.keep_scale : 0.f;
+          yb[o] = v;
+        }
       }
     }
   }
@@ -203,9 +220,16 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
   const int Rper = (R + is - 1) / is;
   const int slab_floats = (is * Rper * (KC + 1) + 3) & ~3;
   const size_t lds = 2 * sizeof(float) * ((size_t)slab_floats + (size_t)a.t.ntaps * KC * TN);   // two pipeline stages
-  if (lds > 64 * 1024) {
-    set_error("conv_mfma: LDS tile %zu B exceeds 64 KiB (ntaps=%d, in_stride=%d)", lds, a.t.ntaps, is);
+  if (lds > 160 * 1024) {
+    set_error("conv_mfma: LDS tile %zu B exceeds 160 KiB (ntaps=%d, in_stride=%d)", lds, a.t.ntaps, is);
     return GN_EINVAL;
+  }
+  if (lds > 64 * 1024) {   // opt in to more than the default 64 KiB of dynamic LDS (once per instantiation)
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
   }
   const int m_tiles = (a.M + TM - 1) / TM, n_tiles = (a.Cout + TN - 1) / TN;
   const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
@@ -220,7 +244,10 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
 }
 
 // Entry used by the C-ABI wrappers in capi.hip.
-int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s) {
+int conv_mfma_dispatch(const ConvArgs& a_in, hipStream_t s) {
+  ConvArgs a = a_in;
+  static const int dbg = getenv("GN_CONV_DBG") ? atoi(getenv("GN_CONV_DBG")) : 0;   // timing experiments only (wrong results)
+  a.dbg = dbg;
   if (a.Cin % 4 || a.Cout % 4) {
     set_error("conv_mfma: Cin (%d) and Cout (%d) must be multiples of 4", a.Cin, a.Cout);
     return GN_EINVAL;
@@ -234,14 +261,16 @@ int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s) {
     return GN_EINVAL;
   }
   const bool narrow = a.Cout <= 64;   // 256 x 64 tile instead of 128 x 128
-#define GN_CONV(NT_)                                                        \
-  return narrow ? launch_conv<2, 2, 4, 1, 8, NT_>(a, s) : launch_conv<2, 2, 2, 2, 8, NT_>(a, s)
+  // K-chunk: 8 channels for 4-5 taps (2 x 30 KiB stages -> 2-3 blocks/CU); 16 for 1-3 taps, so every barrier still covers >= 32
+  // MFMAs per wave (Dense, the stride-2 data-gradient phases and any short kernel)
+#define GN_CONV(NT_, KC_)                                                   \
+  return narrow ? launch_conv<2, 2, 4, 1, KC_, NT_>(a, s) : launch_conv<2, 2, 2, 2, KC_, NT_>(a, s)
   switch (a.t.ntaps) {
-    case 1: GN_CONV(1);
-    case 2: GN_CONV(2);
-    case 3: GN_CONV(3);
-    case 4: GN_CONV(4);
-    default: GN_CONV(5);
+    case 1: GN_CONV(1, 16);
+    case 2: GN_CONV(2, 16);
+    case 3: GN_CONV(3, 16);
+    case 4: GN_CONV(4, 8);
+    default: GN_CONV(5, 8);
   }
 #undef GN_CONV
 }

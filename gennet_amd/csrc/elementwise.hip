@@ -39,6 +39,31 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
   for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dx[i] = dy[i] * act_grad_from_y(y[i], act, p);
 }
 
+// fused backward of [activation -> inverted dropout] expressed through the layer output y (post-dropout):
+// dx = mask ? dy * keep_scale * act'(y / keep_scale) : 0
+__global__ void act_dropout_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const uint8_t* __restrict__ mask, float* __restrict__ dx,
+                                       size_t n, int act, float p, float keep_scale) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = n >> 2;
+  const float inv = 1.0f / keep_scale;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    const uchar4 k = reinterpret_cast<const uchar4*>(mask)[i];
+    float4 o;
+    o.x = k.x ? g.x * keep_scale * act_grad_from_y(v.x * inv, act, p) : 0.f; o.y = k.y ? g.y * keep_scale * act_grad_from_y(v.y * inv, act, p) : 0.f;
+    o.z = k.z ? g.z * keep_scale * act_grad_from_y(v.z * inv, act, p) : 0.f; o.w = k.w ? g.w * keep_scale * act_grad_from_y(v.w * inv, act, p) : 0.f;
+    reinterpret_cast<float4*>(dx)[i] = o;
+  }
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dx[i] = mask[i] ? dy[i] * keep_scale * act_grad_from_y(y[i] * inv, act, p) : 0.f;
+}
+int act_dropout_bwd(const float* dy, const float* y, const uint8_t* mask, float* dx, size_t n, int act, float p, float rate, hipStream_t s) {
+  if (n == 0) return GN_OK;
+  hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, dy, y, mask, dx, n, act, p, 1.0f / (1.0f - rate));
+  return check_launch("act_dropout_bwd");
+}
+
 int act_fwd(const float* x, float* y, size_t n, int act, float p, hipStream_t s) {
   if (n == 0) return GN_OK;
   hipLaunchKernelGGL(act_fwd_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, x, y, n, act, p);

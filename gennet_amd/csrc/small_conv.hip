@@ -54,7 +54,13 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvArgs a, int m_ti
       }
       s.x = act_apply(s.x, a.act, a.act_param); s.y = act_apply(s.y, a.act, a.act_param);
       s.z = act_apply(s.z, a.act, a.act_param); s.w = act_apply(s.w, a.act, a.act_param);
-      *reinterpret_cast<float4*>(yb + (size_t)(a.t.out_stride * m + a.t.out_off) * a.Cout + 4 * q) = s;
+      const size_t o = (size_t)(a.t.out_stride * m + a.t.out_off) * a.Cout + 4 * q;
+      if (a.mask) {
+        const uchar4 k = *reinterpret_cast<const uchar4*>(a.mask + (size_t)b * a.Ly * a.Cout + o);
+        s.x = k.x ? s.x * a.keep_scale : 0.f; s.y = k.y ? s.y * a.keep_scale : 0.f;
+        s.z = k.z ? s.z * a.keep_scale : 0.f; s.w = k.w ? s.w * a.keep_scale : 0.f;
+      }
+      *reinterpret_cast<float4*>(yb + o) = s;
     }
   }
 }

@@ -19,6 +19,24 @@ def _check_init(kernel_initializer):
         raise NotImplementedError('kernel_initializer %r (only glorot_uniform is used on the hot path)' % (kernel_initializer,))
 
 
+def _conv_fwd(node, ctx, x, w, b, stride, pl, Lout, act, out_shape_for_mask):
+    """conv + activation epilogue, plus the following Dropout when the planner fused one (training phase only)."""
+    if node.fused_drop is not None and ctx.training and node.fused_drop[0] > 0.0:
+        rate, drop_layer = node.fused_drop
+        mask = drop_layer.make_mask(ctx, out_shape_for_mask)
+        return ops.conv1d_fwd_dropout(x, w, b, mask, stride, pl, Lout, act[0], act[1], rate), mask, rate
+    return ops.conv1d_fwd(x, w, b, stride, pl, Lout, act[0], act[1]), None, 0.0
+
+
+def _conv_bwd_epilogue(dy, y, act, mask, rate):
+    """gradient through [activation -> dropout] expressed through the layer output, in place, one pass."""
+    if mask is not None:
+        return ops.act_dropout_bwd(dy, y, mask, act[0], act[1], rate, inplace=True)
+    if act[0] != 'linear':
+        return ops.act_bwd(dy, y, act[0], act[1], inplace=True)
+    return dy
+
+
 class Dense(Layer):
     """bbhMahoGANy.py:234 (100 -> 256*n_pix/2, MFMA GEMM), :377,:399,:494 (flatten -> 1 heads, streaming dot product)."""
     fusable_act = True
@@ -67,6 +85,7 @@ class Dense(Layer):
 class Conv1D(Layer):
     """bbhMahoGANy.py:250-292, :362-394."""
     fusable_act = True
+    fusable_drop = True
 
     def __init__(self, filters, kernel_size, strides=1, padding='valid', activation=None, kernel_initializer='glorot_uniform', use_bias=True, **kw):
         Layer.__init__(self, **kw)
@@ -92,15 +111,16 @@ class Conv1D(Layer):
     def forward(self, ctx, node, x):
         a = node.fused_act or self.activation
         Lout, pl = ops.conv_geometry(x.shape[1], self.k, self.stride, self.padding)
-        y = ops.conv1d_fwd(x, self.kernel.data, self.bias.data, self.stride, pl, Lout, a[0], a[1])
-        ctx.tape[node.index] = (x, y, a, pl)
+        fused_drop = node.fused_drop is not None and self.filters > 4
+        if node.fused_drop is not None and not fused_drop:
+            raise NotImplementedError('Dropout directly after a Conv1D with <= 4 filters')
+        y, mask, rate = _conv_fwd(node, ctx, x, self.kernel.data, self.bias.data, self.stride, pl, Lout, a, (x.shape[0], Lout, self.filters))
+        ctx.tape[node.index] = (x, y, a, pl, mask, rate)
         return y
 
     def backward(self, ctx, node, dy, need_dx, need_dw):
-        x, y, a, pl = ctx.tape.pop(node.index)
-        dy = dy.contiguous()
-        if a[0] != 'linear':
-            dy = ops.act_bwd(dy, y, a[0], a[1], inplace=True)
+        x, y, a, pl, mask, rate = ctx.tape.pop(node.index)
+        dy = _conv_bwd_epilogue(dy.contiguous(), y, a, mask, rate)
         if need_dw:
             ops.conv1d_wgrad(x, dy, self.k, self.stride, pl, self.kernel.grad, self.bias.grad)
         if need_dx:
@@ -113,6 +133,7 @@ class Conv2D(Layer):
     Executed as the exactly equivalent Conv1D over H with (w,c)-interleaved channels; the dead
     width taps kw in {0,4} receive zero gradient, as they do in the reference."""
     fusable_act = True
+    fusable_drop = True
 
     def __init__(self, filters, kernel_size, strides=(1, 1), padding='valid', activation=None, kernel_initializer='glorot_uniform', use_bias=True, **kw):
         Layer.__init__(self, **kw)
@@ -141,15 +162,13 @@ class Conv2D(Layer):
         Lout, pl = ops.conv_geometry(H, self.kh, self.sh, 'same')
         wf, bf = ops.conv2d_w2_fold(self.kernel.data, self.bias.data)
         xf = x.reshape(B, H, 2 * Cin)
-        y = ops.conv1d_fwd(xf, wf, bf, self.sh, pl, Lout, a[0], a[1])
-        ctx.tape[node.index] = (xf, y, a, pl, wf, Cin)
+        y, mask, rate = _conv_fwd(node, ctx, xf, wf, bf, self.sh, pl, Lout, a, (B, Lout, 2, self.filters))
+        ctx.tape[node.index] = (xf, y, a, pl, wf, Cin, mask, rate)
         return y.reshape(B, Lout, 2, self.filters)
 
     def backward(self, ctx, node, dy, need_dx, need_dw):
-        xf, y, a, pl, wf, Cin = ctx.tape.pop(node.index)
-        dy = dy.contiguous().reshape(y.shape)
-        if a[0] != 'linear':
-            dy = ops.act_bwd(dy, y, a[0], a[1], inplace=True)
+        xf, y, a, pl, wf, Cin, mask, rate = ctx.tape.pop(node.index)
+        dy = _conv_bwd_epilogue(dy.contiguous().reshape(y.shape), y, a, mask, rate)
         if need_dw:
             dwf, dbf = ops.conv1d_wgrad(xf, dy, self.kh, self.sh, pl)
             ops.conv2d_w2_unfold_grad(dwf, dbf, Cin, self.filters, self.kernel.grad, self.bias.grad)

@@ -65,6 +65,25 @@ def conv1d_fwd(x, w, b, stride, pad_left, Lout, act='linear', act_param=0.0):
     return y
 
 
+def conv1d_fwd_dropout(x, w, b, mask, stride, pad_left, Lout, act, act_param, rate):
+    """conv + activation + inverted dropout in one epilogue; mask: uint8 keep-mask with the shape of the output."""
+    _chk(x, w, b, mask)
+    B, L, Cin = x.shape
+    k, _, Cout = w.shape
+    y = torch.empty((B, Lout, Cout), dtype=torch.float32, device=x.device)
+    assert mask.numel() == y.numel()
+    _lib.call('gn_conv1d_fwd_dropout', _p(x), _p(w), _p(b), _p(mask), _p(y), B, L, Cin, Cout, k, stride, pad_left, Lout, ACT[act], float(act_param),
+              float(rate), _stream())
+    return y
+
+
+def act_dropout_bwd(dy, y, mask, act, act_param, rate, inplace=False):
+    _chk(dy, y, mask)
+    dx = dy if inplace else torch.empty_like(dy)
+    _lib.call('gn_act_dropout_bwd', _p(dy), _p(y), _p(mask), _p(dx), dy.numel(), ACT[act], float(act_param), float(rate), _stream())
+    return dx
+
+
 def conv1d_transpose_w(w):
     _chk(w)
     k, Cin, Cout = w.shape

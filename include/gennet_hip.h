@@ -45,6 +45,12 @@ int gn_conv1d_fwd(const float* x, const float* w, const float* bias, float* y,
                   int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout,
                   int act, float act_param, void* stream);
 
+/* Same with a following Dropout fused into the epilogue (discriminator: Conv2D -> LeakyReLU -> Dropout(0.4), bbhMahoGANy.py:439-443,
+ * :447-452): y = mask ? act(.)/(1-rate) : 0, mask = uint8 keep-mask of y's shape (gn_dropout_mask).  Cout > 4. */
+int gn_conv1d_fwd_dropout(const float* x, const float* w, const float* bias, const uint8_t* mask, float* y,
+                          int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout,
+                          int act, float act_param, float rate, void* stream);
+
 /* wt[k, co, ci] = w[k, ci, co]  (operand layout the dgrad GEMM consumes) */
 int gn_conv1d_transpose_w(const float* w, float* wt, int k, int Cin, int Cout, void* stream);
 
@@ -81,6 +87,8 @@ int gn_dense_bwd(const float* x, const float* w, const float* dy, float* dx, flo
 int gn_act_fwd(const float* x, float* y, size_t n, int act, float act_param, void* stream);
 /* dx = dy * act'(.) expressed through the activation OUTPUT y; in-place (dx == dy) allowed */
 int gn_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float act_param, void* stream);
+/* backward of [activation -> dropout] in one pass through the post-dropout output y: dx = mask ? dy/(1-rate) * act'(y*(1-rate)) : 0 */
+int gn_act_dropout_bwd(const float* dy, const float* y, const uint8_t* mask, float* dx, size_t n, int act, float act_param, float rate, void* stream);
 /* Dropout (bbhMahoGANy.py:239,255,...,288 rate 0.2; :443,:452 rate 0.4): keep-mask generation (Philox4x32-10,
  * element i draws counter (offset + i/4), lane i%4; keep iff u >= rate) and application y = x*mask/(1-rate). */
 int gn_dropout_mask(uint8_t* mask, size_t n, float rate, uint64_t seed, uint64_t offset, void* stream);
