@@ -110,76 +110,102 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_kernel(Co
   // Validity is applied when the registers are WRITTEN TO LDS, not when they are loaded: a select on freshly loaded data would
   // make the compiler wait for the prefetch immediately.  smask / wmask remember which items of the in-flight chunk are live.
   unsigned smask = 0, wmask = 0;
-  auto load_chunk = [&](int c0) {
-    smask = 0; wmask = 0;
-    if (!(a.dbg & 8))
-#pragma unroll
-    for (int it = 0; it < S_ITEMS; ++it) {
-      const bool ok = c0 < slim[it];
-      smask |= (ok ? 1u : 0u) << it;
-      sreg[it] = *reinterpret_cast<const float4*>(sp[it] + (ok ? c0 : 0));   // always an in-bounds global address; zeroed at STORE time
-    }
-    if (!(a.dbg & 16))
-#pragma unroll
-    for (int it = 0; it < W_ITEMS; ++it) {
-      const bool ok = c0 < wlim[it];
-      wmask |= (ok ? 1u : 0u) << it;
-      wreg[it] = *reinterpret_cast<const float4*>(wp[it] + (ok ? (size_t)c0 * a.Cout : (size_t)0));
+  auto load_s = [&](int it, int c0) {
+    const bool ok = c0 < slim[it];
+    smask = (smask & ~(1u << it)) | ((ok ? 1u : 0u) << it);
+    sreg[it] = *reinterpret_cast<const float4*>(sp[it] + (ok ? c0 : 0));   // always an in-bounds global address; zeroed at STORE time
+  };
+  auto load_w = [&](int it, int c0) {
+    const bool ok = c0 < wlim[it];
+    wmask = (wmask & ~(1u << it)) | ((ok ? 1u : 0u) << it);
+    wreg[it] = *reinterpret_cast<const float4*>(wp[it] + (ok ? (size_t)c0 * a.Cout : (size_t)0));
+  };
+  auto store_s = [&](int it, float* stage) {
+    if (sl[it] >= 0) {
+      float* d = stage + sl[it];
+      const bool ok = (smask >> it) & 1u;
+      d[0] = ok ? sreg[it].x : 0.f; d[1] = ok ? sreg[it].y : 0.f; d[2] = ok ? sreg[it].z : 0.f; d[3] = ok ? sreg[it].w : 0.f;
     }
   };
-  auto store_chunk = [&](float* stage) {
-    float* wl = stage + slab_floats;
-#pragma unroll
-    for (int it = 0; it < S_ITEMS; ++it) {
-      if (sl[it] >= 0) {
-        float* d = stage + sl[it];
-        const bool ok = (smask >> it) & 1u;
-        d[0] = ok ? sreg[it].x : 0.f; d[1] = ok ? sreg[it].y : 0.f; d[2] = ok ? sreg[it].z : 0.f; d[3] = ok ? sreg[it].w : 0.f;
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < W_ITEMS; ++it) {
-      const int id = tid + it * NT;
-      if (id < w_count) {                                                      // [tap][KC][TN] is exactly id order
-        const bool ok = (wmask >> it) & 1u;
-        *reinterpret_cast<float4*>(wl + id * 4) = make_float4(ok ? wreg[it].x : 0.f, ok ? wreg[it].y : 0.f, ok ? wreg[it].z : 0.f, ok ? wreg[it].w : 0.f);
-      }
+  auto store_w = [&](int it, float* stage) {
+    const int id = tid + it * NT;
+    if (id < w_count) {                                                        // [tap][KC][TN] is exactly id order
+      const bool ok = (wmask >> it) & 1u;
+      *reinterpret_cast<float4*>(stage + slab_floats + id * 4) = make_float4(ok ? wreg[it].x : 0.f, ok ? wreg[it].y : 0.f, ok ? wreg[it].z : 0.f, ok ? wreg[it].w : 0.f);
     }
   };
 
   const int n_chunks = (a.Cin + KC - 1) / KC;
-  load_chunk(0);
-  store_chunk(smem);
-  if (n_chunks > 1) load_chunk(KC);
+#pragma unroll
+  for (int it = 0; it < S_ITEMS; ++it) { load_s(it, 0); }
+#pragma unroll
+  for (int it = 0; it < W_ITEMS; ++it) { load_w(it, 0); }
+#pragma unroll
+  for (int it = 0; it < S_ITEMS; ++it) { store_s(it, smem); }
+#pragma unroll
+  for (int it = 0; it < W_ITEMS; ++it) { store_w(it, smem); }
+  {
+    const int c1 = (n_chunks > 1 ? 1 : 0) * KC;
+#pragma unroll
+    for (int it = 0; it < S_ITEMS; ++it) { load_s(it, c1); }
+#pragma unroll
+    for (int it = 0; it < W_ITEMS; ++it) { load_w(it, c1); }
+  }
   __syncthreads();
 
+  // Main loop, ONE barrier per K-chunk and NO separate staging phase: while the MFMAs of chunk ch run from stage `cur`, each
+  // staging item (a float4 of chunk ch+1 held in registers since the previous iteration) is written to stage `nxt` and its
+  // register is immediately re-loaded with chunk ch+2, one item per slot, spread evenly between the MFMA groups of the unrolled
+  // tap loop -- so co-resident blocks that run in lockstep never all sit in a staging phase at the same time.  The code is
+  // branch-free: past the end the loads are clamped to the last chunk and the stores land in the stage nobody reads again.
+  constexpr int SLOTS = NTAPS * (KC / 2);
+  constexpr int ITEMS = S_ITEMS + W_ITEMS;
   for (int ch = 0; ch < n_chunks; ++ch) {
     float* cur = smem + (ch & 1) * buf_floats;
-    if (ch + 1 < n_chunks && !(a.dbg & 1)) store_chunk(smem + ((ch + 1) & 1) * buf_floats);   // stage last read during chunk ch-1 (barrier below)
-    if (ch + 2 < n_chunks && !(a.dbg & 2)) load_chunk((ch + 2) * KC);
+    float* nxt = smem + ((ch + 1) & 1) * buf_floats;
+    const int c2 = min(ch + 2, n_chunks - 1) * KC;
     const float* slab = cur;
     const float* wl = cur + slab_floats;
 
-#pragma unroll
-    for (int j = 0; j < ntaps; ++j) {
+    // operand registers are double-buffered: the ds_reads of MFMA group g+1 are issued before the MFMAs of group g, so a
+    // wave's LDS latency hides under its own 256 cycles of matrix work (groups run across the tap boundary)
+    auto read_ops = [&](int g, float (&av)[WM], float (&bv)[WN]) {
+      const int j = g / (KC / 2), q = g % (KC / 2);
       const int d = a.t.off[j] - minoff;
       const int rowbase = (is == 1) ? d : ((d & 1) * Rper + (d >> 1));
       const float* ap = slab + (rowbase + wm * WM * 32 + i32) * RS + h;
       const float* bp = wl + (j * KC + h) * TN + wn * WN * 32 + i32;
 #pragma unroll
-      for (int q = 0; q < KC / 2; ++q) {
-        float av[WM], bv[WN];
+      for (int mt = 0; mt < WM; ++mt) av[mt] = ap[mt * 32 * RS + 2 * q];
 #pragma unroll
-        for (int mt = 0; mt < WM; ++mt) av[mt] = ap[mt * 32 * RS + 2 * q];
+      for (int nt = 0; nt < WN; ++nt) bv[nt] = bp[2 * q * TN + nt * 32];
+    };
+    float av0[WM], bv0[WN], av1[WM], bv1[WN];
+    read_ops(0, av0, bv0);
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) bv[nt] = bp[2 * q * TN + nt * 32];
+    for (int g = 0; g < SLOTS; ++g) {
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i) {
+        if ((i * SLOTS) / ITEMS == g) {             // compile-time after unrolling: item i is staged in this slot
+          if (i < S_ITEMS) { store_s(i, nxt); load_s(i, c2); }
+          else { store_w(i - S_ITEMS, nxt); load_w(i - S_ITEMS, c2); }
+        }
+      }
+      if (g % 2 == 0) {
+        if (g + 1 < SLOTS) read_ops(g + 1, av1, bv1);
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[mt], bv0[nt], acc[mt][nt], 0, 0, 0);
+      } else {
+        if (g + 1 < SLOTS) read_ops(g + 1, av0, bv0);
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[mt], bv1[nt], acc[mt][nt], 0, 0, 0);
       }
     }
-    if (!(a.dbg & 4)) __syncthreads();   // (a) stage `cur` is free to be overwritten at ch+1; (b) the stores into the other stage are visible
+    __syncthreads();   // (a) stage `cur` may be overwritten during ch+1; (b) the stores into `nxt` are visible to every wave
   }
 
   // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
