@@ -34,6 +34,19 @@ GFLOP_PER_WAVE_GAN = 79.6
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = 1/16 of the bf16 peak
 
 
+def pmc_traffic_per_launch():
+    """HBM-side bytes per conv_mfma_kernel launch from the committed PMC passes of this same command
+    (profiles/r01_pmc_traffic.json, written by scripts/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+    runs; counters cannot be read from inside the timed run).  None when the file is absent."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    ks = json.load(open(path))['kernels']
+    n = sum(v['launches'] for k, v in ks.items() if 'conv_mfma_kernel' in k)
+    b = sum(v['launches'] * v['hbm_bytes_per_launch'] for k, v in ks.items() if 'conv_mfma_kernel' in k)
+    return b / n if n else None
+
+
 def host_cores():
     """Host cores this process may actually use: min(affinity mask, cgroup CPU quota) -- the GPU box shows 256 logical CPUs
     but grants a 16-CPU quota per GPU; oversubscribing oneDNN with 256 threads there is ~10x slower than 16."""
@@ -84,7 +97,8 @@ def main():
     args = ap.parse_args()
 
     from gennet_amd import bbh, dist, engine, ops
-    dp = dist.init('nccl') if args.gpus > 1 else None
+    # RCCL (backend "nccl") over xGMI; GENNET_DIST_BACKEND=gloo only exists to rehearse the N>1 code path on a one-GPU box
+    dp = dist.init(os.environ.get('GENNET_DIST_BACKEND', 'nccl')) if args.gpus > 1 else None
     rank = dp.rank if dp else 0
     world = dp.world_size if dp else 1
     dev = engine.device()
@@ -144,7 +158,9 @@ def main():
                        'n_pix': N_PIX, 'cnn_batch': CNN_BATCH, 'gan_batch': GAN_BATCH, 'waveforms_per_step_per_gpu': WAVES,
                        'parallelism': 'dp%d' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (implicit-GEMM Conv1D forward + data gradient, v_mfma_f32_32x32x2_f32)',
-                         'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic_per_launch(),
+                         'traffic_note': 'fabric-side bytes per conv_mfma_kernel launch (2*FETCH_SIZE + WRITE_SIZE KiB, gfx950 FETCH correction) '
+                                         'from the separate PMC passes of this command summarised in profiles/r01_pmc_traffic.json',
                          'launches': conv['launches'], 'avg_launch_ms': conv['ms'] / max(conv['launches'], 1),
                          'algorithmic_flop_per_launch': conv['flop'] / max(conv['launches'], 1),
                          'wgrad_mfma_kernel': {'achieved': wgrad['flop'] / (wgrad['ms'] * 1e-3) / 1e12 if wgrad['ms'] > 0 else 0.0,
