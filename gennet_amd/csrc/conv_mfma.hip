@@ -21,7 +21,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int KC, int NTAPS>
+// WGLDS: the weight tile goes global -> LDS directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write); legal when the
+// tile has no ragged edge (Cout % TN == 0, Cin % KC == 0) because the LDS image [tap][KC][TN] is exactly lane-linear per wave.
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KC, int NTAPS, bool WGLDS>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_kernel(ConvArgs a, int m_tiles, int n_tiles) {
   constexpr int TM = WAVES_M * WM * 32;
   constexpr int TN = WAVES_N * WN * 32;
@@ -135,23 +137,41 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_kernel(Co
     }
   };
 
+  // LDS-DMA of one weight item: 64 lanes x 16 B land contiguously at the wave-uniform LDS address of the wave's first lane
+  auto glds_w = [&](int it, int c0, float* stage) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const float* src = wp[it] + (size_t)c0 * a.Cout;
+    float* dst = stage + slab_floats + (it * NT + (tid & ~63)) * 4;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+  };
+
   const int n_chunks = (a.Cin + KC - 1) / KC;
 #pragma unroll
   for (int it = 0; it < S_ITEMS; ++it) { load_s(it, 0); }
+  if (WGLDS) {
 #pragma unroll
-  for (int it = 0; it < W_ITEMS; ++it) { load_w(it, 0); }
+    for (int it = 0; it < W_ITEMS; ++it) { glds_w(it, 0, smem); }
+  } else {
+#pragma unroll
+    for (int it = 0; it < W_ITEMS; ++it) { load_w(it, 0); }
+  }
 #pragma unroll
   for (int it = 0; it < S_ITEMS; ++it) { store_s(it, smem); }
+  if (!WGLDS) {
 #pragma unroll
-  for (int it = 0; it < W_ITEMS; ++it) { store_w(it, smem); }
+    for (int it = 0; it < W_ITEMS; ++it) { store_w(it, smem); }
+  }
   {
     const int c1 = (n_chunks > 1 ? 1 : 0) * KC;
 #pragma unroll
     for (int it = 0; it < S_ITEMS; ++it) { load_s(it, c1); }
+    if (!WGLDS) {
 #pragma unroll
-    for (int it = 0; it < W_ITEMS; ++it) { load_w(it, c1); }
+      for (int it = 0; it < W_ITEMS; ++it) { load_w(it, c1); }
+    }
   }
-  __syncthreads();
+  __syncthreads();       // with WGLDS the compiler drains the LDS-DMA (vmcnt(0)) in front of this barrier
 
   // Main loop, ONE barrier per K-chunk and NO separate staging phase: while the MFMAs of chunk ch run from stage `cur`, each
   // staging item (a float4 of chunk ch+1 held in registers since the previous iteration) is written to stage `nxt` and its
@@ -159,11 +179,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_kernel(Co
   // tap loop -- so co-resident blocks that run in lockstep never all sit in a staging phase at the same time.  The code is
   // branch-free: past the end the loads are clamped to the last chunk and the stores land in the stage nobody reads again.
   constexpr int SLOTS = NTAPS * (KC / 2);
-  constexpr int ITEMS = S_ITEMS + W_ITEMS;
+  constexpr int ITEMS = S_ITEMS + (WGLDS ? 0 : W_ITEMS);
   for (int ch = 0; ch < n_chunks; ++ch) {
     float* cur = smem + (ch & 1) * buf_floats;
     float* nxt = smem + ((ch + 1) & 1) * buf_floats;
     const int c2 = min(ch + 2, n_chunks - 1) * KC;
+    if (WGLDS) {          // weights of chunk ch+1 fly global -> LDS stage `nxt` during this chunk's MFMAs; retired by the barrier below
+      const int c1 = min(ch + 1, n_chunks - 1) * KC;
+#pragma unroll
+      for (int it = 0; it < W_ITEMS; ++it) { glds_w(it, c1, nxt); }
+    }
     const float* slab = cur;
     const float* wl = cur + slab_floats;
 
@@ -233,8 +258,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_kernel(Co
   }
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int KC, int NTAPS>
-static int launch_conv(const ConvArgs& a, hipStream_t s) {
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KC, int NTAPS, bool WGLDS>
+static int launch_conv_impl(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WAVES_M * WM * 32, TN = WAVES_N * WN * 32;
   const int is = a.t.in_stride;
   int minoff = a.t.off[0], maxoff = a.t.off[0];
@@ -253,7 +278,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
   if (lds > 64 * 1024) {   // opt in to more than the default 64 KiB of dynamic LDS (once per instantiation)
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS, WGLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
   }
@@ -264,9 +289,17 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     return GN_EINVAL;
   }
   prof_begin(s);
-  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles);
+  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS, WGLDS>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles);
   prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0);
   return check_launch("conv_mfma");
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KC, int NTAPS>
+static int launch_conv(const ConvArgs& a, hipStream_t s) {
+  constexpr int TN = WAVES_N * WN * 32;
+  static const bool no_glds = getenv("GN_CONV_NOGLDS") != nullptr;      // A/B switch for benchmarking
+  const bool full = (a.Cout % TN == 0) && (a.Cin % KC == 0) && ((NTAPS * KC * (TN / 4)) % (64 * WAVES_M * WAVES_N) == 0) && !no_glds;
+  return full ? launch_conv_impl<WM, WN, WAVES_M, WAVES_N, KC, NTAPS, true>(a, s) : launch_conv_impl<WM, WN, WAVES_M, WAVES_N, KC, NTAPS, false>(a, s);
 }
 
 // Entry used by the C-ABI wrappers in capi.hip.
