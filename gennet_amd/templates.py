@@ -362,3 +362,54 @@ def training_arrays(ts, pars):
     images = np.reshape(ts[0], (ts[0].shape[0], ts[0].shape[2]))
     labels = np.array([[k.mc, (k.m2 / k.m1)] for k in pars])
     return images[:-1], labels[:-1], images[-1], labels[-1]
+
+
+# --------------------------------------------------------------------------------------------------- posterior-driven mode
+def m1m2_from_mc_q(mc, q):
+    """Closed form of what data/get_lalinf_pars.py:41-91 solves symbolically: q = m2/m1 <= 1, mc = (m1 m2)^(3/5)/(m1+m2)^(1/5)
+    -> m1 = mc (1+q)^(1/5) / q^(3/5), m2 = q m1."""
+    mc = np.asarray(mc, np.float64); q = np.asarray(q, np.float64)
+    m1 = mc * (1.0 + q) ** 0.2 / q ** 0.6
+    return m1, q * m1
+
+
+def sim_data_posterior(fs, T_obs, psds, post_m1, post_m2, post_mc=None, dets=['H1'], size=None, beta=[0.45, 0.55], batch_size=3907,
+                       peak_off=PEAK_OFFSET, to_host=True):
+    """lalinf_post_waveform_maker.py sim_data / gen_par (:383-476, :694-746): the same synthesiser fed with component masses
+    taken row by row from posterior samples instead of the prior (the CNN "sanity check" set, bbhMahoGANy.py:1228-1231).
+    Parameter handling follows the reference: idx ~ randint per sample from the numpy legacy stream, at most batch_size-1
+    posterior waveforms, np.random.permutation shuffle, then the event-like (36, 29) template with idx = N/2 - 4 appended last.
+    Returns ([ts (n,1,fs), yval], pars)."""
+    post_m1 = np.asarray(post_m1, np.float64); post_m2 = np.asarray(post_m2, np.float64)
+    n = len(post_m1) if size is None else min(size - 1 if gw_tmp else size, len(post_m1))
+    n = min(n, batch_size - 1)
+    low_idx, high_idx = convert_beta(beta, fs, T_obs)
+    pars = []
+    for k in range(n):
+        m1, m2 = post_m1[k], post_m2[k]
+        eta = m1 * m2 / (m1 + m2) ** 2
+        mc = post_mc[k] if post_mc is not None else (m1 + m2) * eta ** 0.6
+        idx = low_idx if low_idx == high_idx else int(np.random.randint(low_idx, high_idx, 1)[0])
+        pars.append(bbhparams(mc, m1 + m2, eta, m1, m2, RA, DEC, IOTA, PHI, PSI, idx, None, None))
+    syn = Synth(fs, T_obs, psds, dets[0], peak_off)
+    ts, _ = syn.templates([p.m1 for p in pars], [p.m2 for p in pars], [p.idx for p in pars])
+    perm = np.random.permutation(n)
+    pars = [pars[i] for i in perm]
+    ts = ts[torch.as_tensor(perm).to(ts.device)]
+    if gw_tmp:
+        m1, m2 = 36.0, 29.0
+        eta = m1 * m2 / (m1 + m2) ** 2
+        p = bbhparams((m1 + m2) * eta ** 0.6, m1 + m2, eta, m1, m2, RA, DEC, IOTA, PHI, PSI, int((T_obs * fs) / 2) - 4, None, None)
+        ev, _ = syn.templates([p.m1], [p.m2], [p.idx])
+        ts = torch.cat([ts, ev])
+        pars.append(p)
+    ts = ts.reshape(len(pars), 1, int(fs))
+    return [ts.cpu().numpy() if to_host else ts, np.ones(len(pars), dtype=int)], pars
+
+
+def save_sanity_check(path, ts, gw_norm_constant=1.0):
+    """data/<event>_cnn_sanity_check_ts_mass-time-vary<tag>.sav (lalinf_post_waveform_maker.py:812-837): float64 (n, fs)."""
+    arr = np.reshape(np.asarray(ts[0], np.float64) * gw_norm_constant, (ts[0].shape[0], ts[0].shape[2]))
+    with open(path, 'wb') as f:
+        pickle.dump(arr, f, protocol=2)
+    return arr

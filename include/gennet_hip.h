@@ -181,6 +181,12 @@ int gn_scale_f64(double* x, double s, size_t n, void* stream);
 int gn_mul_f64(double* x, const double* w, size_t n, size_t period, int complex_x, void* stream);
 int gn_f64_to_f32(const double* x, float* y, double s, size_t n, void* stream);
 
+/* ---- posterior read-out score (bbhMahoGANy.py:811-873 overlap_tests; kernel.pdf(positions) at :861,:866) -------------
+ * 2-D Gaussian KDE: out[p] = norm * sum_i exp(-0.5 * d^T Sinv d), d = pts[:,p] - data[:,i]; data (2,n), pts (2,m) row-major fp64;
+ * Sinv = [[inv00, inv01],[inv01, inv11]] and norm = 1/(n*sqrt(det(2*pi*Sigma))) as scipy.stats.gaussian_kde defines them. */
+int gn_kde2d_pdf(const double* data, int n, const double* pts, int m, double inv00, double inv01, double inv11, double norm,
+                 double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

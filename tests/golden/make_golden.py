@@ -76,6 +76,36 @@ def main():
     out['hunt_seed1_next_uniform'] = np.random.uniform(0, 1, 3)
     np.savez_compressed(OUT, **out)
     print('wrote', OUT, {k: np.asarray(v).shape for k, v in out.items()})
+    posterior_golden()
+
+
+def posterior_golden():
+    """overlap_tests (bbhMahoGANy.py:811-873) executed as written, on seeded samples, with scipy KDEs built the way
+    make_contour_plot does (:790: gaussian_kde(dataset), dataset = np.array([x, y]))."""
+    import warnings
+    from scipy.stats import anderson_ksamp, gaussian_kde, ks_2samp
+    lines = open('/root/reference/BBH_version/bbhMahoGANy.py').read().splitlines(True)
+    ns = {'np': np, 'ks_2samp': ks_2samp, 'anderson_ksamp': anderson_ksamp, 'comb_pe_model': False}
+    exec(compile(grab(lines, 811, 873), 'bbhMahoGANy.py:811-873', 'exec'), ns)
+    rng = np.random.RandomState(21)
+    n_pe, n_lal = 4000, 3907
+    cov = np.array([[0.6, 0.012], [0.012, 0.002]])
+    pe = rng.multivariate_normal([30.2, 0.80], cov, n_pe)
+    lal = rng.multivariate_normal([30.0, 0.79], cov * 1.3, n_lal)
+    pred_samp = [pe[:, 0:1].astype(np.float32), pe[:, 1:2].astype(np.float32)]          # what signal_pe.predict returns
+    lalinf_samp = np.array([lal[:, 0], lal[:, 1]])
+    k_cnn = gaussian_kde(np.array([pred_samp[0].reshape(-1), pred_samp[1].reshape(-1)]))
+    k_lal = gaussian_kde(lalinf_samp)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ks, ad, beta = ns['overlap_tests'](pred_samp, lalinf_samp, [30.0, 0.79], k_cnn, k_lal)
+    probe = np.vstack([rng.uniform(27, 33, 50), rng.uniform(0.6, 1.0, 50)])
+    out = {'pred_mc': pred_samp[0], 'pred_q': pred_samp[1], 'lalinf': lalinf_samp, 'beta': beta,
+           'ks': np.array([[ks[0][0], ks[0][1]], [ks[1][0], ks[1][1]]], dtype=np.float64),
+           'ad_stat': np.array([ad[0][0], ad[1][0]]), 'probe': probe, 'probe_pdf_cnn': k_cnn.pdf(probe), 'probe_pdf_lal': k_lal.pdf(probe)}
+    path = os.path.join(os.path.dirname(OUT), 'posterior_golden.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, 'beta =', beta)
 
 
 if __name__ == '__main__':

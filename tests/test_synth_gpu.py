@@ -213,3 +213,29 @@ def test_full_size_property_envelope_peak_lands_on_idx():
     assert idx.min() >= 3891 and idx.max() < 4300
     ts, ref2 = syn.templates([p.m1 for p in pars], [p.m2 for p in pars], idx)
     assert torch.equal(ref, ref2) and ts.shape == (256, fs) and torch.isfinite(ts).all()
+
+
+def test_posterior_driven_mode_matches_oracle():
+    """lalinf_post_waveform_maker mode: masses from posterior rows, randint idx per row from the legacy stream,
+    shuffle, event-like template with idx = N/2 - 4 last."""
+    from gennet_amd import templates as T
+    fs, Tobs = 512, 4
+    N = fs * Tobs
+    psd = S.analytic_psd(N // 2 + 1, 1.0 / Tobs)
+    rng = np.random.RandomState(8)
+    mc = rng.uniform(26, 32, 9); q = rng.uniform(0.6, 1.0, 9)
+    m1, m2 = T.m1m2_from_mc_q(mc, q)
+    assert np.allclose((m1 * m2) ** 0.6 / (m1 + m2) ** 0.2, mc, rtol=1e-13) and np.allclose(m2 / m1, q, rtol=1e-13)
+    np.random.seed(2)
+    (ts, y), pars = T.sim_data_posterior(fs, Tobs, psd, m1, m2, mc, size=8)
+    assert ts.shape == (8, 1, fs) and len(pars) == 8 and (pars[-1].m1, pars[-1].m2, pars[-1].idx) == (36.0, 29.0, N // 2 - 4)
+    np.random.seed(2)
+    lo, hi = S.convert_beta([0.45, 0.55], fs, Tobs)
+    idx = [int(np.random.randint(lo, hi, 1)[0]) for _ in range(7)]
+    perm = np.random.permutation(7)
+    Fp, Fc = S.antenna_response(S.EVENT_TIME, S.RA, S.DEC, S.PSI)
+    for row, k in enumerate(perm):
+        assert (pars[row].m1, pars[row].m2, pars[row].idx, pars[row].mc) == (m1[k], m2[k], idx[k], mc[k])
+        p = S.bbhparams(mc[k], m1[k] + m2[k], 0, m1[k], m2[k], S.RA, S.DEC, S.IOTA, S.PHI, S.PSI, idx[k], None, None)
+        crop, _ = S.gen_bbh(fs, Tobs, psd, p, Fp, Fc)
+        assert rel(ts[row, 0], crop) < 1e-9
