@@ -32,6 +32,7 @@ _SIGS = {
     'gn_upsample2_bwd': [vp, vp, i32, i32, i32, vp],
     'gn_subtract_stack_fwd': [vp, vp, vp, i32, i32, vp],
     'gn_subtract_stack_bwd': [vp, vp, i32, i32, vp],
+    'gn_assemble_d_batch': [vp, vp, vp, vp, vp, i32, i32, vp],
     'gn_fill_uniform': [vp, sz, f32, f32, u64, u64, vp],
     'gn_fill_normal': [vp, sz, f32, f32, u64, u64, vp],
     'gn_gather_rows': [vp, vp, vp, i32, i32, vp],
@@ -74,8 +75,16 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise GennetHipError('%s not found: build it with `python -m gennet_amd.build` (hipcc --offload-arch=gfx950); '
-                                 'gennet_amd has no CPU fallback' % LIB_PATH)
+            try:                            # a fresh checkout on a box that has hipcc: compile the kernels (~30 s), nothing else
+                from . import build as _build
+                _build.build(verbose=False)
+            except Exception as e:          # noqa: BLE001
+                raise GennetHipError('%s not found and building it failed (%s): run `python -m gennet_amd.build` '
+                                     '(hipcc --offload-arch=gfx950); gennet_amd has no CPU fallback' % (LIB_PATH, e))
+        # torch ships its own libamdhip64; it must be the HIP runtime of the process (device pointers and streams come from
+        # torch), so torch is imported BEFORE this library is dlopen-ed and the library's NEEDED libamdhip64 resolves to the
+        # already-loaded copy.  Loading in the other order gives the process two HIP runtimes and launches fail.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for table, restype in ((_SIGS, i32), (_SIZE_FNS, sz)):
             for name, args in table.items():

@@ -214,10 +214,7 @@ def assemble_discriminator_batch(real, noise, fake, event):
     real images [template | N(0,1) noise], fake images [G(z) | event - G(z)] in REVERSED sample order (:1271 prepends),
     labels 1...1 0...0."""
     B, n = real.shape[0], real.shape[1]
-    real2 = torch.stack([real.reshape(B, n), noise.reshape(B, n)], dim=2)
-    fake2 = ops.subtract_stack_fwd(fake.reshape(B, n, 1).contiguous(), event).reshape(B, n, 2)
-    fake2 = torch.flip(fake2, dims=[0])
-    sX = torch.cat([real2, fake2]).reshape(2 * B, n, 2, 1).contiguous()
+    sX = ops.assemble_d_batch(real.reshape(B, n).contiguous(), noise.reshape(B, n).contiguous(), fake.reshape(B, n).contiguous(), event)
     sy = torch.cat([torch.ones(B, device=real.device), torch.zeros(B, device=real.device)])
     return sX, sy
 

@@ -353,6 +353,10 @@ int gn_subtract_stack_bwd(const float* dimg, float* dx, int B, int n, void* stre
   GN_REQUIRE(dimg && dx, "subtract_stack_bwd: null pointer");
   return subtract_stack_bwd(dimg, dx, B, n, (hipStream_t)stream);
 }
+int gn_assemble_d_batch(const float* real, const float* noise, const float* fake, const float* event, float* sX, int B, int n, void* stream) {
+  GN_REQUIRE(real && noise && fake && event && sX && B >= 0 && n > 0, "assemble_d_batch: bad arguments");
+  return assemble_d_batch(real, noise, fake, event, sX, B, n, (hipStream_t)stream);
+}
 int gn_fill_uniform(float* out, size_t n, float lo, float hi, uint64_t seed, uint64_t offset, void* stream) {
   GN_REQUIRE(out, "fill_uniform: null pointer");
   return fill_uniform(out, n, lo, hi, seed, offset, (hipStream_t)stream);

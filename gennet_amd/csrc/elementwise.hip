@@ -169,6 +169,26 @@ int subtract_stack_bwd(const float* dimg, float* dx, int B, int n, hipStream_t s
   return check_launch("subtract_stack_bwd");
 }
 
+// bbhMahoGANy.py:1268-1289: discriminator batch [real | fake] as width-2 images, fake half in reversed sample order
+__global__ void assemble_d_batch_kernel(const float* __restrict__ real, const float* __restrict__ noise, const float* __restrict__ fake,
+                                        const float* __restrict__ ev, float2* __restrict__ sX, int B, int n) {
+  const size_t total = (size_t)2 * B * n, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int row = (int)(i / n), t = (int)(i % n);
+    if (row < B) {
+      sX[i] = make_float2(real[(size_t)row * n + t], noise[(size_t)row * n + t]);
+    } else {
+      const float f = fake[(size_t)(2 * B - 1 - row) * n + t];
+      sX[i] = make_float2(f, ev[t] - f);
+    }
+  }
+}
+int assemble_d_batch(const float* real, const float* noise, const float* fake, const float* ev, float* sX, int B, int n, hipStream_t s) {
+  if (!B || !n) return GN_OK;
+  hipLaunchKernelGGL(assemble_d_batch_kernel, dim3(stream_grid((size_t)2 * B * n)), dim3(256), 0, s, real, noise, fake, ev, (float2*)sX, B, n);
+  return check_launch("assemble_d_batch");
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ out, size_t rows, int width) {
   const size_t total = rows * width, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {

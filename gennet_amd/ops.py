@@ -220,6 +220,15 @@ def subtract_stack_bwd(dimg):
     return dx
 
 
+def assemble_d_batch(real, noise, fake, event):
+    """[real | fake] discriminator batch (2B, n, 2, 1); fake half reversed like the reference's prepend loop."""
+    _chk(real, noise, fake, event)
+    B, n = real.shape[0], real.shape[1]
+    sX = torch.empty((2 * B, n, 2, 1), dtype=torch.float32, device=real.device)
+    _lib.call('gn_assemble_d_batch', _p(real), _p(noise), _p(fake), _p(event), _p(sX), B, n, _stream())
+    return sX
+
+
 def fill_uniform(shape, lo, hi, seed, offset, device):
     t = torch.empty(shape, dtype=torch.float32, device=device)
     _lib.call('gn_fill_uniform', _p(t), t.numel(), float(lo), float(hi), int(seed), int(offset), _stream())

@@ -99,6 +99,9 @@ int gn_upsample2_bwd(const float* dy, float* dx, int B, int L, int C, void* stre
 /* MyLayer (bbhMahoGANy.py:180-184): img[b,t,0] = x[b,t]; img[b,t,1] = event[t] - x[b,t];  adjoint dx = d0 - d1 */
 int gn_subtract_stack_fwd(const float* x, const float* event, float* img, int B, int n, void* stream);
 int gn_subtract_stack_bwd(const float* dimg, float* dx, int B, int n, void* stream);
+/* discriminator batch assembly (bbhMahoGANy.py:1268-1289): sX (2B, n, 2, 1): rows [0,B) = [real[b,t], noise[b,t]], rows [B,2B) =
+ * [fake[j,t], event[t]-fake[j,t]] with j = 2B-1-row (the reference's np.append prepends, so the fake half is in reversed order) */
+int gn_assemble_d_batch(const float* real, const float* noise, const float* fake, const float* event, float* sX, int B, int n, void* stream);
 /* uniform(lo,hi) and normal(mean,std) fills from Philox (host RNG replacement for bbhMahoGANy.py:1161,1247,1277,1295) */
 int gn_fill_uniform(float* out, size_t n, float lo, float hi, uint64_t seed, uint64_t offset, void* stream);
 int gn_fill_normal(float* out, size_t n, float mean, float std, uint64_t seed, uint64_t offset, void* stream);
