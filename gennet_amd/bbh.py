@@ -209,6 +209,18 @@ def pe_train_step(signal_pe, bank, batch, cnn_noise_frac=1.0 / 8.0, rng=_pyrando
     return signal_pe.train_on_batch(x.reshape(batch, bank.n_pix, 1), [y[:, 0].contiguous(), y[:, 1].contiguous()])
 
 
+def pe_train_step_online(signal_pe, online_bank, batch, cnn_noise_frac=1.0 / 8.0, nprng=np.random):
+    """The CNN loop body with templates synthesised on the GPU for every batch (BASELINE config 5; templates.OnlineBank) instead of
+    gathered from a stored bank; otherwise identical to pe_train_step."""
+    x, y = online_bank.draw(batch)
+    n_noisy = int(batch * cnn_noise_frac)
+    sigma = float(nprng.uniform(0, 5))
+    if n_noisy > 0:
+        seed, off = device_rng().take(n_noisy * online_bank.n_pix)
+        ops.axpy(x[:n_noisy], ops.fill_normal((n_noisy, online_bank.n_pix), 0.0, sigma, seed, off, device()), 1.0)
+    return signal_pe.train_on_batch(x.reshape(batch, online_bank.n_pix, 1), [y[:, 0].contiguous(), y[:, 1].contiguous()])
+
+
 def assemble_discriminator_batch(real, noise, fake, event):
     """bbhMahoGANy.py:1268-1289 on the device, vectorised (the reference's np.append loop is O(B^2) host copies):
     real images [template | N(0,1) noise], fake images [G(z) | event - G(z)] in REVERSED sample order (:1271 prepends),

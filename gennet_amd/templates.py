@@ -413,3 +413,67 @@ def save_sanity_check(path, ts, gw_norm_constant=1.0):
     with open(path, 'wb') as f:
         pickle.dump(arr, f, protocol=2)
     return arr
+
+
+# --------------------------------------------------------------------------------------------------- on-GPU synthesis inside the train loop
+class OnlineBank(object):
+    """BASELINE config 5: templates (and, optionally, PSD-coloured noise whitened with the same PSD) synthesised on the GPU inside
+    the training loop instead of being read from a stored bank -- no template ever touches host memory.
+
+    Every draw() is a fresh batch from the prior: masses by the hunt_constrain rejection rule (vectorised on the host: a few
+    thousand uniforms), idx ~ randint(convert_beta(beta)), then chirp -> whiten -> irFFT -> align -> crop on the device, scaled by
+    gw_norm_constant, labels [mc, m2/m1].  The stream is this object's own RandomState(seed): data-parallel ranks pass different
+    seeds and never exchange anything (SURVEY 8e).  noise='coloured' adds gen_noise (Philox) -> whiten_data('td') -> central crop;
+    noise='white' adds N(0,1) as the reference's train loops do (bbhMahoGANy.py:1161, :1277)."""
+
+    def __init__(self, fs, T_obs=4, psd=None, gw_norm_constant=1.0, beta=(0.45, 0.55), seed=1, noise=None, peak_off=PEAK_OFFSET):
+        self.fs, self.T_obs = int(fs), int(T_obs)
+        self.N = self.fs * self.T_obs
+        self.psd = np.asarray(psd, np.float64)
+        self.syn = Synth(fs, T_obs, self.psd, 'H1', peak_off)
+        self.g = float(gw_norm_constant)
+        self.lo, self.hi = convert_beta(list(beta), fs, T_obs)
+        self.rng = np.random.RandomState(seed)
+        self.noise = noise
+        self.seed = int(seed)
+        self.counter = 0
+        self.n_pix = self.fs
+        self._win = _d64(tukey(self.N, alpha=1.0 / 8.0)) if noise == 'coloured' else None
+
+    def draw_masses(self, n):
+        """hunt_constrain prior (gw_template_maker.py:327-339), vectorised rejection sampling."""
+        out1, out2 = [], []
+        lo, span = np.log(5.0), np.log(95.0) - np.log(5.0)
+        need = n
+        while need > 0:
+            m = np.exp(lo + self.rng.uniform(0, 1, (4 * need + 64, 2)) * span)
+            a, b = m[:, 0], m[:, 1]
+            eta = a * b / (a + b) ** 2
+            mc = (a + b) * eta ** 0.6
+            ok = (a + b < 100.0) & (a > 5.0) & (b > 5.0) & (a >= b) & (b / a >= 0.5) & (mc >= 20.0) & (mc <= 35.0)
+            out1.append(a[ok][:need]); out2.append(b[ok][:need])
+            need -= len(out1[-1])
+        return np.concatenate(out1), np.concatenate(out2)
+
+    def draw(self, batch):
+        """-> (images (batch, fs) fp32, labels (batch, 2) fp32), both device tensors."""
+        m1, m2 = self.draw_masses(batch)
+        idx = self.rng.randint(self.lo, self.hi, batch) if self.hi > self.lo else np.full(batch, self.lo)
+        ts, _ = self.syn.templates(m1, m2, idx, g=self.g)
+        c0 = int((self.T_obs / 2) * self.fs - self.fs / 2)
+        if self.noise == 'coloured':
+            nz = gen_noise_device(self.fs, self.T_obs, self.psd, batch, self.seed, self.counter)
+            self.counter += batch * (self.N // 2 + 1)
+            _mul(nz, self._win, False)
+            X = _mul(rfft(nz), self.syn.scale, True)
+            ts = ts + irfft(X, self.N)[:, c0:c0 + self.fs]
+        out = torch.empty((batch, self.fs), dtype=torch.float32, device=device())
+        ts = ts.contiguous()
+        _lib.call('gn_f64_to_f32', ts.data_ptr(), out.data_ptr(), 1.0, ts.numel(), _s())
+        if self.noise == 'white':
+            _lib.call('gn_fill_normal', (nz32 := torch.empty_like(out)).data_ptr(), out.numel(), 0.0, 1.0, self.seed, self.counter, _s())
+            self.counter += out.numel()
+            _lib.call('gn_axpy', out.data_ptr(), nz32.data_ptr(), 1.0, out.numel(), _s())
+        eta = m1 * m2 / (m1 + m2) ** 2
+        labels = torch.as_tensor(np.stack([(m1 + m2) * eta ** 0.6, m2 / m1], axis=1).astype(np.float32)).to(device())
+        return out, labels

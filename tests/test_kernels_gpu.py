@@ -287,3 +287,57 @@ def test_bad_arguments_raise_not_crash():
         ops.conv1d_fwd(x, w, None, 1, 2, 8)
     with pytest.raises(_lib.GennetHipError):
         ops.conv1d_fwd(torch.zeros((1, 8, 16)), torch.zeros((5, 16, 16)), None, 1, 2, 8)       # CPU tensors: no fallback
+
+
+FULL_SIZE_LAYERS = [
+    # the BASELINE-size layer shapes of the three networks at n_pix = 2048: (L, Cin, Cout, stride, padding)
+    (2048, 512, 1024, 1, 'same'),      # generator conv5 (74 % of G)
+    (1018, 512, 1024, 2, 'valid'),     # point-estimator q-branch conv5
+    (2040, 256, 512, 2, 'valid'),      # q-branch conv4
+    (1024, 512, 1024, 2, 'same'),      # discriminator conv2 after the width-2 fold
+    (2048, 1024, 1, 1, 'same'),        # generator output conv
+    (2048, 2, 512, 2, 'same'),         # discriminator conv1 after the fold
+]
+
+
+@pytest.mark.parametrize("L,Cin,Cout,s,padding", FULL_SIZE_LAYERS)
+def test_full_size_layers_spot_checked_against_the_definition(L, Cin, Cout, s, padding):
+    """Full BASELINE layer shapes: the oracle cannot run them whole in seconds, so 300 randomly chosen output / gradient elements
+    are recomputed in fp64 straight from the definition y[b,t,co] = bias + sum_{k,ci} x[b, s t + k - pl, ci] w[k,ci,co]
+    (and its two adjoints).  Tolerance 2e-5 of the output scale (K up to 2560-term fp32 chains)."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(L + Cin)
+    B, k = 3, 5
+    x = rng.randn(B, L, Cin).astype(np.float32); w = (rng.randn(k, Cin, Cout) / np.sqrt(k * Cin)).astype(np.float32); b = rng.randn(Cout).astype(np.float32)
+    Lout, pl = ops.conv_geometry(L, k, s, padding)
+    xd, wd = g(x), g(w)
+    y = ops.conv1d_fwd(xd, wd, g(b), s, pl, Lout).cpu().numpy()
+    dy = rng.randn(B, Lout, Cout).astype(np.float32)
+    dyd = g(dy)
+    dx = ops.conv1d_dgrad(dyd, ops.conv1d_transpose_w(wd), L, s, pl).cpu().numpy()
+    dw, db = ops.conv1d_wgrad(xd, dyd, k, s, pl)
+    dw = dw.cpu().numpy(); db = db.cpu().numpy()
+    x64, w64, dy64 = x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64)
+    ys = np.abs(y).max(); dxs = np.abs(dx).max(); dws = np.abs(dw).max()
+    for _ in range(300):
+        bb, t, co = rng.randint(B), rng.randint(Lout), rng.randint(Cout)
+        acc = float(b[co])
+        for kk in range(k):
+            tt = s * t + kk - pl
+            if 0 <= tt < L:
+                acc += x64[bb, tt] @ w64[kk, :, co]
+        assert abs(y[bb, t, co] - acc) <= 2e-5 * ys
+        tau, ci = rng.randint(L), rng.randint(Cin)
+        acc = 0.0
+        for kk in range(k):
+            num = tau + pl - kk
+            if num % s == 0 and 0 <= num // s < Lout:
+                acc += dy64[bb, num // s] @ w64[kk, ci]
+        assert abs(dx[bb, tau, ci] - acc) <= 2e-5 * dxs
+    for _ in range(40):
+        kk, ci, co = rng.randint(k), rng.randint(Cin), rng.randint(Cout)
+        ts_ = np.arange(Lout); src = s * ts_ + kk - pl
+        ok = (src >= 0) & (src < L)
+        acc = sum(x64[bb, src[ok], ci] @ dy64[bb, ts_[ok], co] for bb in range(B))
+        assert abs(dw[kk, ci, co] - acc) <= 5e-5 * dws
+    assert np.abs(db - dy64.sum(axis=(0, 1))).max() <= 5e-5 * np.abs(db).max()

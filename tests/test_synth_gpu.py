@@ -239,3 +239,39 @@ def test_posterior_driven_mode_matches_oracle():
         p = S.bbhparams(mc[k], m1[k] + m2[k], 0, m1[k], m2[k], S.RA, S.DEC, S.IOTA, S.PHI, S.PSI, idx[k], None, None)
         crop, _ = S.gen_bbh(fs, Tobs, psd, p, Fp, Fc)
         assert rel(ts[row, 0], crop) < 1e-9
+
+
+def test_online_bank_config5_fs4096():
+    """BASELINE config 5 (srate 4096): on-GPU synthesis inside the loop.  Size-independent properties at full size: labels obey the
+    prior box, the envelope peak lands inside the crop-relative window [1649, 2468) + peak offset, draws are
+    reproducible per seed and differ across seeds (rank streams), coloured + whitened noise has ~unit variance."""
+    from gennet_amd import templates as T
+    fs, Tobs = 4096, 4
+    psd = S.analytic_psd(fs * Tobs // 2 + 1, 1.0 / Tobs)
+    ob = T.OnlineBank(fs, Tobs, psd, gw_norm_constant=1.0, seed=3)
+    x, y = ob.draw(64)
+    assert x.shape == (64, fs) and x.dtype == torch.float32 and y.shape == (64, 2) and torch.isfinite(x).all()
+    yl = y.cpu().numpy()
+    assert np.all((yl[:, 0] >= 20) & (yl[:, 0] <= 35) & (yl[:, 1] >= 0.5) & (yl[:, 1] <= 1.0))
+    peak = x.abs().argmax(dim=1).cpu().numpy()
+    assert np.all((peak >= 7782 + 11 - 6144 - 40) & (peak < 8601 + 11 - 6144 + 40))
+    x2, y2 = T.OnlineBank(fs, Tobs, psd, seed=3).draw(64)
+    assert torch.equal(x, x2) and torch.equal(y, y2)
+    x3, _ = T.OnlineBank(fs, Tobs, psd, seed=4).draw(64)
+    assert not torch.equal(x, x3)
+    obn = T.OnlineBank(fs, Tobs, psd, seed=3, noise='coloured')
+    xn, _ = obn.draw(64)
+    resid = (xn - x).cpu().numpy()
+    assert abs(resid.std() - 0.95) < 0.06                    # sqrt(mean tukey^2) loss of the 'td' whitening path (SURVEY Appendix D)
+
+
+def test_pe_train_step_online_runs_at_fs2048():
+    from gennet_amd import bbh, engine, templates as T
+    fs = 2048
+    psd = S.analytic_psd(fs * 4 // 2 + 1, 0.25)
+    ob = T.OnlineBank(fs, 4, psd, seed=1, noise='white')
+    pe = bbh.signal_pe_model(fs)
+    pe.compile(loss='mean_squared_error', optimizer=engine.Adam(lr=9e-5, beta_1=0.5), metrics=['accuracy'])
+    l0 = bbh.pe_train_step_online(pe, ob, 16)
+    l1 = bbh.pe_train_step_online(pe, ob, 16)
+    assert len(l0) == 5 and np.isfinite(l0).all() and np.isfinite(l1).all()
