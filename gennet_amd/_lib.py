@@ -18,6 +18,8 @@ _SIGS = {
     'gn_conv1d_fwd_dropout': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp],
     'gn_conv1d_transpose_w': [vp, vp, i32, i32, i32, vp],
     'gn_conv1d_dgrad': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    'gn_conv1d_dgrad_fused': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, f32, vp],
+    'gn_dense_bwd_fused': [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, f32, f32, vp],
     'gn_conv1d_wgrad': [vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'gn_conv2d_w2_fold': [vp, vp, vp, vp, i32, i32, i32, vp],
     'gn_conv2d_w2_unfold_grad': [vp, vp, vp, vp, i32, i32, i32, vp],

@@ -196,7 +196,23 @@ int gn_conv1d_transpose_w(const float* w, float* wt, int k, int Cin, int Cout, v
   return transpose_w(w, wt, k, Cin, Cout, (hipStream_t)stream);
 }
 
+static int dgrad_impl(const float* dy, const float* wt, float* dx, int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout, const float* gy,
+                      const uint8_t* gmask, int gact, float gparam, float grate, void* stream);
+
 int gn_conv1d_dgrad(const float* dy, const float* wt, float* dx, int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout, void* stream) {
+  return dgrad_impl(dy, wt, dx, B, L, Cin, Cout, k, stride, pad_left, Lout, nullptr, nullptr, GN_ACT_LINEAR, 0.f, 0.f, stream);
+}
+
+int gn_conv1d_dgrad_fused(const float* dy, const float* wt, float* dx, int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout,
+                          const float* y_prev, const uint8_t* mask_prev, int act_prev, float act_param_prev, float rate_prev, void* stream) {
+  GN_REQUIRE(y_prev, "conv1d_dgrad_fused: y_prev is NULL");
+  GN_REQUIRE(Cin > 4 && Cout > 4, "conv1d_dgrad_fused: only the MFMA path fuses the producer's activation gradient (Cin %d, Cout %d)", Cin, Cout);
+  GN_REQUIRE(rate_prev >= 0.f && rate_prev < 1.f, "conv1d_dgrad_fused: bad rate");
+  return dgrad_impl(dy, wt, dx, B, L, Cin, Cout, k, stride, pad_left, Lout, y_prev, mask_prev, act_prev, act_param_prev, mask_prev ? rate_prev : 0.f, stream);
+}
+
+static int dgrad_impl(const float* dy, const float* wt, float* dx, int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout, const float* gy,
+                      const uint8_t* gmask, int gact, float gparam, float grate, void* stream) {
   GN_REQUIRE(dy && wt && dx, "conv1d_dgrad: null pointer");
   GN_REQUIRE(B >= 0 && L > 0 && Cin > 0 && Cout > 0 && k >= 1 && k <= 8 && stride >= 1 && Lout > 0 && pad_left >= 0, "conv1d_dgrad: bad shape");
   if (B == 0) return GN_OK;
@@ -220,6 +236,7 @@ int gn_conv1d_dgrad(const float* dy, const float* wt, float* dx, int B, int L, i
     GN_REQUIRE(nt > 0, "conv1d_dgrad: phase %d has no taps (k %d < stride %d)", p, k, stride);
     a.t.ntaps = nt;
     a.act = GN_ACT_LINEAR;
+    a.gy = gy; a.gmask = gmask; a.gact = gact; a.gparam = gparam; a.gscale = 1.0f / (1.0f - grate);
     int rc = conv_dispatch(a, (hipStream_t)stream);
     if (rc) return rc;
   }
@@ -284,6 +301,13 @@ size_t gn_dense_bwd_workspace(int B, int in, int out) {
   size_t w = wgrad_workspace_bytes(1, in, out, 1);
   size_t b = bias_grad_ws((size_t)B, out);
   return (w > b ? w : b) + (size_t)in * out * sizeof(float) + 256;
+}
+
+int gn_dense_bwd_fused(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int in, int out, const uint8_t* mask_prev,
+                       int act_prev, float act_param_prev, float rate_prev, void* stream) {
+  GN_REQUIRE(x && w && dy && dx && dw && B > 0 && in > 0 && out >= 1 && out <= 4, "dense_bwd_fused: bad arguments (small-output heads only)");
+  GN_REQUIRE(rate_prev >= 0.f && rate_prev < 1.f, "dense_bwd_fused: bad rate");
+  return dense_small_bwd(x, w, dy, dx, dw, db, B, in, out, (hipStream_t)stream, act_prev, act_param_prev, mask_prev, 1.0f / (1.0f - (mask_prev ? rate_prev : 0.f)));
 }
 
 int gn_dense_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, void* ws, size_t ws_bytes, int B, int in, int out, void* stream) {

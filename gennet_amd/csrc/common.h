@@ -42,6 +42,12 @@ struct ConvArgs {
   int dbg;  // timing-experiment switches (GN_CONV_DBG), 0 in production
   const uint8_t* mask;  // optional dropout keep-mask, same shape as y: y = mask ? act(.) * keep_scale : 0 (fused Dropout)
   float keep_scale;
+  // gradient epilogue (data-gradient launches): out *= d act(prev)/d pre-activation, expressed through the PRODUCER layer's output
+  // gy (same shape as y), optionally through its dropout: out = gmask ? out * gscale * act'(gy/gscale) : 0
+  const float* gy;
+  const uint8_t* gmask;
+  int gact;
+  float gparam, gscale;
 };
 
 struct WgradArgs {
@@ -90,7 +96,8 @@ int conv_smallcout_dispatch(const ConvArgs& a, hipStream_t s);
 size_t wgrad_small_workspace_bytes(int B, int M, int Cin, int Cout, int ntaps);
 int wgrad_small_dispatch(WgradSmallArgs a, float* dw, size_t ws_bytes, hipStream_t s);
 int dense_small_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in, int out, int act, float p, hipStream_t s);
-int dense_small_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int in, int out, hipStream_t s);
+int dense_small_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int in, int out, hipStream_t s,
+                    int gact = 0, float gparam = 0.f, const uint8_t* gmask = nullptr, float gscale = 1.f);
 // elementwise.hip
 int act_fwd(const float* x, float* y, size_t n, int act, float p, hipStream_t s);
 int act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float p, hipStream_t s);

@@ -358,7 +358,8 @@ int dense_small_fwd(const float* x, const float* w, const float* bias, float* y,
 // dw[i,o] = sum_b x[b,i] dy[b,o];  dx[b,i] = sum_o dy[b,o] w[i,o];  one thread per 4 input features, loop over b.
 template <int OUT>
 __global__ __launch_bounds__(256) void dense_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
-                                                              float* __restrict__ dx, float* __restrict__ dw, int B, int in) {
+                                                              float* __restrict__ dx, float* __restrict__ dw, int B, int in, int gact, float gparam,
+                                                              const uint8_t* __restrict__ gmask, float gscale) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= (size_t)in) return;
   float wv[4][OUT], acc[4][OUT];
@@ -383,7 +384,15 @@ __global__ __launch_bounds__(256) void dense_small_bwd_kernel(const float* __res
         acc[e][o] = fmaf(xs[e], g[o], acc[e][o]);
         d[e] = fmaf(g[o], wv[e][o], d[e]);
       }
-    if (dx) *reinterpret_cast<float4*>(dx + (size_t)b * in + i) = make_float4(d[0], d[1], d[2], d[3]);
+    if (dx) {
+      if (gact != GN_ACT_LINEAR || gmask) {       // x IS the producer's output: fuse its [activation -> dropout] backward here
+        uint8_t k[4] = {1, 1, 1, 1};
+        if (gmask) { const uchar4 m = *reinterpret_cast<const uchar4*>(gmask + (size_t)b * in + i); k[0] = m.x; k[1] = m.y; k[2] = m.z; k[3] = m.w; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = k[e] ? d[e] * gscale * act_grad_from_y(xs[e] / gscale, gact, gparam) : 0.f;
+      }
+      *reinterpret_cast<float4*>(dx + (size_t)b * in + i) = make_float4(d[0], d[1], d[2], d[3]);
+    }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -399,17 +408,18 @@ __global__ void colsum_small_kernel(const float* __restrict__ dy, float* __restr
   db[o] = s;
 }
 
-int dense_small_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int in, int out, hipStream_t s) {
+int dense_small_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int in, int out, hipStream_t s, int gact,
+                    float gparam, const uint8_t* gmask, float gscale) {
   if (out < 1 || out > 4 || in % 4) {
     set_error("dense_small_bwd: out %d (1..4) / in %d (%%4) unsupported", out, in);
     return GN_EINVAL;
   }
   const unsigned grid = cdiv((size_t)in / 4, 256);
   switch (out) {
-    case 1: hipLaunchKernelGGL(dense_small_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, x, w, dy, dx, dw, B, in); break;
-    case 2: hipLaunchKernelGGL(dense_small_bwd_kernel<2>, dim3(grid), dim3(256), 0, s, x, w, dy, dx, dw, B, in); break;
-    case 3: hipLaunchKernelGGL(dense_small_bwd_kernel<3>, dim3(grid), dim3(256), 0, s, x, w, dy, dx, dw, B, in); break;
-    default: hipLaunchKernelGGL(dense_small_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, x, w, dy, dx, dw, B, in); break;
+    case 1: hipLaunchKernelGGL(dense_small_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, x, w, dy, dx, dw, B, in, gact, gparam, gmask, gscale); break;
+    case 2: hipLaunchKernelGGL(dense_small_bwd_kernel<2>, dim3(grid), dim3(256), 0, s, x, w, dy, dx, dw, B, in, gact, gparam, gmask, gscale); break;
+    case 3: hipLaunchKernelGGL(dense_small_bwd_kernel<3>, dim3(grid), dim3(256), 0, s, x, w, dy, dx, dw, B, in, gact, gparam, gmask, gscale); break;
+    default: hipLaunchKernelGGL(dense_small_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, x, w, dy, dx, dw, B, in, gact, gparam, gmask, gscale); break;
   }
   int rc = check_launch("dense_small_bwd");
   if (rc) return rc;

@@ -187,6 +187,8 @@ class RunContext(object):
         self.dropout_masks = dropout_masks or {}
         self.train_ids = None if train_params is None else set(id(p) for p in train_params)
         self.tape = {}
+        self.epi = {}                      # node index -> (y, act, act_param, mask, rate): epilogue a consumer's dgrad can differentiate
+        self.pre_applied = set()           # producers whose activation gradient has already been applied to their dy
 
     def wants_grad(self, layer):
         if self.train_ids is None:
@@ -290,7 +292,7 @@ class Layer(object):
 
 
 class Node(object):
-    __slots__ = ('layer', 'inbound', 'fused_act', 'fused_drop', 'absorbed', 'index', 'out_shape', 'owners')
+    __slots__ = ('layer', 'inbound', 'fused_act', 'fused_drop', 'absorbed', 'index', 'out_shape', 'owners', 'fuse_prev')
 
     def __init__(self, layer, inbound, out_shape, owners=()):
         self.layer = layer
@@ -301,6 +303,7 @@ class Node(object):
         self.absorbed = False              # this node's work happens inside its producer
         self.index = -1
         self.out_shape = out_shape
+        self.fuse_prev = -1                # producer node whose [activation -> dropout] backward this node's dgrad absorbs
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -497,6 +500,20 @@ class Model(Layer):
                 if c is not None and c.layer.drop_rate is not None:
                     n.fused_drop = (c.layer.drop_rate, c.layer)
                     c.absorbed = True
+        # backward fusion: node n's data gradient can carry the producer p's activation/dropout derivative in its epilogue when p's
+        # output reaches n through shape-only nodes (absorbed activations, Flatten, Reshape) and nothing else consumes it
+        for n in self.nodes:
+            n.fuse_prev = -1
+            if n.absorbed or len(n.inbound) != 1 or not getattr(n.layer, 'can_absorb_prev_act_bwd', False):
+                continue
+            cur, ok = n.inbound[0], True
+            while cur >= 0 and (self.nodes[cur].absorbed or getattr(self.nodes[cur].layer, 'shape_only', False)):
+                if len(consumers[cur]) != 1 or cur in outs:
+                    ok = False
+                    break
+                cur = self.nodes[cur].inbound[0]
+            if ok and cur >= 0 and len(consumers[cur]) == 1 and cur not in outs and getattr(self.nodes[cur].layer, 'offers_act_bwd', False):
+                n.fuse_prev = cur
         self._planned = True
 
     # -- execution
@@ -529,7 +546,8 @@ class Model(Layer):
                 need_dw = ctx.wants_grad(n.layer)
                 if not need_dx and not need_dw:
                     continue
-                dx = n.layer.backward(ctx, n, dy, need_dx, need_dw)
+                prev = ctx.epi.get(n.fuse_prev) if (n.fuse_prev >= 0 and need_dx) else None
+                dx = n.layer.backward(ctx, n, dy, need_dx, need_dw, prev) if prev is not None else n.layer.backward(ctx, n, dy, need_dx, need_dw)
             if dx is None:
                 continue
             for i in n.inbound:

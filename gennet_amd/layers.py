@@ -28,8 +28,11 @@ def _conv_fwd(node, ctx, x, w, b, stride, pl, Lout, act, out_shape_for_mask):
     return ops.conv1d_fwd(x, w, b, stride, pl, Lout, act[0], act[1]), None, 0.0
 
 
-def _conv_bwd_epilogue(dy, y, act, mask, rate):
-    """gradient through [activation -> dropout] expressed through the layer output, in place, one pass."""
+def _conv_bwd_epilogue(dy, y, act, mask, rate, ctx=None, node=None):
+    """gradient through [activation -> dropout] expressed through the layer output, in place, one pass -- unless the consumer's
+    data-gradient kernel already applied it in its epilogue (engine backward fusion)."""
+    if ctx is not None and node.index in ctx.pre_applied:
+        return dy
     if mask is not None:
         return ops.act_dropout_bwd(dy, y, mask, act[0], act[1], rate, inplace=True)
     if act[0] != 'linear':
@@ -40,6 +43,11 @@ def _conv_bwd_epilogue(dy, y, act, mask, rate):
 class Dense(Layer):
     """bbhMahoGANy.py:234 (100 -> 256*n_pix/2, MFMA GEMM), :377,:399,:494 (flatten -> 1 heads, streaming dot product)."""
     fusable_act = True
+    offers_act_bwd = True
+
+    @property
+    def can_absorb_prev_act_bwd(self):
+        return self.units <= 4
 
     def __init__(self, units, activation=None, kernel_initializer='glorot_uniform', use_bias=True, **kw):
         Layer.__init__(self, **kw)
@@ -67,18 +75,20 @@ class Dense(Layer):
         a = self._act(node)
         y = ops.dense_fwd(x, self.kernel.data, self.bias.data, a[0], a[1])
         ctx.tape[node.index] = (x, y, a)
+        if ctx.training and a[0] != 'linear':
+            ctx.epi[node.index] = (y, a[0], a[1], None, 0.0)
         return y
 
-    def backward(self, ctx, node, dy, need_dx, need_dw):
+    def backward(self, ctx, node, dy, need_dx, need_dw, prev=None):
         x, y, a = ctx.tape.pop(node.index)
-        dy = dy.contiguous()
-        if a[0] != 'linear':
-            dy = ops.act_bwd(dy, y, a[0], a[1], inplace=True)
+        dy = _conv_bwd_epilogue(dy.contiguous(), y, a, None, 0.0, ctx, node)
+        if prev is not None:
+            ctx.pre_applied.add(node.fuse_prev)
         if need_dw:
-            dx, _, _ = ops.dense_bwd(x, self.kernel.data, dy, need_dx, self.kernel.grad, self.bias.grad)
+            dx, _, _ = ops.dense_bwd(x, self.kernel.data, dy, need_dx, self.kernel.grad, self.bias.grad, prev=prev)
             return dx
         # frozen layer: data gradient only (scratch weight-gradient buffers are not needed on the small-output path)
-        dx, _, _ = ops.dense_bwd(x, self.kernel.data, dy, True)
+        dx, _, _ = ops.dense_bwd(x, self.kernel.data, dy, True, prev=prev)
         return dx
 
 
@@ -86,6 +96,8 @@ class Conv1D(Layer):
     """bbhMahoGANy.py:250-292, :362-394."""
     fusable_act = True
     fusable_drop = True
+    offers_act_bwd = True
+    can_absorb_prev_act_bwd = True
 
     def __init__(self, filters, kernel_size, strides=1, padding='valid', activation=None, kernel_initializer='glorot_uniform', use_bias=True, **kw):
         Layer.__init__(self, **kw)
@@ -116,15 +128,21 @@ class Conv1D(Layer):
             raise NotImplementedError('Dropout directly after a Conv1D with <= 4 filters')
         y, mask, rate = _conv_fwd(node, ctx, x, self.kernel.data, self.bias.data, self.stride, pl, Lout, a, (x.shape[0], Lout, self.filters))
         ctx.tape[node.index] = (x, y, a, pl, mask, rate)
+        if ctx.training and (a[0] != 'linear' or mask is not None):
+            ctx.epi[node.index] = (y, a[0], a[1], mask, rate)
         return y
 
-    def backward(self, ctx, node, dy, need_dx, need_dw):
+    def backward(self, ctx, node, dy, need_dx, need_dw, prev=None):
         x, y, a, pl, mask, rate = ctx.tape.pop(node.index)
-        dy = _conv_bwd_epilogue(dy.contiguous(), y, a, mask, rate)
+        dy = _conv_bwd_epilogue(dy.contiguous(), y, a, mask, rate, ctx, node)
         if need_dw:
             ops.conv1d_wgrad(x, dy, self.k, self.stride, pl, self.kernel.grad, self.bias.grad)
         if need_dx:
-            return ops.conv1d_dgrad(dy, ops.conv1d_transpose_w(self.kernel.data), x.shape[1], self.stride, pl)
+            if prev is not None and ops.can_fuse_dgrad(x.shape[2], self.filters):
+                ctx.pre_applied.add(node.fuse_prev)
+            else:
+                prev = None
+            return ops.conv1d_dgrad(dy, ops.conv1d_transpose_w(self.kernel.data), x.shape[1], self.stride, pl, prev)
         return None
 
 
@@ -134,6 +152,8 @@ class Conv2D(Layer):
     width taps kw in {0,4} receive zero gradient, as they do in the reference."""
     fusable_act = True
     fusable_drop = True
+    offers_act_bwd = True
+    can_absorb_prev_act_bwd = True
 
     def __init__(self, filters, kernel_size, strides=(1, 1), padding='valid', activation=None, kernel_initializer='glorot_uniform', use_bias=True, **kw):
         Layer.__init__(self, **kw)
@@ -164,16 +184,22 @@ class Conv2D(Layer):
         xf = x.reshape(B, H, 2 * Cin)
         y, mask, rate = _conv_fwd(node, ctx, xf, wf, bf, self.sh, pl, Lout, a, (B, Lout, 2, self.filters))
         ctx.tape[node.index] = (xf, y, a, pl, wf, Cin, mask, rate)
+        if ctx.training and (a[0] != 'linear' or mask is not None):
+            ctx.epi[node.index] = (y, a[0], a[1], mask, rate)
         return y.reshape(B, Lout, 2, self.filters)
 
-    def backward(self, ctx, node, dy, need_dx, need_dw):
+    def backward(self, ctx, node, dy, need_dx, need_dw, prev=None):
         xf, y, a, pl, wf, Cin, mask, rate = ctx.tape.pop(node.index)
-        dy = _conv_bwd_epilogue(dy.contiguous().reshape(y.shape), y, a, mask, rate)
+        dy = _conv_bwd_epilogue(dy.contiguous().reshape(y.shape), y, a, mask, rate, ctx, node)
         if need_dw:
             dwf, dbf = ops.conv1d_wgrad(xf, dy, self.kh, self.sh, pl)
             ops.conv2d_w2_unfold_grad(dwf, dbf, Cin, self.filters, self.kernel.grad, self.bias.grad)
         if need_dx:
-            dx = ops.conv1d_dgrad(dy, ops.conv1d_transpose_w(wf), xf.shape[1], self.sh, pl)
+            if prev is not None and ops.can_fuse_dgrad(2 * Cin, 2 * self.filters):
+                ctx.pre_applied.add(node.fuse_prev)
+            else:
+                prev = None
+            dx = ops.conv1d_dgrad(dy, ops.conv1d_transpose_w(wf), xf.shape[1], self.sh, pl, prev)
             return dx.reshape(xf.shape[0], xf.shape[1], 2, Cin)
         return None
 
@@ -305,6 +331,8 @@ class Dropout(Layer):
 
 
 class Reshape(Layer):
+    shape_only = True
+
     def __init__(self, target_shape, **kw):
         Layer.__init__(self, **kw)
         self.target_shape = tuple(int(v) for v in target_shape)
@@ -322,6 +350,7 @@ class Reshape(Layer):
 
 
 class Flatten(Layer):
+    shape_only = True
     """Row-major flatten of channels-last activations: feature index = t*C + c (keras order, SURVEY Appendix B.7)."""
 
     def compute_output_shape(self, input_shape):

@@ -92,13 +92,25 @@ def conv1d_transpose_w(w):
     return wt
 
 
-def conv1d_dgrad(dy, wt, L, stride, pad_left):
+def conv1d_dgrad(dy, wt, L, stride, pad_left, prev=None):
+    """prev = (y_prev, act, act_param, mask_prev, rate): fuse the producer layer's activation/dropout backward into the epilogue."""
     _chk(dy, wt)
     B, Lout, Cout = dy.shape
     k, _, Cin = wt.shape
     dx = torch.empty((B, L, Cin), dtype=torch.float32, device=dy.device)
-    _lib.call('gn_conv1d_dgrad', _p(dy), _p(wt), _p(dx), B, L, Cin, Cout, k, stride, pad_left, Lout, _stream())
+    if prev is None:
+        _lib.call('gn_conv1d_dgrad', _p(dy), _p(wt), _p(dx), B, L, Cin, Cout, k, stride, pad_left, Lout, _stream())
+    else:
+        y_prev, act, param, mask, rate = prev
+        _chk(y_prev, mask)
+        assert y_prev.numel() == dx.numel()
+        _lib.call('gn_conv1d_dgrad_fused', _p(dy), _p(wt), _p(dx), B, L, Cin, Cout, k, stride, pad_left, Lout, _p(y_prev), _p(mask), ACT[act], float(param),
+                  float(rate), _stream())
     return dx
+
+
+def can_fuse_dgrad(Cin, Cout):
+    return Cin > 4 and Cout > 4
 
 
 def conv1d_wgrad(x, dy, k, stride, pad_left, dw=None, db=None):
@@ -145,11 +157,20 @@ def dense_fwd(x, w, b, act='linear', act_param=0.0):
     return y
 
 
-def dense_bwd(x, w, dy, need_dx=True, dw=None, db=None):
+def dense_bwd(x, w, dy, need_dx=True, dw=None, db=None, prev=None):
     _chk(x, w, dy, dw, db)
     B, n_in = x.shape
     n_out = w.shape[1]
     dx = torch.empty_like(x) if need_dx else None
+    if prev is not None:
+        _, act, param, mask, rate = prev
+        assert need_dx and n_out <= 4
+        if dw is None:
+            dw = torch.empty_like(w)
+        if db is None:
+            db = torch.empty((n_out,), dtype=torch.float32, device=x.device)
+        _lib.call('gn_dense_bwd_fused', _p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), B, n_in, n_out, _p(mask), ACT[act], float(param), float(rate), _stream())
+        return dx, dw, db
     if dw is None:
         dw = torch.empty_like(w)
     if db is None:

@@ -59,6 +59,13 @@ int gn_conv1d_transpose_w(const float* w, float* wt, int k, int Cin, int Cout, v
 int gn_conv1d_dgrad(const float* dy, const float* wt, float* dx,
                     int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout, void* stream);
 
+/* Same, with the backward of the PRODUCER layer's [activation -> dropout] fused into the epilogue, so the gradient leaves the kernel
+ * already multiplied by act'(.): dx = mask_prev ? dx/(1-rate) * act'(y_prev*(1-rate)) : 0 (mask_prev NULL: dx *= act'(y_prev)).
+ * y_prev (B, L, Cin) is the producer's output (= this layer's input).  MFMA path only (Cin > 4 and Cout > 4). */
+int gn_conv1d_dgrad_fused(const float* dy, const float* wt, float* dx,
+                          int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout,
+                          const float* y_prev, const uint8_t* mask_prev, int act_prev, float act_param_prev, float rate_prev, void* stream);
+
 /* dw[k,ci,co] = sum_{b,t} x[b, stride*t + k - pad_left, ci] * dy[b,t,co];  db[co] = sum_{b,t} dy[b,t,co] (db may be NULL).
  * ws: workspace of at least gn_conv1d_wgrad_workspace(...) bytes (split-K partial slabs, summed in a fixed order,
  * so the result is bitwise reproducible).  (TF Conv2DBackpropFilter + BiasAddGrad.) */
@@ -81,6 +88,10 @@ int gn_dense_fwd(const float* x, const float* w, const float* bias, float* y, in
 size_t gn_dense_bwd_workspace(int B, int in, int out);
 int gn_dense_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
                  void* ws, size_t ws_bytes, int B, int in, int out, void* stream);
+
+/* flatten -> Dense(out <= 4) backward with the producer's [activation -> dropout] backward fused (x IS the producer's output) */
+int gn_dense_bwd_fused(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int in, int out,
+                       const uint8_t* mask_prev, int act_prev, float act_param_prev, float rate_prev, void* stream);
 
 /* ---- elementwise ----------------------------------------------------------------------------------------- */
 /* y = act(x) (Activation / LeakyReLU / ReLU layers when not fused into the producing kernel) */
