@@ -265,6 +265,195 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_kernel(Co
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// All-DMA variant for tiles without ragged channel edges (Cin % KC == 0, Cout % TN == 0): BOTH operands go global -> LDS by
+// LDS-DMA, no staging registers, no ds_write, no per-item validity logic.
+//   * weights: global_load_lds_dwordx4, LDS image [tap][KC][TN] is lane-linear per wave;
+//   * input slab: buffer_load_dwordx4 ... lds through a per-batch-element buffer descriptor whose range check returns 0 for rows
+//     outside [0, Lin) -- the zero padding of the convolution comes from the hardware bounds check.  Rows are UNPADDED (KC floats):
+//     the A-operand ds_read_b32 is then 4-way bank-conflicted (stride 8 words), 16 LDS cycles per MFMA group per wave, which the
+//     64-cycle fp32 MFMAs hide (LDS < 35 % busy at 3 blocks/CU).
+// Same tile, same one-barrier double-stage pipeline, same epilogue as conv_mfma_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KC, int NTAPS>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_dma_kernel(ConvArgs a, int m_tiles, int n_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor type does not exist in the host pass (the stub needs no body)
+  constexpr int TM = WAVES_M * WM * 32;
+  constexpr int TN = WAVES_N * WN * 32;
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int bid = blockIdx.x;
+  const int n_tile = bid % n_tiles;
+  const int rest = bid / n_tiles;
+  const int m_tile = rest % m_tiles;
+  const int b = rest / m_tiles;
+  const int m0 = m_tile * TM, n0 = n_tile * TN;
+
+  const int is = a.t.in_stride;
+  int minoff = a.t.off[0], maxoff = a.t.off[0];
+#pragma unroll
+  for (int j = 1; j < NTAPS; ++j) {
+    minoff = min(minoff, a.t.off[j]);
+    maxoff = max(maxoff, a.t.off[j]);
+  }
+  const int R = is * (TM - 1) + (maxoff - minoff) + 1;
+  const int Rper = (R + is - 1) / is;
+  const int slab_floats = is * Rper * KC;
+  const int buf_floats = slab_floats + NTAPS * KC * TN;
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const int t_base = is * m0 + minoff;
+  const float* xb = a.x + (size_t)b * a.Lin * a.Cin;
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, a.Lin * a.Cin * 4, 0x00020000);
+
+  constexpr int S_ITEMS = ((2 * (TM - 1) + 6) * (KC / 4) + NT - 1) / NT;
+  constexpr int W_ITEMS = (NTAPS * KC * (TN / 4)) / NT;
+  const int s_count = is * Rper * (KC / 4);              // granules of one slab stage, in LDS order
+  int soff[S_ITEMS];                                      // byte offset of the item's source inside the batch element (chunk 0)
+#pragma unroll
+  for (int it = 0; it < S_ITEMS; ++it) {
+    const int id = tid + it * NT;
+    const int lr = id / (KC / 4), c4 = id % (KC / 4);
+    const int r = (is == 1) ? lr : (lr < Rper ? 2 * lr : 2 * (lr - Rper) + 1);
+    soff[it] = (id < s_count && r < R) ? ((t_base + r) * a.Cin + 4 * c4) * 4 : 0x40000000;   // out of range -> the descriptor returns 0
+  }
+  const float* wp[W_ITEMS];
+#pragma unroll
+  for (int it = 0; it < W_ITEMS; ++it) {
+    const int id = tid + it * NT;
+    const int n4 = id % (TN / 4);
+    const int kk = (id / (TN / 4)) % KC;
+    const int j = id / ((TN / 4) * KC);
+    wp[it] = a.w + ((size_t)a.t.widx[j] * a.Cin + kk) * a.Cout + n0 + 4 * n4;
+  }
+  auto dma_chunk = [&](int c0, float* stage) {
+#pragma unroll
+    for (int it = 0; it < S_ITEMS; ++it) {
+      if (tid + it * NT < s_count)                        // lanes past the slab end stay masked off (EXEC): they would land in the weight tile
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stage + (it * NT + (tid & ~63)) * 4), 16, soff[it] + c0 * 4, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < W_ITEMS; ++it)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wp[it] + (size_t)c0 * a.Cout), (lptr_t)(stage + slab_floats + (it * NT + (tid & ~63)) * 4), 16, 0, 0);
+  };
+
+  const int n_chunks = a.Cin / KC;
+  dma_chunk(0, smem);
+  __syncthreads();                                         // drains the LDS-DMA (vmcnt(0)) in front of the barrier
+
+  constexpr int SLOTS = NTAPS * (KC / 2);
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const float* slab = smem + (ch & 1) * buf_floats;
+    const float* wl = slab + slab_floats;
+    dma_chunk(min(ch + 1, n_chunks - 1) * KC, smem + ((ch + 1) & 1) * buf_floats);   // chunk ch+1 flies during this chunk's MFMAs
+
+    auto read_ops = [&](int g, float (&av)[WM], float (&bv)[WN]) {
+      const int j = g / (KC / 2), q = g % (KC / 2);
+      const int d = a.t.off[j] - minoff;
+      const int rowbase = (is == 1) ? d : ((d & 1) * Rper + (d >> 1));
+      const float* ap = slab + (rowbase + wm * WM * 32 + i32) * KC + h;
+      const float* bp = wl + (j * KC + h) * TN + wn * WN * 32 + i32;
+#pragma unroll
+      for (int mt = 0; mt < WM; ++mt) av[mt] = ap[mt * 32 * KC + 2 * q];
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) bv[nt] = bp[2 * q * TN + nt * 32];
+    };
+    float av0[WM], bv0[WN], av1[WM], bv1[WN];
+    read_ops(0, av0, bv0);
+#pragma unroll
+    for (int g = 0; g < SLOTS; ++g) {
+      if (g % 2 == 0) {
+        if (g + 1 < SLOTS) read_ops(g + 1, av1, bv1);
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[mt], bv0[nt], acc[mt][nt], 0, 0, 0);
+      } else {
+        if (g + 1 < SLOTS) read_ops(g + 1, av0, bv0);
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[mt], bv1[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  float* yb = a.y + (size_t)b * a.Ly * a.Cout;
+  const uint8_t* mb = a.mask ? a.mask + (size_t)b * a.Ly * a.Cout : nullptr;
+  const float* gyb = a.gy ? a.gy + (size_t)b * a.Ly * a.Cout : nullptr;
+  const uint8_t* gmb = a.gmask ? a.gmask + (size_t)b * a.Ly * a.Cout : nullptr;
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    const int n = n0 + wn * WN * 32 + nt * 32 + i32;
+    const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = m0 + wm * WM * 32 + mt * 32 + row;
+        if (m < a.M) {
+          const size_t o = (size_t)(a.t.out_stride * m + a.t.out_off) * a.Cout + n;
+          float v = act_apply(acc[mt][nt][r] + bias, a.act, a.act_param);
+          if (mb) v = mb[o] ? v * a.keep_scale : 0.f;
+          if (gyb) {
+            const float gv = gyb[o];
+            if (gmb) v = gmb[o] ? v * a.gscale * act_grad_from_y(gv / a.gscale, a.gact, a.gparam) : 0.f;
+            else v *= act_grad_from_y(gv, a.gact, a.gparam);
+          }
+          yb[o] = v;
+        }
+      }
+    }
+  }
+#endif
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KC, int NTAPS>
+static int launch_conv_dma(const ConvArgs& a, hipStream_t s) {
+  constexpr int TM = WAVES_M * WM * 32, TN = WAVES_N * WN * 32;
+  const int is = a.t.in_stride;
+  int minoff = a.t.off[0], maxoff = a.t.off[0];
+  for (int j = 1; j < a.t.ntaps; ++j) {
+    minoff = std::min(minoff, a.t.off[j]);
+    maxoff = std::max(maxoff, a.t.off[j]);
+  }
+  const int R = is * (TM - 1) + (maxoff - minoff) + 1;
+  const int Rper = (R + is - 1) / is;
+  const size_t lds = 2 * sizeof(float) * ((size_t)is * Rper * KC + (size_t)NTAPS * KC * TN);
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_mfma_dma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+  }
+  const int m_tiles = (a.M + TM - 1) / TM, n_tiles = a.Cout / TN;
+  const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
+  if (blocks == 0 || blocks > 0x7fffffffull) {
+    set_error("conv_mfma_dma: bad grid %zu", blocks);
+    return GN_EINVAL;
+  }
+  prof_begin(s);
+  hipLaunchKernelGGL((conv_mfma_dma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles);
+  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0);
+  return check_launch("conv_mfma_dma");
+}
+
 template <int WM, int WN, int WAVES_M, int WAVES_N, int KC, int NTAPS, bool WGLDS>
 static int launch_conv_impl(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WAVES_M * WM * 32, TN = WAVES_N * WN * 32;
@@ -304,8 +493,10 @@ static int launch_conv_impl(const ConvArgs& a, hipStream_t s) {
 template <int WM, int WN, int WAVES_M, int WAVES_N, int KC, int NTAPS>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
   constexpr int TN = WAVES_N * WN * 32;
-  static const bool no_glds = getenv("GN_CONV_NOGLDS") != nullptr;      // A/B switch for benchmarking
+  static const bool no_glds = getenv("GN_CONV_NOGLDS") != nullptr;      // A/B switches for benchmarking
+  static const bool no_dma = getenv("GN_CONV_NODMA") != nullptr;
   const bool full = (a.Cout % TN == 0) && (a.Cin % KC == 0) && ((NTAPS * KC * (TN / 4)) % (64 * WAVES_M * WAVES_N) == 0) && !no_glds;
+  if (full && !no_dma && (size_t)a.Lin * a.Cin * 4 < 0x40000000ull) return launch_conv_dma<WM, WN, WAVES_M, WAVES_N, KC, NTAPS>(a, s);
   return full ? launch_conv_impl<WM, WN, WAVES_M, WAVES_N, KC, NTAPS, true>(a, s) : launch_conv_impl<WM, WN, WAVES_M, WAVES_N, KC, NTAPS, false>(a, s);
 }
 
