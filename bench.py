@@ -42,8 +42,9 @@ def pmc_traffic_per_launch():
     if not os.path.exists(path):
         return None
     ks = json.load(open(path))['kernels']
-    n = sum(v['launches'] for k, v in ks.items() if 'conv_mfma_kernel' in k)
-    b = sum(v['launches'] * v['hbm_bytes_per_launch'] for k, v in ks.items() if 'conv_mfma_kernel' in k)
+    sel = [v for k, v in ks.items() if 'conv_mfma_kernel' in k or 'conv_mfma_dma_kernel' in k]
+    n = sum(v['launches'] for v in sel)
+    b = sum(v['launches'] * v['hbm_bytes_per_launch'] for v in sel)
     return b / n if n else None
 
 
@@ -146,6 +147,17 @@ def main():
         dt = float(t.item())
     conv = ops.prof_collect(0); wgrad = ops.prof_collect(1)
 
+    # SURVEY 8d also asks for the two loops separately: timed AFTER the K steps (not part of `value`)
+    def timed(fn, reps):
+        barrier()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        return (time.perf_counter() - t) / reps
+    t_cnn = timed(lambda: bbh.pe_train_step(nets.signal_pe, bank, CNN_BATCH, rank=rank, world=world), 4)
+    t_gan = timed(lambda: bbh.gan_train_step(nets, bank, event, GAN_BATCH, rank=rank, world=world, predict_batch=GAN_BATCH), 2)
+
     if rank == 0:
         value = world * WAVES * args.steps / dt
         ach = conv['flop'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
@@ -157,16 +169,20 @@ def main():
                                    '(G.predict, D step on 2B, G step through frozen D); n_pix=2048; %d-row synthetic template bank in HBM' % bank_n,
                        'n_pix': N_PIX, 'cnn_batch': CNN_BATCH, 'gan_batch': GAN_BATCH, 'waveforms_per_step_per_gpu': WAVES,
                        'parallelism': 'dp%d' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (implicit-GEMM Conv1D forward + data gradient, v_mfma_f32_32x32x2_f32)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_dma_kernel + conv_mfma_kernel (implicit-GEMM Conv1D forward + data gradient, v_mfma_f32_32x32x2_f32; the DMA variant runs every tile without ragged channel edges)',
                          'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic_per_launch(),
                          'traffic_note': 'fabric-side bytes per conv_mfma_kernel launch (2*FETCH_SIZE + WRITE_SIZE KiB, gfx950 FETCH correction) '
                                          'from the separate PMC passes of this command summarised in profiles/r01_pmc_traffic.json',
                          'launches': conv['launches'], 'avg_launch_ms': conv['ms'] / max(conv['launches'], 1),
                          'algorithmic_flop_per_launch': conv['flop'] / max(conv['launches'], 1),
+                         'algorithmic_bytes_per_launch': conv['bytes'] / max(conv['launches'], 1),
                          'wgrad_mfma_kernel': {'achieved': wgrad['flop'] / (wgrad['ms'] * 1e-3) / 1e12 if wgrad['ms'] > 0 else 0.0,
                                                'launches': wgrad['launches'], 'avg_launch_ms': wgrad['ms'] / max(wgrad['launches'], 1)},
                          'mfma_kernel_time_share': (conv['ms'] + wgrad['ms']) * 1e-3 / dt,
                          'step_algorithmic_tflops': world * WAVES * args.steps * (GFLOP_PER_WAVE_CNN + GFLOP_PER_WAVE_GAN) * 1e-3 / dt},
+            'breakdown': {'cnn_train_waveforms_per_s': world * CNN_BATCH / t_cnn, 'gan_iteration_waveforms_per_s': world * GAN_BATCH / t_gan,
+                          'cnn_ms_per_batch': 1e3 * t_cnn, 'gan_ms_per_iteration': 1e3 * t_gan,
+                          'note': 'rank-0 clock, measured after the timed steps; value = B / (t_CNN + t_GAN) comes from the K timed steps only'},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

@@ -30,6 +30,7 @@ struct ProfRec {
   hipEvent_t a, b;
   double flop;
   int kind;
+  double bytes;
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -54,12 +55,12 @@ void prof_begin(hipStream_t s) {
   (void)hipEventRecord(g_cur, s);
 }
 
-void prof_end(hipStream_t s, double flop, int kind) {
+void prof_end(hipStream_t s, double flop, int kind, double bytes) {
   if (!g_prof_on) return;
   hipEvent_t b = get_event();
   (void)hipEventRecord(b, s);
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof.push_back({g_cur, b, flop, kind});
+  g_prof.push_back({g_cur, b, flop, kind, bytes});
 }
 
 static void fwd_taps(ConvTaps* t, int k, int stride, int pad_left) {
@@ -145,7 +146,7 @@ int gn_prof_reset(void) {
 }
 int gn_prof_collect(int kind, double* out) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  double ms = 0, flop = 0, cnt = 0;
+  double ms = 0, flop = 0, cnt = 0, bytes = 0;
   for (auto& r : g_prof) {
     if (kind >= 0 && r.kind != kind) continue;
     cnt += 1;
@@ -154,10 +155,12 @@ int gn_prof_collect(int kind, double* out) {
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) { set_error("prof: elapsed failed"); return GN_ELAUNCH; }
     ms += t;
     flop += r.flop;
+    bytes += r.bytes;
   }
   out[0] = cnt;
   out[1] = ms;
   out[2] = flop;
+  out[3] = bytes;
   return GN_OK;
 }
 

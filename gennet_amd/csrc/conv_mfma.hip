@@ -450,7 +450,7 @@ static int launch_conv_dma(const ConvArgs& a, hipStream_t s) {
   }
   prof_begin(s);
   hipLaunchKernelGGL((conv_mfma_dma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles);
-  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0);
+  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0, 4.0 * ((double)a.B * a.Lin * a.Cin + (double)a.t.ntaps * a.Cin * a.Cout + (double)a.B * a.M * a.Cout));
   return check_launch("conv_mfma_dma");
 }
 
@@ -486,7 +486,7 @@ static int launch_conv_impl(const ConvArgs& a, hipStream_t s) {
   }
   prof_begin(s);
   hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS, WGLDS>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles);
-  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0);
+  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0, 4.0 * ((double)a.B * a.Lin * a.Cin + (double)a.t.ntaps * a.Cin * a.Cout + (double)a.B * a.M * a.Cout));
   return check_launch("conv_mfma");
 }
 

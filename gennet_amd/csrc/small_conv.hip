@@ -132,6 +132,51 @@ __global__ __launch_bounds__(256) void conv_smallcout_kernel(ConvArgs a) {
   }
 }
 
+// Cout == 1, unit strides, contiguous taps (the generator's output conv, bbhMahoGANy.py:292): one wave owns a RUN of ROWS
+// consecutive output rows, reads each of the ROWS + NTAPS - 1 input rows it needs ONCE (the kernel above re-reads every row
+// NTAPS times through L1/L2) and scatters the per-tap partial dot products into ROWS lane-private accumulators.
+template <int NTAPS, int ROWS>
+__global__ __launch_bounds__(256) void conv_cout1_rows_kernel(ConvArgs a, int runs_per_b) {
+  const int lane = threadIdx.x & 63;
+  const size_t run = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (run >= (size_t)a.B * runs_per_b) return;
+  const int b = (int)(run / runs_per_b), m0 = (int)(run % runs_per_b) * ROWS;
+  const float* xb = a.x + (size_t)b * a.Lin * a.Cin;
+  const int t0 = m0 + a.t.off[0];
+  float acc[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+  for (int c = 4 * lane; c < a.Cin; c += 256) {
+    float4 wv[NTAPS];
+#pragma unroll
+    for (int j = 0; j < NTAPS; ++j) wv[j] = *reinterpret_cast<const float4*>(a.w + (size_t)a.t.widx[j] * a.Cin + c);
+#pragma unroll
+    for (int tl = 0; tl < ROWS + NTAPS - 1; ++tl) {
+      const int t = t0 + tl;
+      float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t >= 0 && t < a.Lin) xv = *reinterpret_cast<const float4*>(xb + (size_t)t * a.Cin + c);
+#pragma unroll
+      for (int j = 0; j < NTAPS; ++j) {
+        const int r = tl - j;                      // output row (local) that tap j of input row tl feeds
+        if (r >= 0 && r < ROWS) {
+          acc[r] = fmaf(xv.x, wv[j].x, acc[r]); acc[r] = fmaf(xv.y, wv[j].y, acc[r]);
+          acc[r] = fmaf(xv.z, wv[j].z, acc[r]); acc[r] = fmaf(xv.w, wv[j].w, acc[r]);
+        }
+      }
+    }
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    float v = acc[r];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
+    if (lane == r) mine = v;
+  }
+  if (lane < ROWS && m0 + lane < a.M)
+    a.y[(size_t)b * a.Ly + (size_t)(m0 + lane + a.t.out_off)] = act_apply(mine + (a.bias ? a.bias[0] : 0.f), a.act, a.act_param);
+}
+
 int conv_smallcout_dispatch(const ConvArgs& a, hipStream_t s) {
   if (a.Cout < 1 || a.Cout > 4 || a.Cin % 4) {
     set_error("conv_smallcout: Cout %d (1..4) / Cin %d (%%4) unsupported", a.Cout, a.Cin);
@@ -139,6 +184,14 @@ int conv_smallcout_dispatch(const ConvArgs& a, hipStream_t s) {
   }
   const size_t rows = (size_t)a.B * a.M;
   if (rows == 0) return GN_OK;
+  bool contiguous = a.t.in_stride == 1 && a.t.out_stride == 1 && a.t.ntaps == 5;
+  for (int j = 1; j < a.t.ntaps; ++j) contiguous = contiguous && a.t.off[j] == a.t.off[0] + j;
+  if (a.Cout == 1 && contiguous && a.Cin >= 256) {
+    constexpr int ROWS = 16;
+    const int runs_per_b = cdiv(a.M, ROWS);
+    hipLaunchKernelGGL((conv_cout1_rows_kernel<5, ROWS>), dim3(cdiv((size_t)a.B * runs_per_b, 4)), dim3(256), 0, s, a, runs_per_b);
+    return check_launch("conv_cout1_rows");
+  }
   const unsigned grid = cdiv(rows, 4);
   switch (a.Cout) {
     case 1: hipLaunchKernelGGL(conv_smallcout_kernel<1>, dim3(grid), dim3(256), 0, s, a); break;
@@ -242,6 +295,77 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradSmallArgs a) {
   }
 }
 
+// Small Cout, unit input stride: the same partial sums with the loop turned over INPUT rows, so every x row is loaded once
+// (the loop above loads it ntaps times) and the ntaps dy scalars it meets are L2-resident broadcasts; U rows in flight per
+// thread.  Chunks are ranges of flattened input rows (b, t); the partial-slab layout and the final reduce are unchanged.
+template <int CS>
+__global__ __launch_bounds__(256) void wgrad_smallcout_s1_kernel(WgradSmallArgs a) {
+  constexpr int MAXT = 5, U = 4;
+  const int NQ = a.Cin >> 2;
+  const int NQc = NQ < 256 ? NQ : 256;
+  const int RL = 256 / NQc;
+  const int tid = threadIdx.x;
+  const int ql = tid % NQc, rl = tid / NQc;
+  const int q = blockIdx.x * NQc + ql;
+  const bool active = (rl < RL) && (q < NQ);
+  float4 acc[MAXT][CS];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+    for (int c = 0; c < CS; ++c) acc[j][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t rows = (size_t)a.B * a.Lin;
+  const size_t r_lo = (size_t)blockIdx.y * a.rows_per_chunk;
+  const size_t r_hi = r_lo + a.rows_per_chunk < rows ? r_lo + a.rows_per_chunk : rows;
+  if (active) {
+    for (size_t r0 = r_lo + rl; r0 < r_hi; r0 += (size_t)RL * U) {
+      float4 xv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t r = r0 + (size_t)u * RL;
+        xv[u] = r < r_hi ? *reinterpret_cast<const float4*>(a.x + r * a.Cin + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t r = r0 + (size_t)u * RL;
+        if (r >= r_hi) break;
+        const int b = (int)(r / a.Lin), t = (int)(r % a.Lin);
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) {
+          if (j >= a.ntaps) break;
+          const int m = t - a.off[j];
+          if (m < 0 || m >= a.M) continue;
+#pragma unroll
+          for (int c = 0; c < CS; ++c) {
+            const float g = a.dy[((size_t)b * a.M + m) * CS + c];
+            acc[j][c].x = fmaf(xv[u].x, g, acc[j][c].x); acc[j][c].y = fmaf(xv[u].y, g, acc[j][c].y);
+            acc[j][c].z = fmaf(xv[u].z, g, acc[j][c].z); acc[j][c].w = fmaf(xv[u].w, g, acc[j][c].w);
+          }
+        }
+      }
+    }
+  }
+  __shared__ float4 red[256];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    if (j >= a.ntaps) break;
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+      red[tid] = acc[j][c];
+      __syncthreads();
+      if (rl == 0 && q < NQ) {
+        float4 s = red[ql];
+        for (int k = 1; k < RL; ++k) {
+          const float4 v = red[k * NQc + ql];
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float* d = a.part + (size_t)blockIdx.y * a.ntaps * a.Cin * a.Cout + ((size_t)j * a.Cin + 4 * q) * CS + c;   // dw[j][cin][cout]
+        d[0] = s.x; d[CS] = s.y; d[2 * CS] = s.z; d[3 * CS] = s.w;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 static int wgrad_small_chunks(size_t rows, int CL) {
   const int NQ = CL / 4, NQc = NQ < 256 ? NQ : 256, RL = 256 / NQc;
   const int gx = (NQ + NQc - 1) / NQc;
@@ -281,6 +405,20 @@ int wgrad_small_dispatch(WgradSmallArgs a, float* dw, size_t ws_bytes, hipStream
   a.rows_per_chunk = (int)((rows + chunks - 1) / chunks);
   const int NQ = CL / 4, NQc = NQ < 256 ? NQ : 256;
   dim3 grid((NQ + NQc - 1) / NQc, chunks);
+  if (!small_in && a.in_stride == 1) {   // every x row loaded once
+    a.rows_per_chunk = (int)(((size_t)a.B * a.Lin + chunks - 1) / chunks);
+    switch (CS) {
+      case 1: hipLaunchKernelGGL(wgrad_smallcout_s1_kernel<1>, grid, dim3(256), 0, s, a); break;
+      case 2: hipLaunchKernelGGL(wgrad_smallcout_s1_kernel<2>, grid, dim3(256), 0, s, a); break;
+      case 3: hipLaunchKernelGGL(wgrad_smallcout_s1_kernel<3>, grid, dim3(256), 0, s, a); break;
+      default: hipLaunchKernelGGL(wgrad_smallcout_s1_kernel<4>, grid, dim3(256), 0, s, a); break;
+    }
+    int rc1 = check_launch("wgrad_smallcout_s1");
+    if (rc1) return rc1;
+    const size_t n1 = (size_t)a.ntaps * a.Cin * a.Cout;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n1, 256)), dim3(256), 0, s, a.part, dw, n1, chunks);
+    return check_launch("wgrad_small_reduce");
+  }
 #define GN_WS(CSV)                                                                                            \
   if (small_in) hipLaunchKernelGGL((wgrad_small_kernel<CSV, true>), grid, dim3(256), 0, s, a);                \
   else hipLaunchKernelGGL((wgrad_small_kernel<CSV, false>), grid, dim3(256), 0, s, a);

@@ -360,6 +360,6 @@ def prof_reset():
 def prof_collect(kind=-1):
     """kind 0: conv_mfma_kernel (forward + data gradient), 1: wgrad_mfma_kernel, -1: both."""
     import ctypes
-    out = (ctypes.c_double * 3)()
+    out = (ctypes.c_double * 4)()
     _lib.call('gn_prof_collect', int(kind), ctypes.cast(out, ctypes.c_void_p))
-    return {'launches': int(out[0]), 'ms': out[1], 'flop': out[2]}
+    return {'launches': int(out[0]), 'ms': out[1], 'flop': out[2], 'bytes': out[3]}

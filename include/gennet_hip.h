@@ -164,8 +164,9 @@ int gn_adam_step(float* p, const float* g, float* m, float* v, size_t n, float l
 int gn_prof_enable(int on);
 int gn_prof_reset(void);
 /* sums over launches since reset of one kernel family (kind 0 = conv_mfma_kernel: forward + data gradient,
- * 1 = wgrad_mfma_kernel, -1 = both): out[0] = launches, out[1] = total ms, out[2] = total algorithmic FLOP */
-int gn_prof_collect(int kind, double* out3_host);
+ * 1 = wgrad_mfma_kernel, -1 = both): out[0] = launches, out[1] = total ms, out[2] = total algorithmic FLOP,
+ * out[3] = total algorithmic bytes (each operand read once, the result written once) */
+int gn_prof_collect(int kind, double* out4_host);
 
 /* ---- template synthesiser (gw_template_maker.py) --------------------------------------------------------- */
 /* Closed-form frequency-domain IMR chirp (this library's own model, NOT LAL IMRPhenomPv2; replaces the call at

@@ -49,6 +49,8 @@ CONV_CASES = [
     (3, 50, 2, 512, 5, 2, 'same'),        # folded discriminator first layer
     (2, 64, 256, 1, 5, 1, 'same'),        # small-Cout (generator output conv)
     (2, 64, 128, 2, 5, 2, 'same'),
+    (3, 70, 512, 1, 5, 1, 'valid'),       # Cout = 1 row-run kernel, ragged run, two channel passes
+    (2, 61, 128, 3, 5, 1, 'same'),        # small-Cout weight gradient looped over input rows
 ]
 
 
