@@ -17,6 +17,7 @@ model trains live in ONE flat fp32 buffer (plus one flat gradient buffer), so th
 and data-parallel training needs a single all-reduce per step.
 """
 import pickle
+import re
 
 import numpy as np
 import torch
@@ -200,17 +201,33 @@ class RunContext(object):
 # layers: base class + symbolic tensors
 # --------------------------------------------------------------------------------------------------------------
 class SymTensor(object):
-    def __init__(self, shape, layer=None, inbound=()):
+    def __init__(self, shape, layer=None, inbound=(), name=None):
         self.shape = tuple(shape)          # without the batch axis
         self.layer = layer
         self.inbound = tuple(inbound)
-
-
-def Input(shape=None, name=None):
-    return SymTensor(shape)
+        self.name = name                   # only graph inputs carry a name (keras InputLayer)
 
 
 _NAME_COUNTS = {}
+
+
+def to_snake_case(name):
+    """keras.engine.base_layer._to_snake_case: Conv1D -> conv1d, BatchNormalization -> batch_normalization,
+    LeakyReLU -> leaky_re_lu, UpSampling1D -> up_sampling1d (the names keras writes into .h5 files)."""
+    intermediate = re.sub('(.)([A-Z][a-z0-9]+)', r'\1_\2', name)
+    insecure = re.sub('([a-z])([A-Z])', r'\1_\2', intermediate).lower()
+    return 'private' + insecure if insecure[0] == '_' else insecure
+
+
+def _unique_name(base):
+    _NAME_COUNTS[base] = _NAME_COUNTS.get(base, 0) + 1
+    return '%s_%d' % (base, _NAME_COUNTS[base])
+
+
+def Input(shape=None, name=None, batch_shape=None, dtype=None):
+    if shape is None and batch_shape is not None:
+        shape = tuple(batch_shape[1:])
+    return SymTensor(shape, name=name or _unique_name('input'))
 
 
 class Layer(object):
@@ -218,10 +235,8 @@ class Layer(object):
     forward(ctx, node, x) and backward(ctx, node, dy, need_dx, need_dw)."""
 
     def __init__(self, input_shape=None, name=None, trainable=True, **kwargs):
-        base = name or self.__class__.__name__.lower()
         if name is None:
-            _NAME_COUNTS[base] = _NAME_COUNTS.get(base, 0) + 1
-            name = '%s_%d' % (base, _NAME_COUNTS[base])
+            name = _unique_name(to_snake_case(self.__class__.__name__))
         self.name = name
         self.trainable = trainable
         self.built = False
@@ -333,6 +348,25 @@ class Adam(object):
         for grp, a, b, m, v in self.state:
             ops.adam_step(grp.data[a:b], grp.grad[a:b], m, v, lr_t, self.beta_1, self.beta_2, self.epsilon)
 
+    def _moment_views(self, p):
+        for grp, a, b, m, v in self.state:
+            if grp is p.group and a <= p.offset and p.offset + p.size <= b:
+                return m[p.offset - a:p.offset - a + p.size], v[p.offset - a:p.offset - a + p.size]
+        raise KeyError('%s is not trained by this optimizer' % p.name)
+
+    def param_moments(self, params):
+        """[(m, v)] numpy arrays in the parameters' shapes (keras optimizer_weights order is decided by the caller)."""
+        out = []
+        for p in params:
+            m, v = self._moment_views(p)
+            out.append((m.cpu().numpy().reshape(p.shape), v.cpu().numpy().reshape(p.shape)))
+        return out
+
+    def set_param_moments(self, params, moments):
+        for p, (mn, vn) in zip(params, moments):
+            m, v = self._moment_views(p)
+            m.copy_(to_device(np.asarray(mn, np.float32).reshape(-1))); v.copy_(to_device(np.asarray(vn, np.float32).reshape(-1)))
+
     def get_state(self):
         return {'iterations': self.iterations, 'mv': [(m.cpu().numpy(), v.cpu().numpy()) for _, _, _, m, v in (self.state or [])],
                 'config': (self.lr, self.beta_1, self.beta_2, self.epsilon)}
@@ -379,6 +413,7 @@ class Model(Layer):
         ins = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
         outs = list(outputs) if isinstance(outputs, (list, tuple)) else [outputs]
         self.input_shapes = [t.shape for t in ins]
+        self._sym_inputs, self._sym_outputs = ins, outs        # kept for model_config / keras layer order (keras_io.py)
         index = {}
         for k, t in enumerate(ins):
             index[id(t)] = -1 - k
@@ -593,6 +628,22 @@ class Model(Layer):
             group_params(self._train_params)
             self.optimizer.bind(self._train_params)
             self._bound = True
+            pend = getattr(self, '_pending_optimizer_weights', None)
+            if pend is not None:           # optimizer_weights of a loaded .h5: [iterations, m..., v..., (vhat stubs...)]
+                self._pending_optimizer_weights = None
+                order = self._keras_train_order()
+                n = len(order)
+                if len(pend) >= 1 + 2 * n:
+                    self.optimizer.iterations = int(np.asarray(pend[0]).reshape(-1)[0])
+                    self.optimizer.set_param_moments(order, list(zip(pend[1:1 + n], pend[1 + n:1 + 2 * n])))
+
+    def _keras_train_order(self):
+        """The compiled trainable weights in keras' model.trainable_weights order (the order of optimizer_weights in .h5 files)."""
+        from . import keras_io
+        ids = set(id(p) for p in self._train_params)
+        order = [p for p in keras_io._tw(self) if id(p) in ids]
+        seen = set(id(p) for p in order)
+        return order + [p for p in self._train_params if id(p) not in seen]
 
     @property
     def metrics_names(self):
@@ -708,33 +759,46 @@ class Model(Layer):
         s = '\n'.join(lines)
         (print_fn or print)(s)
 
-    # -- persistence.  h5py is not available in this image, so the container is a pickle with the keras weight ORDER
-    #    and layouts ((k,Cin,Cout) kernels, (L,C)-major flatten); the Keras-HDF5 byte layout is SURVEY section 8f row n2.
+    # -- persistence: Keras' HDF5 layout through gennet_amd/keras_io.py + h5lite.py (bbhMahoGANy.py:1135-1142, :1171-1173, :1372-1375)
     def save_weights(self, filepath, overwrite=True):
         import os
+        from . import keras_io
         if os.path.exists(filepath) and not overwrite:
             raise IOError('%s exists' % filepath)
-        with open(filepath, 'wb') as f:
-            pickle.dump({'format': 'gennet_amd-weights-1', 'names': [p.name for p in self.weights], 'weights': self.get_weights()}, f, protocol=2)
+        keras_io.save_weights(self, filepath)
 
-    def load_weights(self, filepath):
-        with open(filepath, 'rb') as f:
-            blob = pickle.load(f)
-        self.set_weights(blob['weights'])
+    def load_weights(self, filepath, by_name=False):
+        from . import keras_io
+        if by_name:
+            raise NotImplementedError('load_weights(by_name=True)')
+        if not keras_io.is_hdf5(filepath):     # container written by the first builds of this package
+            with open(filepath, 'rb') as f:
+                blob = pickle.load(f)
+            self.set_weights(blob['weights'])
+            return
+        keras_io.load_weights(self, filepath)
 
-    def save(self, filepath, overwrite=True):
+    def save(self, filepath, overwrite=True, include_optimizer=True):
         import os
+        from . import keras_io
         if os.path.exists(filepath) and not overwrite:
             raise IOError('%s exists' % filepath)
-        blob = {'format': 'gennet_amd-model-1', 'config': getattr(self, '_config', None), 'weights': self.get_weights(),
-                'loss': self.loss, 'metrics': self.metrics, 'optimizer': self.optimizer.get_state() if self.optimizer and self.optimizer.state is not None else None}
-        with open(filepath, 'wb') as f:
-            pickle.dump(blob, f, protocol=2)
+        keras_io.save_model(self, filepath, include_optimizer)
+
+    def get_config(self):
+        from . import keras_io
+        return keras_io.model_config(self)['config']
+
+    def to_json(self):
+        import json
+        from . import keras_io
+        return json.dumps(keras_io.model_config(self))
 
 
 class Sequential(Model):
     def __init__(self, layers=None, name=None):
         Model.__init__(self, name=name)
+        self._top = []                     # what was add()-ed, nested models unflattened: keras' `model.layers`
         for l in (layers or []):
             self.add(l)
 
@@ -754,24 +818,21 @@ class Sequential(Model):
             layer._ensure_built(prev_shape)
             out_shape = tuple(layer.compute_output_shape(prev_shape))
         idx = self._append(layer, [prev], out_shape)
+        self._top.append(layer)
         self.output_ids = [idx]
         self.built = True
         return self
 
 
-def load_model(filepath, custom_objects=None):
-    """keras.models.load_model counterpart for files written by Model.save (needs the builder config, see bbh.py)."""
-    with open(filepath, 'rb') as f:
-        blob = pickle.load(f)
-    cfg = blob.get('config')
-    if cfg is None:
-        raise ValueError('%s holds weights but no model config; rebuild the model and use load_weights' % filepath)
-    from . import bbh
-    model = bbh.model_from_config(cfg)
-    model.set_weights(blob['weights'])
-    if blob.get('loss') is not None and blob.get('optimizer') is not None:
-        lr, b1, b2, eps = blob['optimizer']['config']
-        model.compile(loss=blob['loss'], optimizer=Adam(lr=lr, beta_1=b1, beta_2=b2, epsilon=eps), metrics=blob['metrics'])
-        model._ensure_bound()
-        model.optimizer.set_state(blob['optimizer'])
-    return model
+def load_model(filepath, custom_objects=None, compile=True):
+    """keras.models.load_model: rebuilds the model from the file's model_config, loads model_weights, and (compile=True)
+    re-creates the optimizer with its iteration count and Adam moments.  Custom layers (the script's MyLayer,
+    bbhMahoGANy.py:164-188, needs its constant) come through custom_objects={'MyLayer': layer_instance | class | factory(config)}."""
+    from . import keras_io
+    return keras_io.load_model(filepath, custom_objects, compile)
+
+
+def model_from_json(text, custom_objects=None):
+    import json
+    from . import keras_io
+    return keras_io.model_from_config(json.loads(text), custom_objects)

@@ -335,10 +335,18 @@ class Reshape(Layer):
 
     def __init__(self, target_shape, **kw):
         Layer.__init__(self, **kw)
-        self.target_shape = tuple(int(v) for v in target_shape)
+        self.target_shape_arg = tuple(int(v) for v in target_shape)      # may hold one -1, as keras allows
+        self.target_shape = self.target_shape_arg
+        if list(self.target_shape_arg).count(-1) > 1:
+            raise ValueError('Reshape: at most one unknown dimension')
 
     def compute_output_shape(self, input_shape):
-        assert int(np.prod(input_shape)) == int(np.prod(self.target_shape))
+        n = int(np.prod(input_shape))
+        if -1 in self.target_shape_arg:
+            known = -int(np.prod(self.target_shape_arg))
+            assert known > 0 and n % known == 0, 'Reshape%r does not fit an input of %d elements' % (self.target_shape_arg, n)
+            self.target_shape = tuple(n // known if v == -1 else v for v in self.target_shape_arg)
+        assert n == int(np.prod(self.target_shape)), 'Reshape%r does not fit an input of %d elements' % (self.target_shape_arg, n)
         return self.target_shape
 
     def forward(self, ctx, node, x):
