@@ -179,6 +179,26 @@ int gn_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, i
   return conv_dispatch(a, (hipStream_t)stream);
 }
 
+size_t gn_conv1d_bf16x3_workspace(int B, int L, int Cin, int Cout, int k) { return conv_bf16x3_workspace_bytes(B, L, Cin, Cout, k); }
+
+int gn_conv1d_fwd_bf16x3(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B, int L, int Cin, int Cout, int k, int stride,
+                         int pad_left, int Lout, int act, float act_param, int resplit, void* stream) {
+  GN_REQUIRE(x && w && y && ws, "conv1d_fwd_bf16x3: null pointer");
+  GN_REQUIRE(B >= 0 && L > 0 && Cin > 0 && Cout > 0 && k >= 1 && k <= 5 && stride >= 1 && Lout > 0 && pad_left >= 0, "conv1d_fwd_bf16x3: bad shape");
+  if (B == 0) return GN_OK;
+  ConvArgs a = {};
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.B = B; a.Lin = L; a.Cin = Cin; a.Cout = Cout; a.M = Lout; a.Ly = Lout;
+  fwd_taps(&a.t, k, stride, pad_left);
+  a.act = act; a.act_param = act_param;
+  GN_REQUIRE(conv_bf16x3_supported(a), "conv1d_fwd_bf16x3: needs Cin %% 16 == 0, Cout %% 64 == 0, k <= 5, stride 1");
+  if (resplit) {
+    int rc = conv_bf16x3_split(a, k, ws, ws_bytes, true, true, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return conv_bf16x3_run(a, k, ws, (hipStream_t)stream);
+}
+
 int gn_conv1d_fwd_dropout(const float* x, const float* w, const float* bias, const uint8_t* mask, float* y, int B, int L, int Cin, int Cout, int k, int stride,
                           int pad_left, int Lout, int act, float act_param, float rate, void* stream) {
   GN_REQUIRE(x && w && y && mask, "conv1d_fwd_dropout: null pointer");

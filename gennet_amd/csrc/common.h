@@ -90,6 +90,11 @@ struct ColRedArgs {
 int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s);
 size_t wgrad_workspace_bytes(int B, int Cin, int Cout, int ntaps);
 int wgrad_mfma_dispatch(WgradArgs a, float* dw, size_t ws_bytes, hipStream_t s);
+// conv_bf16x3.hip (experimental bf16 x 3 operand-split convolution, opt-in)
+size_t conv_bf16x3_workspace_bytes(int B, int Lin, int Cin, int Cout, int w_taps);
+bool conv_bf16x3_supported(const ConvArgs& a);
+int conv_bf16x3_split(const ConvArgs& a, int w_taps, void* ws, size_t ws_bytes, bool split_x, bool split_w, hipStream_t s);
+int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s);
 // small_conv.hip
 int conv_smallcin_dispatch(const ConvArgs& a, hipStream_t s);
 int conv_smallcout_dispatch(const ConvArgs& a, hipStream_t s);

@@ -1,0 +1,358 @@
+// EXPERIMENTAL, opt-in (never on the default path): fp32 convolution on the bf16 matrix cores by operand splitting.
+//
+// Every fp32 operand is written as a = hi + mid + lo with three bf16 pieces (8 significant bits each; hi = bf16(a),
+// mid = bf16(a - hi), lo = bf16(a - hi - mid), the subtractions are exact in fp32), so a*b = sum of nine bf16 x bf16 products,
+// each EXACT in fp32.  The six largest (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) are accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16; the three dropped ones are <= 2^-24 |a||b| together -- the size of one fp32 rounding of the
+// product itself.  Six MFMAs at 1/16 of the cycles-per-flop of v_mfma_f32_32x32x2_f32 = 2.67x fewer matrix-core cycles.
+// Measured error against fp64 (scripts/bf16x3_check.py): equal to or below the exact-fp32 MFMA path's.
+//
+// Structure: the split is a separate elementwise pass that also BLOCKS the operands by 16-channel K chunk, in 16-byte granules
+// of 8 consecutive channels (= one lane's MFMA fragment):
+//     activations  planes[3][B][Cin/16][2][1 + L + 1][8]  (a zero guard row on either side of every run)
+//     weights      planes[3][tap][Cin/16][2][Cout][8]
+// so everything a block needs for one chunk is contiguous runs of granules: a wave's LDS-DMA instruction reads 1 KiB contiguous
+// (with channels-last planes every lane touches its own 128-byte line and the texture path, not the matrix core, sets the pace:
+// measured 139 -> 186 TFLOP/s-equivalent from this alone).  The convolution is then pure LDS-DMA + ds_read_b128 + MFMA:
+//   * 128 x 64 output tile, 4 waves (2 x 2), each wave 64 x 32 (two 32 x 32 MFMA tiles); K chunk = 16 channels = one MFMA K;
+//   * LDS image per stage: A [plane][k-half][row] and B [plane][tap][k-half][n] in 16-byte granules, so DMA writes and fragment
+//     reads are lane-linear and bank-conflict free; rows outside [0, L) are redirected to the zero guard rows;
+//   * THREE stages (3 x 48 KiB) at one block per CU: an LDS-DMA lands ~1.1 us after issue, longer than one chunk of MFMAs, so the
+//     DMA of chunk c+2 is issued during chunk c and retired by a COUNTED s_waitcnt vmcnt(N) + raw s_barrier at the end of chunk
+//     c+1 (every wave issues the same number of DMA instructions per chunk, which is what makes the count valid);
+//   * the fragment reads of tap j+1 are interleaved between the MFMAs of tap j (sched_group_barrier), the chunk's barrier sits
+//     in front of the last tap's MFMAs.
+//
+// Measured (MI355X, Conv1D(512 -> 1024, k5) on (64, 2048, 512), random data): 188-190 TFLOP/s fp32-equivalent for the
+// convolution, 183 with the split pass, against 134 for the exact-fp32 MFMA kernel (1.4x; 1.2x on 256 -> 512).  Ablations on
+// the same launch: without the fragment reads 237, without the DMA 224, with neither 266 -- the bare MFMA loop itself holds only
+// ~64 % of the nominal 2.5 PFLOP/s because the chip clocks down under dense bf16 MFMA on random data, and what remains is LDS
+// throughput: per fp32-equivalent flop this scheme moves 1.5x the LDS bytes of the fp32 kernel in 2.67x less matrix-core
+// time, ~4x its LDS load (which was 31 %); the 160 KiB of LDS rules out the larger wave tiles that would cut it.
+// Limits: unit input stride only (the stride-2 slab needs 5 segments per region: 3 x 60 KiB); forward / data-gradient
+// geometry only (no weight gradient); an infinite input comes out as NaN (inf * 0 in a cross term).
+#include "common.h"
+
+namespace gn {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__device__ inline void split3(float a, unsigned short& h, unsigned short& m, unsigned short& l) {
+  const __bf16 bh = (__bf16)a;
+  float r1 = a - (float)bh;
+  if (!(fabsf(a) < INFINITY)) r1 = 0.f;      // inf / nan stay in the hi piece alone
+  const __bf16 bm = (__bf16)r1;
+  const float r2 = r1 - (float)bm;
+  const __bf16 bl = (__bf16)r2;
+  h = __builtin_bit_cast(unsigned short, bh);
+  m = __builtin_bit_cast(unsigned short, bm);
+  l = __builtin_bit_cast(unsigned short, bl);
+}
+
+__device__ inline uint4 pack8(const unsigned short* p) {
+  uint4 r;
+  r.x = p[0] | ((unsigned)p[1] << 16); r.y = p[2] | ((unsigned)p[3] << 16);
+  r.z = p[4] | ((unsigned)p[5] << 16); r.w = p[6] | ((unsigned)p[7] << 16);
+  return r;
+}
+
+// x (B, L, C) fp32 -> planes[3][B][C/16][2][L + 2][8] bf16 (row 0 and row L + 1 of every run are zeros).
+// Block = 32 rows x 64 channels; thread = (row, 8-channel group): reads are 256-byte runs per row, writes 128-byte runs
+// (8 consecutive rows of one group) per plane.
+__global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ x, unsigned short* __restrict__ planes, int B, int L, int C) {
+  const int g = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c8 = blockIdx.y * 8 + g;                       // 8-channel group index = chunk * 2 + half
+  const size_t row = (size_t)blockIdx.x * 32 + rl;         // flattened (b, t)
+  if (row >= (size_t)B * L || c8 * 8 >= C) return;
+  const int b = (int)(row / L), t = (int)(row % L);
+  const float* src = x + row * C + 8 * c8;
+  const float4 v0 = reinterpret_cast<const float4*>(src)[0], v1 = reinterpret_cast<const float4*>(src)[1];
+  const float vs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+  unsigned short h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split3(vs[e], h[e], m[e], l[e]);
+  const size_t plane = (size_t)B * C * (L + 2);
+  const size_t run = ((size_t)b * (C >> 3) + c8) * (L + 2);
+  const size_t o = (run + 1 + t) * 8;
+  *reinterpret_cast<uint4*>(planes + o) = pack8(h);
+  *reinterpret_cast<uint4*>(planes + plane + o) = pack8(m);
+  *reinterpret_cast<uint4*>(planes + 2 * plane + o) = pack8(l);
+  if (t == 0 || t == L - 1) {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      if (t == 0) *reinterpret_cast<uint4*>(planes + p * plane + run * 8) = z;
+      if (t == L - 1) *reinterpret_cast<uint4*>(planes + p * plane + (run + L + 1) * 8) = z;
+    }
+  }
+}
+
+// W[tap][K][N] fp32 (the layout the fp32 conv kernels take) -> planes[3][tap][K/16][2][N][8] bf16; thread = (tap, 8-k group, n)
+__global__ __launch_bounds__(256) void split_w_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, int taps, int K, int N) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int K8 = K >> 3;
+  const size_t total = (size_t)taps * K8 * N;
+  if (i >= total) return;
+  const int n = (int)(i % N);
+  const int k8 = (int)((i / N) % K8);
+  const int tap = (int)(i / ((size_t)N * K8));
+  unsigned short h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split3(w[((size_t)tap * K + 8 * k8 + e) * N + n], h[e], m[e], l[e]);
+  const size_t plane = (size_t)taps * K * N;
+  const size_t o = (((size_t)tap * K8 + k8) * N + n) * 8;
+  *reinterpret_cast<uint4*>(planes + o) = pack8(h);
+  *reinterpret_cast<uint4*>(planes + plane + o) = pack8(m);
+  *reinterpret_cast<uint4*>(planes + 2 * plane + o) = pack8(l);
+}
+
+#define GN_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)      /* lgkmcnt(0), vmcnt / expcnt untouched */
+
+template <int NTAPS, int ASEG>   // ASEG = 64-row DMA segments of one (plane, k-half) region: 3 for stride 1, 5 for stride 2
+__global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgs a, const unsigned short* __restrict__ xs, const unsigned short* __restrict__ ws,
+                                                             size_t x_plane, size_t w_plane, int m_tiles, int n_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TM = 128, TN = 64;
+  constexpr int A_BYTES = 6 * ASEG * 1024, B_BYTES = 6 * NTAPS * 1024, STAGE = A_BYTES + B_BYTES;
+  constexpr int Q_TOTAL = 6 * ASEG + 6 * NTAPS;            // wave-level DMA instructions per chunk
+  constexpr int Q_WAVE = (Q_TOTAL + 3) / 4;                // ... per wave (the same for every wave: counted vmcnt)
+  constexpr int VMCNT_Q = 0x0F70 | (Q_WAVE & 15) | ((Q_WAVE >> 4) << 14);          // s_waitcnt vmcnt(Q_WAVE), lgkmcnt / expcnt untouched
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int bid = blockIdx.x;
+  const int n_tile = bid % n_tiles;
+  const int rest = bid / n_tiles;
+  const int m_tile = rest % m_tiles;
+  const int b = rest / m_tiles;
+  const int m0 = m_tile * TM, n0 = n_tile * TN;
+
+  const int is = a.t.in_stride;
+  int minoff = a.t.off[0], maxoff = a.t.off[0];
+#pragma unroll
+  for (int j = 1; j < NTAPS; ++j) {
+    minoff = min(minoff, a.t.off[j]);
+    maxoff = max(maxoff, a.t.off[j]);
+  }
+  const int R = is * (TM - 1) + (maxoff - minoff) + 1;
+  const int Rper = (R + is - 1) / is;
+  const int Rtot = is * Rper;
+  const int n_chunks = a.Cin >> 4;
+  const int Lg = a.Lin + 2;                                 // rows of one guarded run
+  const int t_base = is * m0 + minoff;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  // DMA instruction table of this wave: instruction q = wave + 4 i.  q < 6 ASEG: A region (plane, half), 64-row segment;
+  // else B region (plane, tap, half) = 64 columns.  Source pointers advance by a constant per chunk.
+  const unsigned short* src[Q_WAVE];
+  int dst[Q_WAVE];          // LDS byte offset inside a stage
+  size_t step[Q_WAVE];      // elements per chunk
+#pragma unroll
+  for (int i = 0; i < Q_WAVE; ++i) {
+    int q = wave + 4 * i;
+    if (q >= Q_TOTAL) q = Q_TOTAL - 1;                      // padding instruction: repeats the last one (same bytes, same place)
+    if (q < 6 * ASEG) {
+      const int ph = q / ASEG, seg = q % ASEG;
+      const int lr = seg * 64 + lane;
+      const int r = (is == 1) ? lr : (lr < Rper ? 2 * lr : 2 * (lr - Rper) + 1);
+      const int t = t_base + r;
+      const int row = (lr < Rtot && r < R && t >= 0 && t < a.Lin) ? t + 1 : 0;          // 0 = the leading zero guard row
+      src[i] = xs + (ph >> 1) * x_plane + ((((size_t)b * n_chunks) * 2 + (ph & 1)) * Lg + row) * 8;
+      dst[i] = q * 1024;
+      step[i] = (size_t)2 * Lg * 8;
+    } else {
+      const int qb = q - 6 * ASEG;
+      const int pt = qb >> 1, hh = qb & 1;
+      const int p = pt / NTAPS, tap = pt % NTAPS;
+      src[i] = ws + p * w_plane + ((((size_t)a.t.widx[tap] * n_chunks) * 2 + hh) * a.Cout + n0 + lane) * 8;
+      dst[i] = A_BYTES + qb * 1024;
+      step[i] = (size_t)2 * a.Cout * 8;
+    }
+  }
+  auto dma_one = [&](int i, int c, unsigned char* stage) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)c * step[i]), (lptr_t)(stage + dst[i]), 16, 0, 0);
+  };
+
+  auto read_tap = [&](const unsigned char* sa, int j, bf16x8 (&av)[3][2], bf16x8 (&bv)[3]) {
+    const int d = a.t.off[j] - minoff;
+    const int rowbase = (is == 1) ? d : ((d & 1) * Rper + (d >> 1));
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        av[p][mt] = *reinterpret_cast<const bf16x8*>(sa + ((p * 2 + h) * (ASEG * 64) + rowbase + wm * 64 + mt * 32 + i32) * 16);
+      bv[p] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + (((p * NTAPS + j) * 2 + h) * 64 + wn * 32 + i32) * 16);
+    }
+  };
+  auto mma_tap = [&](const bf16x8 (&av)[3][2], const bf16x8 (&bv)[3]) {
+    // smallest terms first: hi*lo, lo*hi, mid*mid, then hi*mid, mid*hi, then hi*hi
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[q]][mt], bv[PB[q]], acc[mt], 0, 0, 0);
+  };
+
+  // ---- prologue: chunks 0 and 1 in flight, chunk 0 retired
+#pragma unroll
+  for (int i = 0; i < Q_WAVE; ++i) dma_one(i, 0, smem_b);
+#pragma unroll
+  for (int i = 0; i < Q_WAVE; ++i) dma_one(i, min(1, n_chunks - 1), smem_b + STAGE);
+  __builtin_amdgcn_s_waitcnt(VMCNT_Q);                      // chunk 0 has landed (chunk 1 may still fly)
+  __builtin_amdgcn_s_barrier();
+
+  // fragment buffers: tap 0 -> [2], tap j >= 1 -> [(j - 1) & 1]
+  bf16x8 fa[3][3][2], fb[3][3];
+  read_tap(smem_b, 0, fa[2], fb[2]);
+  int s_cur = 0;                                            // stage of chunk ch; chunk ch+2 goes to (s_cur + 2) % 3
+  constexpr int DMA_TAPS = NTAPS > 1 ? NTAPS - 1 : 1;       // taps of a chunk that carry DMA issue (all but the last)
+  constexpr int DMA_PER_TAP = (Q_WAVE + DMA_TAPS - 1) / DMA_TAPS;
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const unsigned char* sa = smem_b + s_cur * STAGE;
+    const int s_nxt = s_cur == 2 ? 0 : s_cur + 1;
+    unsigned char* s_dma = smem_b + (s_nxt == 2 ? 0 : s_nxt + 1) * STAGE;
+    const int c_dma = min(ch + 2, n_chunks - 1);            // past the end: reloads the last chunk into a free stage (keeps the count)
+#pragma unroll
+    for (int j = 0; j < NTAPS; ++j) {
+      const int cur = j == 0 ? 2 : ((j - 1) & 1);
+      GN_WAIT_LGKM0();                                      // this tap's fragments are in registers
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 1 < NTAPS) {
+#pragma unroll
+        for (int i = j * DMA_PER_TAP; i < (j + 1) * DMA_PER_TAP && i < Q_WAVE; ++i) dma_one(i, c_dma, s_dma);
+        read_tap(sa, j + 1, fa[j & 1], fb[j & 1]);
+      } else {
+        if (NTAPS == 1) {
+#pragma unroll
+          for (int i = 0; i < Q_WAVE; ++i) dma_one(i, c_dma, s_dma);
+        }
+        // every read of this stage has landed; chunk ch+1 must have landed: at most this chunk's own Q_WAVE DMAs stay in flight
+        __builtin_amdgcn_s_waitcnt(VMCNT_Q);
+        __builtin_amdgcn_s_barrier();
+        if (ch + 1 < n_chunks) read_tap(smem_b + s_nxt * STAGE, 0, fa[2], fb[2]);
+      }
+      mma_tap(fa[cur], fb[cur]);
+      // 12 MFMAs with the 9 fragment reads of the next tap (and this tap's DMA issue) between them
+#pragma unroll
+      // front-loaded: the reads are out after 5 MFMAs, so 7 more MFMAs (~220 cycles) cover their latency before the next wait
+      for (int k = 0; k < 4; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        if (k < DMA_PER_TAP) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    s_cur = s_nxt;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): drain the padding DMAs before the block may end
+
+  float* yb = a.y + (size_t)b * a.Ly * a.Cout;
+  const uint8_t* mb = a.mask ? a.mask + (size_t)b * a.Ly * a.Cout : nullptr;
+  const float* gyb = a.gy ? a.gy + (size_t)b * a.Ly * a.Cout : nullptr;
+  const uint8_t* gmb = a.gmask ? a.gmask + (size_t)b * a.Ly * a.Cout : nullptr;
+  const int n = n0 + wn * 32 + i32;
+  const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int m = m0 + wm * 64 + mt * 32 + row;
+      if (m < a.M) {
+        const size_t o = (size_t)(a.t.out_stride * m + a.t.out_off) * a.Cout + n;
+        float v = act_apply(acc[mt][r] + bias, a.act, a.act_param);
+        if (mb) v = mb[o] ? v * a.keep_scale : 0.f;
+        if (gyb) {
+          const float gv = gyb[o];
+          if (gmb) v = gmb[o] ? v * a.gscale * act_grad_from_y(gv / a.gscale, a.gact, a.gparam) : 0.f;
+          else v *= act_grad_from_y(gv, a.gact, a.gparam);
+        }
+        yb[o] = v;
+      }
+    }
+  }
+#endif
+}
+
+size_t conv_bf16x3_workspace_bytes(int B, int Lin, int Cin, int Cout, int w_taps) {
+  return 6 * ((size_t)B * (Lin + 2) * Cin + (size_t)w_taps * Cin * Cout) + 256;
+}
+
+bool conv_bf16x3_supported(const ConvArgs& a) {
+  return a.Cin % 16 == 0 && a.Cout % 64 == 0 && a.t.ntaps >= 1 && a.t.ntaps <= 5 && a.t.in_stride == 1;
+}
+
+// splits: x (B, Lin, Cin) and the conv-layout weights w (w_taps, Cin, Cout) -> blocked bf16 planes in `ws`
+int conv_bf16x3_split(const ConvArgs& a, int w_taps, void* ws, size_t ws_bytes, bool split_x, bool split_w, hipStream_t s) {
+  if (ws_bytes < conv_bf16x3_workspace_bytes(a.B, a.Lin, a.Cin, a.Cout, w_taps)) {
+    set_error("conv_bf16x3: workspace too small");
+    return GN_EWORKSPACE;
+  }
+  const size_t xn = (size_t)a.B * (a.Lin + 2) * a.Cin, wn = (size_t)w_taps * a.Cin * a.Cout;
+  unsigned short* xs = (unsigned short*)ws;
+  unsigned short* wsp = xs + 3 * xn;
+  if (split_x) {
+    hipLaunchKernelGGL(split_x_kernel, dim3(cdiv((size_t)a.B * a.Lin, 32), cdiv(a.Cin, 64)), dim3(256), 0, s, a.x, xs, a.B, a.Lin, a.Cin);
+    int rc = check_launch("split_x");
+    if (rc) return rc;
+  }
+  if (split_w) {
+    hipLaunchKernelGGL(split_w_kernel, dim3(cdiv(wn / 8, 256)), dim3(256), 0, s, a.w, wsp, w_taps, a.Cin, a.Cout);
+    int rc = check_launch("split_w");
+    if (rc) return rc;
+  }
+  return GN_OK;
+}
+
+template <int NTAPS, int ASEG>
+static int launch_bf16x3(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
+  const size_t lds = 3 * ((size_t)6 * ASEG * 1024 + (size_t)6 * NTAPS * 1024);
+  if (lds > 160 * 1024) {
+    set_error("conv_bf16x3: LDS %zu", lds);
+    return GN_EINVAL;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_bf16x3_kernel<NTAPS, ASEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int m_tiles = (a.M + 127) / 128, n_tiles = a.Cout / 64;
+  const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
+  const size_t xn = (size_t)a.B * (a.Lin + 2) * a.Cin, wn = (size_t)w_taps * a.Cin * a.Cout;
+  const unsigned short* xs = (const unsigned short*)ws;
+  const unsigned short* wsp = xs + 3 * xn;
+  prof_begin(s);
+  hipLaunchKernelGGL((conv_bf16x3_kernel<NTAPS, ASEG>), dim3((unsigned)blocks), dim3(256), lds, s, a, xs, wsp, xn, wn, m_tiles, n_tiles);
+  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 2);
+  return check_launch("conv_bf16x3");
+}
+
+int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
+  if (!conv_bf16x3_supported(a)) {
+    set_error("conv_bf16x3: shape not supported (Cin %% 16, Cout %% 64, taps <= 5, unit input stride)");
+    return GN_EINVAL;
+  }
+  switch (a.t.ntaps) {
+    case 1: return launch_bf16x3<1, 3>(a, w_taps, ws, s);
+    case 2: return launch_bf16x3<2, 3>(a, w_taps, ws, s);
+    case 3: return launch_bf16x3<3, 3>(a, w_taps, ws, s);
+    case 4: return launch_bf16x3<4, 3>(a, w_taps, ws, s);
+    default: return launch_bf16x3<5, 3>(a, w_taps, ws, s);
+  }
+}
+
+}  // namespace gn

@@ -65,6 +65,25 @@ def conv1d_fwd(x, w, b, stride, pad_left, Lout, act='linear', act_param=0.0):
     return y
 
 
+_BF16X3_WS = {}
+
+
+def conv1d_fwd_bf16x3(x, w, b, stride, pad_left, Lout, act='linear', act_param=0.0, resplit=True):
+    """EXPERIMENTAL opt-in: conv1d_fwd on the bf16 matrix cores with 3-way split fp32 operands (csrc/conv_bf16x3.hip)."""
+    _chk(x, w, b)
+    B, L, Cin = x.shape
+    k, _, Cout = w.shape
+    n = _lib.size('gn_conv1d_bf16x3_workspace', B, L, Cin, Cout, k)
+    key = (x.device, n)
+    ws = _BF16X3_WS.get(key)
+    if ws is None:
+        ws = _BF16X3_WS[key] = torch.empty(n, dtype=torch.uint8, device=x.device)
+    y = torch.empty((B, Lout, Cout), dtype=torch.float32, device=x.device)
+    _lib.call('gn_conv1d_fwd_bf16x3', _p(x), _p(w), _p(b), _p(y), _p(ws), n, B, L, Cin, Cout, k, stride, pad_left, Lout, ACT[act], float(act_param),
+              1 if resplit else 0, _stream())
+    return y
+
+
 def conv1d_fwd_dropout(x, w, b, mask, stride, pad_left, Lout, act, act_param, rate):
     """conv + activation + inverted dropout in one epilogue; mask: uint8 keep-mask with the shape of the output."""
     _chk(x, w, b, mask)

@@ -45,6 +45,15 @@ int gn_conv1d_fwd(const float* x, const float* w, const float* bias, float* y,
                   int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout,
                   int act, float act_param, void* stream);
 
+/* EXPERIMENTAL, opt-in: the same forward convolution on the bf16 matrix cores with every fp32 operand split into three bf16
+ * pieces (six v_mfma_f32_32x32x16_bf16 products, fp32 accumulation; error of the order of one fp32 rounding per product --
+ * see gennet_amd/csrc/conv_bf16x3.hip).  Needs Cin % 16 == 0, Cout % 64 == 0, k <= 5, stride 1.  `ws` holds the split
+ * operands (gn_conv1d_bf16x3_workspace bytes); resplit = 0 reuses the planes of the previous call (benchmarks only). */
+size_t gn_conv1d_bf16x3_workspace(int B, int L, int Cin, int Cout, int k);
+int gn_conv1d_fwd_bf16x3(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
+                         int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout,
+                         int act, float act_param, int resplit, void* stream);
+
 /* Same with a following Dropout fused into the epilogue (discriminator: Conv2D -> LeakyReLU -> Dropout(0.4), bbhMahoGANy.py:439-443,
  * :447-452): y = mask ? act(.)/(1-rate) : 0, mask = uint8 keep-mask of y's shape (gn_dropout_mask).  Cout > 4. */
 int gn_conv1d_fwd_dropout(const float* x, const float* w, const float* bias, const uint8_t* mask, float* y,

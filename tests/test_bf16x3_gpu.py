@@ -1,0 +1,72 @@
+"""The EXPERIMENTAL opt-in convolution on the bf16 matrix cores (csrc/conv_bf16x3.hip: every fp32 operand split into three bf16
+pieces, six MFMA products, fp32 accumulation).  It is not on the default path; what is checked here is the claim that makes it
+worth keeping: its results are fp32-grade -- within the tolerance of the exact-fp32 MFMA path's own parity test, and not
+further from the fp64 oracle than that path is."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import keras_ref as K
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, L, Cin, Cout, k, padding
+    (2, 300, 64, 128, 5, 'same'),        # zero guard rows on both sides, ragged M tile
+    (3, 277, 48, 256, 5, 'valid'),       # 3 K chunks, 4 N tiles
+    (2, 200, 32, 64, 3, 'valid'),        # 3 taps (padding DMA instructions), one N tile
+    (1, 128, 16, 64, 1, 'valid'),        # one tap, one chunk (Dense-like)
+    (2, 100, 32, 64, 2, 'valid'),        # 2 taps: 30 DMA instructions over 4 waves -> two padding instructions
+    (2, 131, 48, 128, 4, 'same'),        # 4 taps: 42 -> two padding instructions; asymmetric SAME padding
+    (1, 256, 512, 1024, 5, 'same'),      # the dominant generator layer's channels
+]
+
+
+@pytest.mark.parametrize('B,L,Cin,Cout,k,padding', CASES)
+def test_bf16x3_conv_is_fp32_grade(B, L, Cin, Cout, k, padding):
+    from gennet_amd import ops
+    rng = np.random.RandomState(B * 131 + L + Cin)
+    # wide dynamic range inside every dot product: log-normal magnitudes
+    x = (rng.randn(B, L, Cin) * np.exp(rng.randn(B, L, Cin))).astype(np.float32)
+    w = (rng.randn(k, Cin, Cout) / np.sqrt(k * Cin)).astype(np.float32)
+    b = rng.randn(Cout).astype(np.float32)
+    Lout, pl = ops.conv_geometry(L, k, 1, padding)
+    ref = K.conv1d_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), 1, padding)
+    ref = np.maximum(ref, 0.0)
+    dev = torch.device('cuda:0')
+    xt, wt, bt = (torch.tensor(v).to(dev) for v in (x, w, b))
+    y32 = ops.conv1d_fwd(xt, wt, bt, 1, pl, Lout, 'relu').cpu().numpy().astype(np.float64)
+    y3 = ops.conv1d_fwd_bf16x3(xt, wt, bt, 1, pl, Lout, 'relu').cpu().numpy().astype(np.float64)
+    scale = np.abs(ref).max()
+    e32, e3 = np.abs(y32 - ref).max() / scale, np.abs(y3 - ref).max() / scale
+    r32, r3 = np.sqrt(np.mean((y32 - ref) ** 2)) / scale, np.sqrt(np.mean((y3 - ref) ** 2)) / scale
+    assert e3 <= 2e-5, e3                                   # the tolerance of test_kernels_gpu.test_conv1d_fwd_dgrad_wgrad
+    assert e3 <= 2.0 * e32 + 1e-7, (e3, e32)                # not further from fp64 than the exact-fp32 MFMA path (measured: 0.75-1.1 x)
+    assert r3 <= 1.5 * r32 + 1e-8, (r3, r32)
+
+
+def test_bf16x3_is_non_finite_exactly_where_fp32_is():
+    """A documented difference: an infinite input comes out as NaN, not inf (its hi piece meets the zero lo piece of the other
+    operand: inf * 0).  What is kept: outputs are non-finite exactly where the fp32 path's are, and overflow of the sum is inf."""
+    from gennet_amd import ops
+    dev = torch.device('cuda:0')
+    x = torch.zeros(1, 64, 16, device=dev); w = torch.ones(1, 16, 64, device=dev); b = torch.zeros(64, device=dev)
+    x[0, 3, 2] = float('inf'); x[0, 9, 5] = float('nan'); x[0, 20, 1] = 3.0e38; x[0, 20, 2] = 3.0e38
+    y32 = ops.conv1d_fwd(x, w, b, 1, 0, 64).cpu().numpy()
+    y3 = ops.conv1d_fwd_bf16x3(x, w, b, 1, 0, 64).cpu().numpy()
+    assert np.array_equal(np.isfinite(y3), np.isfinite(y32))
+    assert np.isposinf(y32[0, 3]).all() and np.isnan(y3[0, 3]).all()
+    assert np.isnan(y3[0, 9]).all() and np.isnan(y32[0, 9]).all()
+    assert np.isposinf(y3[0, 20]).all() and np.isposinf(y32[0, 20]).all()          # overflow of the fp32 sum
+    assert (y3[0, 30] == 0).all()
+
+
+def test_bf16x3_rejects_unsupported_shapes():
+    from gennet_amd import _lib, ops
+    dev = torch.device('cuda:0')
+    x = torch.zeros(1, 64, 20, device=dev); w = torch.ones(5, 20, 64, device=dev); b = torch.zeros(64, device=dev)
+    with pytest.raises(_lib.GennetHipError):
+        ops.conv1d_fwd_bf16x3(x, w, b, 1, 2, 64)                                  # Cin % 16 != 0
+    x = torch.zeros(1, 64, 32, device=dev); w = torch.ones(5, 32, 64, device=dev)
+    with pytest.raises(_lib.GennetHipError):
+        ops.conv1d_fwd_bf16x3(x, w, b, 2, 1, 32)                                  # stride 2 is not implemented
