@@ -713,6 +713,9 @@ class Model(Layer):
         """predict() that keeps inputs and outputs in HBM (torch tensors): inference phase, chunks of batch_size."""
         xs = self._prep_inputs(x)
         B = xs[0].shape[0]
+        if B == 0:                         # nothing to run: empty outputs of the right shapes (the kernels are never launched)
+            outs = [torch.empty((0,) + tuple(self.nodes[i].out_shape), dtype=torch.float32, device=device()) for i in self.output_ids]
+            return outs if len(outs) > 1 else outs[0]
         chunks = []
         for s in range(0, B, batch_size):
             ctx = RunContext(False)
