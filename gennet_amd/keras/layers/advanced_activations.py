@@ -1,1 +1,2 @@
-from ...layers import LeakyReLU, ReLU  # noqa: F401
+from ...layers import LeakyReLU, PReLU, ReLU  # noqa: F401
+from .._unused import ThresholdedReLU  # noqa: F401

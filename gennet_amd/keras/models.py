@@ -1,1 +1,1 @@
-from ..engine import Model, Sequential, load_model  # noqa: F401
+from ..engine import Model, Sequential, load_model, model_from_json  # noqa: F401

@@ -189,6 +189,8 @@ def layer_config(layer):
         cfg.update(axis=-1, momentum=layer.momentum, epsilon=layer.epsilon, center=True, scale=True, beta_initializer=_ZEROS, gamma_initializer=_ONES,
                    moving_mean_initializer=_ZEROS, moving_variance_initializer=_ONES, beta_regularizer=None, gamma_regularizer=None,
                    beta_constraint=None, gamma_constraint=None)
+    elif isinstance(layer, L.PReLU):
+        cfg.update(alpha_initializer=_ZEROS, alpha_regularizer=None, alpha_constraint=None, shared_axes=None)
     elif isinstance(layer, L.LeakyReLU):
         cfg.update(alpha=layer.act_spec[1])
     elif isinstance(layer, L.ReLU):
@@ -273,6 +275,8 @@ def _layer_from_config(class_name, cfg, custom_objects):
                         activation=cfg.get('activation'), use_bias=cfg.get('use_bias', True), **kw)
     if class_name == 'BatchNormalization':
         return L.BatchNormalization(axis=cfg.get('axis', -1), momentum=cfg.get('momentum', 0.99), epsilon=cfg.get('epsilon', 1e-3), **kw)
+    if class_name == 'PReLU':
+        return L.PReLU(alpha_initializer=cfg.get('alpha_initializer', 'zeros'), shared_axes=cfg.get('shared_axes'), **kw)
     if class_name == 'LeakyReLU':
         return L.LeakyReLU(alpha=cfg.get('alpha', 0.3), **kw)
     if class_name == 'ReLU':

@@ -298,6 +298,33 @@ class ReLU(Activation):
         self.act_spec = ('relu', 0.0) if max_value is None else ('relu_max', float(max_value))
 
 
+class PReLU(Layer):
+    """keras.layers.PReLU() (bbhMahoGANy.py:39; the act = 'prelu' branches of generator_model, :237-286): one learnable slope per
+    feature of a sample (no shared axes), initialised to zero; y = x > 0 ? x : alpha * x."""
+
+    def __init__(self, alpha_initializer='zeros', shared_axes=None, **kw):
+        Layer.__init__(self, **kw)
+        if alpha_initializer not in ('zeros', None) and not (isinstance(alpha_initializer, dict) and alpha_initializer.get('class_name') == 'Zeros'):
+            raise NotImplementedError('PReLU(alpha_initializer=%r)' % (alpha_initializer,))
+        if shared_axes:
+            raise NotImplementedError('PReLU(shared_axes=%r)' % (shared_axes,))
+
+    def build(self, input_shape):
+        if int(np.prod(input_shape)) % 4:
+            raise NotImplementedError('PReLU on %r: the feature count must be a multiple of 4' % (tuple(input_shape),))
+        self.alpha = self.add_weight('alpha', np.zeros(tuple(input_shape), np.float32))
+
+    def forward(self, ctx, node, x):
+        x = x.contiguous()
+        ctx.tape[node.index] = x
+        return ops.prelu_fwd(x, self.alpha.data)
+
+    def backward(self, ctx, node, dy, need_dx, need_dw):
+        x = ctx.tape.pop(node.index)
+        dx, _ = ops.prelu_bwd(dy.contiguous(), x, self.alpha.data, need_dx or not need_dw, self.alpha.grad if need_dw else None)
+        return dx
+
+
 class Dropout(Layer):
     """Inverted dropout, active in the training phase only (which keras applies to the WHOLE graph in train_on_batch,
     including layers of frozen sub-models: bbhMahoGANy.py:1296 keeps D's Dropout(0.4) active during the G step)."""

@@ -221,6 +221,24 @@ def dropout_mask(shape, rate, seed, offset, device):
     return m
 
 
+def prelu_fwd(x, alpha):
+    """x (B, ...), alpha with the shape of one sample."""
+    _chk(x, alpha)
+    y = torch.empty_like(x)
+    _lib.call('gn_prelu_fwd', _p(x), _p(alpha), _p(y), x.shape[0], alpha.numel(), _stream())
+    return y
+
+
+def prelu_bwd(dy, x, alpha, need_dx=True, dalpha=None):
+    """-> (dx or None, dalpha); dalpha is written into the given tensor when there is one (the flat gradient buffer)."""
+    _chk(dy, x, alpha)
+    dx = torch.empty_like(x) if need_dx else None
+    if dalpha is None:
+        dalpha = torch.empty_like(alpha)
+    _lib.call('gn_prelu_bwd', _p(dy), _p(x), _p(alpha), _p(dx), _p(dalpha), x.shape[0], alpha.numel(), _stream())
+    return dx, dalpha
+
+
 def dropout_apply(x, mask, rate):
     _chk(x, mask)
     y = torch.empty_like(x)

@@ -109,6 +109,11 @@ int gn_act_fwd(const float* x, float* y, size_t n, int act, float act_param, voi
 int gn_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float act_param, void* stream);
 /* backward of [activation -> dropout] in one pass through the post-dropout output y: dx = mask ? dy/(1-rate) * act'(y*(1-rate)) : 0 */
 int gn_act_dropout_bwd(const float* dy, const float* y, const uint8_t* mask, float* dx, size_t n, int act, float act_param, float rate, void* stream);
+/* PReLU (bbhMahoGANy.py:39; the act = 'prelu' branches at :237-286, :315-325): y[b,f] = x > 0 ? x : alpha[f] * x with one
+ * alpha per feature of a sample (F features, F % 4 == 0).  Backward: dx = dy * (x > 0 ? 1 : x < 0 ? alpha : 0) (Keras'
+ * relu(x) - alpha * relu(-x) has zero gradient at x == 0), dalpha[f] = sum_b dy[b,f] * min(x[b,f], 0); dx or dalpha may be NULL. */
+int gn_prelu_fwd(const float* x, const float* alpha, float* y, int B, size_t F, void* stream);
+int gn_prelu_bwd(const float* dy, const float* x, const float* alpha, float* dx, float* dalpha, int B, size_t F, void* stream);
 /* Dropout (bbhMahoGANy.py:239,255,...,288 rate 0.2; :443,:452 rate 0.4): keep-mask generation (Philox4x32-10,
  * element i draws counter (offset + i/4), lane i%4; keep iff u >= rate) and application y = x*mask/(1-rate). */
 int gn_dropout_mask(uint8_t* mask, size_t n, float rate, uint64_t seed, uint64_t offset, void* stream);
