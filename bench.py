@@ -184,6 +184,13 @@ def main():
                           'cnn_ms_per_batch': 1e3 * t_cnn, 'gan_ms_per_iteration': 1e3 * t_gan,
                           'note': 'rank-0 clock, measured after the timed steps; value = B / (t_CNN + t_GAN) comes from the K timed steps only'},
         }
+        conv_math = os.environ.get('GENNET_CONV_MATH', 'fp32')
+        if conv_math != 'fp32':      # the opt-in experiment: say so in the line; never the default configuration
+            x3 = ops.prof_collect(2)
+            out['dtype'] = 'f32 operands split into 3 bf16 pieces on the large unit-stride conv launches (opt-in GENNET_CONV_MATH=%s), f32 elsewhere' % conv_math
+            out['config']['conv_math'] = conv_math
+            out['roofline']['bf16x3_launches'] = {'launches': x3['launches'], 'avg_launch_ms': x3['ms'] / max(x3['launches'], 1),
+                                                  'fp32_equivalent_tflops': x3['flop'] / (x3['ms'] * 1e-3) / 1e12 if x3['ms'] > 0 else 0.0}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -74,10 +74,34 @@ static void fwd_taps(ConvTaps* t, int k, int stride, int pad_left) {
   t->out_off = 0;
 }
 
+// Opt-in conv arithmetic (gn_set_conv_math): 0 = exact fp32 MFMA (default), 1 = bf16 x 3 operand split for the launches it
+// supports and that are large enough to gain from it; everything else stays on the fp32 kernels.
+static int g_conv_math = 0;
+static void* g_conv_ws = nullptr;
+static size_t g_conv_ws_bytes = 0;
+
 static int conv_dispatch(const ConvArgs& a, hipStream_t s) {
   if (a.Cin <= 4) return conv_smallcin_dispatch(a, s);
   if (a.Cout <= 4) return conv_smallcout_dispatch(a, s);
+  if (g_conv_math == 1 && a.Cin >= 256 && a.Cout >= 256 && conv_bf16x3_supported(a)) {
+    int w_taps = 0;
+    for (int j = 0; j < a.t.ntaps; ++j) w_taps = std::max(w_taps, a.t.widx[j] + 1);
+    if (conv_bf16x3_workspace_bytes(a.B, a.Lin, a.Cin, a.Cout, w_taps) <= g_conv_ws_bytes) {
+      int rc = conv_bf16x3_split(a, w_taps, g_conv_ws, g_conv_ws_bytes, true, true, s);
+      if (rc) return rc;
+      return conv_bf16x3_run(a, w_taps, g_conv_ws, s);
+    }
+  }
   return conv_mfma_dispatch(a, s);
+}
+
+static int set_conv_math_impl(int mode, void* workspace, size_t workspace_bytes) {
+  GN_REQUIRE(mode == 0 || mode == 1, "set_conv_math: mode %d (0 = fp32, 1 = bf16x3)", mode);
+  GN_REQUIRE(mode == 0 || workspace, "set_conv_math: bf16x3 needs a device workspace");
+  g_conv_math = mode;
+  g_conv_ws = mode ? workspace : nullptr;
+  g_conv_ws_bytes = mode ? workspace_bytes : 0;
+  return GN_OK;
 }
 
 // small C (< 4 or not a multiple of 4) column sums: fp64 block partials + fp64 atomics
@@ -178,6 +202,8 @@ int gn_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, i
   a.act = act; a.act_param = act_param;
   return conv_dispatch(a, (hipStream_t)stream);
 }
+
+int gn_set_conv_math(int mode, void* workspace, size_t workspace_bytes) { return set_conv_math_impl(mode, workspace, workspace_bytes); }
 
 size_t gn_conv1d_bf16x3_workspace(int B, int L, int Cin, int Cout, int k) { return conv_bf16x3_workspace_bytes(B, L, Cin, Cout, k); }
 

@@ -38,6 +38,8 @@ def device():
         idx = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(idx)
         _DEVICE = torch.device('cuda', idx)
+        if os.environ.get('GENNET_CONV_MATH', 'fp32') != 'fp32':       # opt-in experiment (ops.set_conv_math); default: exact fp32
+            ops.set_conv_math(os.environ['GENNET_CONV_MATH'], float(os.environ.get('GENNET_CONV_WS_GB', '7')), _DEVICE)
     return _DEVICE
 
 

@@ -221,6 +221,24 @@ def dropout_mask(shape, rate, seed, offset, device):
     return m
 
 
+_CONV_MATH_WS = [None]
+
+
+def set_conv_math(mode='fp32', workspace_gb=7.0, device=None):
+    """'fp32' (default): exact-fp32 MFMA everywhere.  'bf16x3': EXPERIMENTAL opt-in -- the large unit-stride Conv1D forward / data
+    gradient launches run on the bf16 matrix cores with 3-way split operands (csrc/conv_bf16x3.hip; fp32-grade results, see
+    tests/test_bf16x3_gpu.py).  workspace_gb must hold 6 * (B * (L + 2) * Cin + k * Cin * Cout) bytes of the largest such launch."""
+    if mode == 'fp32':
+        _lib.call('gn_set_conv_math', 0, None, 0)
+        _CONV_MATH_WS[0] = None
+        return
+    if mode != 'bf16x3':
+        raise ValueError('conv math %r (fp32 | bf16x3)' % (mode,))
+    ws = torch.empty(int(workspace_gb * (1 << 30)), dtype=torch.uint8, device=device or torch.device('cuda', torch.cuda.current_device()))
+    _lib.call('gn_set_conv_math', 1, _p(ws), ws.numel())
+    _CONV_MATH_WS[0] = ws
+
+
 def prelu_fwd(x, alpha):
     """x (B, ...), alpha with the shape of one sample."""
     _chk(x, alpha)

@@ -53,6 +53,11 @@ size_t gn_conv1d_bf16x3_workspace(int B, int L, int Cin, int Cout, int k);
 int gn_conv1d_fwd_bf16x3(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
                          int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout,
                          int act, float act_param, int resplit, void* stream);
+/* Process-wide opt-in: mode 1 routes every Conv1D forward / data-gradient launch that the bf16x3 kernel supports and that is
+ * large enough to gain from it (Cin >= 256 and Cout >= 256, unit input stride) through it, operands split per launch into the
+ * caller-owned device `workspace` (launches whose planes do not fit stay on the fp32 kernel); mode 0 (the default) restores
+ * the exact-fp32 MFMA path everywhere.  The workspace must stay alive while mode 1 is set. */
+int gn_set_conv_math(int mode, void* workspace, size_t workspace_bytes);
 
 /* Same with a following Dropout fused into the epilogue (discriminator: Conv2D -> LeakyReLU -> Dropout(0.4), bbhMahoGANy.py:439-443,
  * :447-452): y = mask ? act(.)/(1-rate) : 0, mask = uint8 keep-mask of y's shape (gn_dropout_mask).  Cout > 4. */
