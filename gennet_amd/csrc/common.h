@@ -39,7 +39,6 @@ struct ConvArgs {
   ConvTaps t;
   int act;
   float act_param;
-  int dbg;  // timing-experiment switches (GN_CONV_DBG), 0 in production
   const uint8_t* mask;  // optional dropout keep-mask, same shape as y: y = mask ? act(.) * keep_scale : 0 (fused Dropout)
   float keep_scale;
   // gradient epilogue (data-gradient launches): out *= d act(prev)/d pre-activation, expressed through the PRODUCER layer's output

@@ -501,10 +501,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
 }
 
 // Entry used by the C-ABI wrappers in capi.hip.
-int conv_mfma_dispatch(const ConvArgs& a_in, hipStream_t s) {
-  ConvArgs a = a_in;
-  static const int dbg = getenv("GN_CONV_DBG") ? atoi(getenv("GN_CONV_DBG")) : 0;   // timing experiments only (wrong results)
-  a.dbg = dbg;
+int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s) {
   if (a.Cin % 4 || a.Cout % 4) {
     set_error("conv_mfma: Cin (%d) and Cout (%d) must be multiples of 4", a.Cin, a.Cout);
     return GN_EINVAL;
