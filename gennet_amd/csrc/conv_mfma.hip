@@ -515,14 +515,15 @@ int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s) {
     return GN_EINVAL;
   }
   const bool narrow = a.Cout <= 64;   // 256 x 64 tile instead of 128 x 128
-  // K-chunk: 8 channels for 4-5 taps (2 x 30 KiB stages -> 2-3 blocks/CU); 16 for 1-3 taps, so every barrier still covers >= 32
-  // MFMAs per wave (Dense, the stride-2 data-gradient phases and any short kernel)
+  // K-chunk: 8 channels for 2-5 taps (stages of 8-25 KiB -> 3-4 blocks/CU; measured on the stride-2 data-gradient phases of 3 and
+  // 2 taps: 134 TFLOP/s against 122 with 16-channel chunks at 2 blocks/CU -- occupancy beats MFMAs-per-barrier); 16 for the
+  // single-tap Dense so that a barrier still covers 32 MFMAs per wave
 #define GN_CONV(NT_, KC_)                                                   \
   return narrow ? launch_conv<2, 2, 4, 1, KC_, NT_>(a, s) : launch_conv<2, 2, 2, 2, KC_, NT_>(a, s)
   switch (a.t.ntaps) {
     case 1: GN_CONV(1, 16);
-    case 2: GN_CONV(2, 16);
-    case 3: GN_CONV(3, 16);
+    case 2: GN_CONV(2, 8);
+    case 3: GN_CONV(3, 8);
     case 4: GN_CONV(4, 8);
     default: GN_CONV(5, 8);
   }
@@ -536,6 +537,7 @@ int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 
 template <int WAVES_C, int WAVES_N, int WNT, int NTAPS, int KT>
+// (220 registers with 5 taps = 2 blocks/CU; forcing 3 with __launch_bounds__(.., 3) spills into the loop: 131 -> 58 TFLOP/s)
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_N) void wgrad_mfma_kernel(WgradArgs a) {
   constexpr int TC = WAVES_C * 32, TN = WAVES_N * WNT * 32;   // each wave: 32 input channels x (WNT x 32) output channels x NTAPS taps
   constexpr int NT = 64 * WAVES_C * WAVES_N;
