@@ -320,7 +320,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_dma_kerne
   const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, a.Lin * a.Cin * 4, 0x00020000);
 
   constexpr int S_ITEMS = ((2 * (TM - 1) + 6) * (KC / 4) + NT - 1) / NT;
-  constexpr int W_ITEMS = (NTAPS * KC * (TN / 4)) / NT;
+  constexpr int W_TOTAL = NTAPS * KC * (TN / 4);         // weight granules of one stage (a multiple of 64: whole waves)
+  constexpr int W_ITEMS = (W_TOTAL + NT - 1) / NT;
   const int s_count = is * Rper * (KC / 4);              // granules of one slab stage, in LDS order
   int soff[S_ITEMS];                                      // byte offset of the item's source inside the batch element (chunk 0)
 #pragma unroll
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_dma_kerne
   const float* wp[W_ITEMS];
 #pragma unroll
   for (int it = 0; it < W_ITEMS; ++it) {
-    const int id = tid + it * NT;
+    const int id = min(tid + it * NT, W_TOTAL - 1);      // (the last item may cover only the first waves; the rest never issue it)
     const int n4 = id % (TN / 4);
     const int kk = (id / (TN / 4)) % KC;
     const int j = id / ((TN / 4) * KC);
@@ -347,7 +348,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_dma_kerne
     }
 #pragma unroll
     for (int it = 0; it < W_ITEMS; ++it)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wp[it] + (size_t)c0 * a.Cout), (lptr_t)(stage + slab_floats + (it * NT + (tid & ~63)) * 4), 16, 0, 0);
+      if ((it + 1) * NT <= W_TOTAL || (tid & ~63) + it * NT < W_TOTAL)      // wave-uniform: whole waves issue or skip
+        __builtin_amdgcn_global_load_lds((gptr_t)(wp[it] + (size_t)c0 * a.Cout), (lptr_t)(stage + slab_floats + (it * NT + (tid & ~63)) * 4), 16, 0, 0);
   };
 
   const int n_chunks = a.Cin / KC;
@@ -495,8 +497,10 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
   constexpr int TN = WAVES_N * WN * 32;
   static const bool no_glds = getenv("GN_CONV_NOGLDS") != nullptr;      // A/B switches for benchmarking
   static const bool no_dma = getenv("GN_CONV_NODMA") != nullptr;
-  const bool full = (a.Cout % TN == 0) && (a.Cin % KC == 0) && ((NTAPS * KC * (TN / 4)) % (64 * WAVES_M * WAVES_N) == 0) && !no_glds;
-  if (full && !no_dma && (size_t)a.Lin * a.Cin * 4 < 0x40000000ull) return launch_conv_dma<WM, WN, WAVES_M, WAVES_N, KC, NTAPS>(a, s);
+  const bool even = (a.Cout % TN == 0) && (a.Cin % KC == 0) && !no_glds;                       // no ragged channel edges
+  const bool full = even && ((NTAPS * KC * (TN / 4)) % (64 * WAVES_M * WAVES_N) == 0);       // ... and whole weight items per thread
+  if (even && (NTAPS * KC * (TN / 4)) % 64 == 0 && !no_dma && (size_t)a.Lin * a.Cin * 4 < 0x40000000ull)
+    return launch_conv_dma<WM, WN, WAVES_M, WAVES_N, KC, NTAPS>(a, s);
   return full ? launch_conv_impl<WM, WN, WAVES_M, WAVES_N, KC, NTAPS, true>(a, s) : launch_conv_impl<WM, WN, WAVES_M, WAVES_N, KC, NTAPS, false>(a, s);
 }
 
@@ -514,7 +518,14 @@ int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s) {
     set_error("conv_mfma: ntaps %d unsupported (1..5)", a.t.ntaps);
     return GN_EINVAL;
   }
-  const bool narrow = a.Cout <= 64;   // 256 x 64 tile instead of 128 x 128
+  // Tile: 256 x 64 (4 waves stacked in M) or 128 x 128 (2 x 2 waves).  The tall tile stages FEWER bytes per flop (a 10 KiB weight
+  // stage, 37 KiB of LDS per block -> 4 blocks/CU against 3; for stride 2, 3 against 2) and wins on the 4-5-tap launches whenever
+  // M fills it: measured 142 against 138 TFLOP/s on the dominant layer, 135.5 against 129.5 on the stride-2 forward; the 2-3-tap
+  // data-gradient phases (130 against 136) and short sequences (M = 125: half a tile idle) keep the square tile.
+  static const bool force_wide = getenv("GN_CONV_WIDE") != nullptr;      // A/B switch
+  auto fill = [&](int T) { return (double)a.M / ((double)((a.M + T - 1) / T) * T); };
+  const bool tall_ok = a.Cout % 64 == 0 && a.t.ntaps >= 4 && fill(256) >= 0.97 * fill(128) && !force_wide;
+  const bool narrow = a.Cout <= 64 || tall_ok;
   // K-chunk: 8 channels for 2-5 taps (stages of 8-25 KiB -> 3-4 blocks/CU; measured on the stride-2 data-gradient phases of 3 and
   // 2 taps: 134 TFLOP/s against 122 with 16-channel chunks at 2 blocks/CU -- occupancy beats MFMAs-per-barrier); 16 for the
   // single-tap Dense so that a barrier still covers 32 MFMAs per wave
