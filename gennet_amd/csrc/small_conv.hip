@@ -381,12 +381,38 @@ size_t wgrad_small_workspace_bytes(int B, int M, int Cin, int Cout, int ntaps) {
   return (size_t)wgrad_small_chunks((size_t)B * M, CL) * ntaps * Cin * Cout * sizeof(float);
 }
 
+// out[i] = sum_k part[k][i] in a FIXED order (reproducible).  n is small here (ntaps * Cin * Cout with one side <= 4) and the chunk
+// count large (up to 1024), so one thread per element would walk 1024 strided loads with 20 blocks on the chip: two levels instead.
+// Level 1 (grid.y = G groups): group g folds the chunks k = g, g + G, ... into slab g IN PLACE (no other group touches slab g);
+// level 2 sums the G slabs.
+constexpr int SUM_GROUPS = 32;
+
+__global__ void sum_partials_l1_kernel(float* __restrict__ part, size_t n, int chunks) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (i >= n || g >= chunks) return;
+  float s = part[(size_t)g * n + i];
+  for (int k = g + SUM_GROUPS; k < chunks; k += SUM_GROUPS) s += part[(size_t)k * n + i];
+  part[(size_t)g * n + i] = s;
+}
+
 __global__ void sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int chunks) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = part[i];
   for (int k = 1; k < chunks; ++k) s += part[(size_t)k * n + i];
   out[i] = s;
+}
+
+static int sum_partials(float* part, float* out, size_t n, int chunks, hipStream_t s) {
+  if (chunks > 2 * SUM_GROUPS) {
+    hipLaunchKernelGGL(sum_partials_l1_kernel, dim3(cdiv(n, 256), SUM_GROUPS), dim3(256), 0, s, part, n, chunks);
+    int rc = check_launch("sum_partials_l1");
+    if (rc) return rc;
+    chunks = SUM_GROUPS;
+  }
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, part, out, n, chunks);
+  return check_launch("wgrad_small_reduce");
 }
 
 int wgrad_small_dispatch(WgradSmallArgs a, float* dw, size_t ws_bytes, hipStream_t s) {
@@ -416,8 +442,7 @@ int wgrad_small_dispatch(WgradSmallArgs a, float* dw, size_t ws_bytes, hipStream
     int rc1 = check_launch("wgrad_smallcout_s1");
     if (rc1) return rc1;
     const size_t n1 = (size_t)a.ntaps * a.Cin * a.Cout;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n1, 256)), dim3(256), 0, s, a.part, dw, n1, chunks);
-    return check_launch("wgrad_small_reduce");
+    return sum_partials(a.part, dw, n1, chunks, s);
   }
 #define GN_WS(CSV)                                                                                            \
   if (small_in) hipLaunchKernelGGL((wgrad_small_kernel<CSV, true>), grid, dim3(256), 0, s, a);                \
@@ -432,8 +457,7 @@ int wgrad_small_dispatch(WgradSmallArgs a, float* dw, size_t ws_bytes, hipStream
   int rc = check_launch("wgrad_small");
   if (rc) return rc;
   const size_t n = (size_t)a.ntaps * a.Cin * a.Cout;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a.part, dw, n, chunks);
-  return check_launch("wgrad_small_reduce");
+  return sum_partials(a.part, dw, n, chunks, s);
 }
 
 // ---------------------------------------------------------------------------------------------
