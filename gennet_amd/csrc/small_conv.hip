@@ -416,34 +416,50 @@ __global__ __launch_bounds__(256) void wgrad_smallcout_s1_kernel(WgradSmallArgs 
   const size_t rows = (size_t)a.B * a.Lin;
   const size_t r_lo = (size_t)blockIdx.y * a.rows_per_chunk;
   const size_t r_hi = r_lo + a.rows_per_chunk < rows ? r_lo + a.rows_per_chunk : rows;
-  if (active) {
-    for (size_t r0 = r_lo + rl; r0 < r_hi; r0 += (size_t)RL * U) {
-      float4 xv[U];
+  // the dy values every (input row, tap, channel) meets go through an LDS table per TR-row tile (zeros where the tap falls outside
+  // [0, M)), so the row loop has only its U batched x loads on the vector-memory path
+  constexpr int TR = 128;
+  __shared__ float tab[TR][MAXT * CS];
+  const int per_row = a.ntaps * CS;
+  for (size_t base = r_lo; base < r_hi; base += TR) {
+    const int nr = (int)(r_hi - base < (size_t)TR ? r_hi - base : (size_t)TR);
+    __syncthreads();
+    for (int e = tid; e < nr * per_row; e += 256) {
+      const int rr = e / per_row, jc = e % per_row;
+      const int j = jc / CS, c = jc % CS;
+      const size_t r = base + rr;
+      const int b = (int)(r / a.Lin), t = (int)(r % a.Lin);
+      const int m = t - a.off[j];
+      tab[rr][j * CS + c] = (m >= 0 && m < a.M) ? a.dy[((size_t)b * a.M + m) * CS + c] : 0.f;
+    }
+    __syncthreads();
+    if (active) {
+      for (int r0 = rl; r0 < nr; r0 += RL * U) {
+        float4 xv[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const size_t r = r0 + (size_t)u * RL;
-        xv[u] = r < r_hi ? *reinterpret_cast<const float4*>(a.x + r * a.Cin + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+        for (int u = 0; u < U; ++u) {
+          const int rr = r0 + u * RL;
+          xv[u] = rr < nr ? *reinterpret_cast<const float4*>(a.x + (base + rr) * a.Cin + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const size_t r = r0 + (size_t)u * RL;
-        if (r >= r_hi) break;
-        const int b = (int)(r / a.Lin), t = (int)(r % a.Lin);
+        for (int u = 0; u < U; ++u) {
+          const int rr = r0 + u * RL;
+          if (rr >= nr) break;
 #pragma unroll
-        for (int j = 0; j < MAXT; ++j) {
-          if (j >= a.ntaps) break;
-          const int m = t - a.off[j];
-          if (m < 0 || m >= a.M) continue;
+          for (int j = 0; j < MAXT; ++j) {
+            if (j >= a.ntaps) break;
 #pragma unroll
-          for (int c = 0; c < CS; ++c) {
-            const float g = a.dy[((size_t)b * a.M + m) * CS + c];
-            acc[j][c].x = fmaf(xv[u].x, g, acc[j][c].x); acc[j][c].y = fmaf(xv[u].y, g, acc[j][c].y);
-            acc[j][c].z = fmaf(xv[u].z, g, acc[j][c].z); acc[j][c].w = fmaf(xv[u].w, g, acc[j][c].w);
+            for (int c = 0; c < CS; ++c) {
+              const float g = tab[rr][j * CS + c];
+              acc[j][c].x = fmaf(xv[u].x, g, acc[j][c].x); acc[j][c].y = fmaf(xv[u].y, g, acc[j][c].y);
+              acc[j][c].z = fmaf(xv[u].z, g, acc[j][c].z); acc[j][c].w = fmaf(xv[u].w, g, acc[j][c].w);
+            }
           }
         }
       }
     }
   }
+  __syncthreads();
   __shared__ float4 red[256];
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
