@@ -192,6 +192,7 @@ class RunContext(object):
         self.tape = {}
         self.epi = {}                      # node index -> (y, act, act_param, mask, rate): epilogue a consumer's dgrad can differentiate
         self.pre_applied = set()           # producers whose activation gradient has already been applied to their dy
+        self.skip = set()                  # inference phase: BatchNormalization nodes already folded into the producing conv
 
     def wants_grad(self, layer):
         if self.train_ids is None:
@@ -309,7 +310,7 @@ class Layer(object):
 
 
 class Node(object):
-    __slots__ = ('layer', 'inbound', 'fused_act', 'fused_drop', 'absorbed', 'index', 'out_shape', 'owners', 'fuse_prev')
+    __slots__ = ('layer', 'inbound', 'fused_act', 'fused_drop', 'absorbed', 'index', 'out_shape', 'owners', 'fuse_prev', 'infer_bn')
 
     def __init__(self, layer, inbound, out_shape, owners=()):
         self.layer = layer
@@ -537,6 +538,15 @@ class Model(Layer):
                 if c is not None and c.layer.drop_rate is not None:
                     n.fused_drop = (c.layer.drop_rate, c.layer)
                     c.absorbed = True
+        # inference-phase fusion: a BatchNormalization that is the sole consumer of a linear conv folds into that conv's weights
+        # (predict only: the training phase normalises with batch statistics)
+        for n in self.nodes:
+            n.infer_bn = None
+            if n.absorbed or not getattr(n.layer, 'can_fold_bn', False) or n.fused_act is not None or n.fused_drop is not None:
+                continue
+            c = sole_consumer(n.index)
+            if c is not None and getattr(c.layer, 'is_batchnorm', False):
+                n.infer_bn = c
         # backward fusion: node n's data gradient can carry the producer p's activation/dropout derivative in its epilogue when p's
         # output reaches n through shape-only nodes (absorbed activations, Flatten, Reshape) and nothing else consumes it
         for n in self.nodes:

@@ -120,9 +120,23 @@ class Conv1D(Layer):
     def compute_output_shape(self, input_shape):
         return (ops.conv_geometry(input_shape[0], self.k, self.stride, self.padding)[0], self.filters)
 
+    @property
+    def can_fold_bn(self):
+        return self.activation[0] == 'linear' and self.filters % 4 == 0 and self.filters > 4
+
     def forward(self, ctx, node, x):
         a = node.fused_act or self.activation
         Lout, pl = ops.conv_geometry(x.shape[1], self.k, self.stride, self.padding)
+        bn_node = getattr(node, 'infer_bn', None)
+        if not ctx.training and bn_node is not None and x.shape[2] > 4:
+            # inference phase: the following BatchNormalization (moving statistics) folds into the weights, its activation into the
+            # epilogue: one kernel, and the pre-BN tensor is never written (generator.predict, bbhMahoGANy.py:1248)
+            bn = bn_node.layer
+            scale, shift = ops.bn_infer_coeffs(bn.gamma.data, bn.beta.data, bn.moving_mean.data, bn.moving_variance.data, bn.epsilon)
+            w2, b2 = ops.conv_fold_bn(self.kernel.data, self.bias.data, scale, shift)
+            act = bn_node.fused_act or ('linear', 0.0)
+            ctx.skip.add(bn_node.index)
+            return ops.conv1d_fwd(x, w2, b2, self.stride, pl, Lout, act[0], act[1])
         fused_drop = node.fused_drop is not None and self.filters > 4
         if node.fused_drop is not None and not fused_drop:
             raise NotImplementedError('Dropout directly after a Conv1D with <= 4 filters')
@@ -225,7 +239,11 @@ class BatchNormalization(Layer):
         self.moving_mean = self.add_weight('moving_mean', np.zeros(C, np.float32), trainable=False)
         self.moving_variance = self.add_weight('moving_variance', np.ones(C, np.float32), trainable=False)
 
+    is_batchnorm = True
+
     def forward(self, ctx, node, x):
+        if node.index in ctx.skip:         # inference phase: already folded into the producing convolution
+            return x
         C = x.shape[-1]
         x2 = x.reshape(-1, C)
         act = node.fused_act or ('linear', 0.0)

@@ -221,6 +221,15 @@ def dropout_mask(shape, rate, seed, offset, device):
     return m
 
 
+def conv_fold_bn(w, b, scale, shift):
+    """(k, Cin, Cout) kernel and bias with an inference-phase BatchNormalization folded in: conv(x; w', b') = BN_infer(conv(x; w, b))."""
+    _chk(w, b, scale, shift)
+    w2 = torch.empty_like(w)
+    b2 = torch.empty_like(scale)
+    _lib.call('gn_conv_fold_bn', _p(w), _p(b), _p(scale), _p(shift), _p(w2), _p(b2), w.numel() // w.shape[-1], w.shape[-1], _stream())
+    return w2, b2
+
+
 _CONV_MATH_WS = [None]
 
 

@@ -114,6 +114,11 @@ int gn_act_fwd(const float* x, float* y, size_t n, int act, float act_param, voi
 int gn_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float act_param, void* stream);
 /* backward of [activation -> dropout] in one pass through the post-dropout output y: dx = mask ? dy/(1-rate) * act'(y*(1-rate)) : 0 */
 int gn_act_dropout_bwd(const float* dy, const float* y, const uint8_t* mask, float* dx, size_t n, int act, float act_param, float rate, void* stream);
+/* Inference-phase BatchNormalization folded into the preceding convolution (generator.predict, bbhMahoGANy.py:1248, :1330):
+ * w_out[r, n] = w[r, n] * scale[n] (r over taps * Cin rows), bias_out[n] = bias[n] * scale[n] + shift[n], with scale / shift
+ * from gn_bn_infer_coeffs; conv(x; w_out, bias_out) then equals BN_infer(conv(x; w, bias)).  Cout % 4 == 0; bias may be NULL. */
+int gn_conv_fold_bn(const float* w, const float* bias, const float* scale, const float* shift, float* w_out, float* bias_out,
+                    size_t rows, int Cout, void* stream);
 /* PReLU (bbhMahoGANy.py:39; the act = 'prelu' branches at :237-286, :315-325): y[b,f] = x > 0 ? x : alpha[f] * x with one
  * alpha per feature of a sample (F features, F % 4 == 0).  Backward: dx = dy * (x > 0 ? 1 : x < 0 ? alpha : 0) (Keras'
  * relu(x) - alpha * relu(-x) has zero gradient at x == 0), dalpha[f] = sum_b dy[b,f] * min(x[b,f], 0); dx or dalpha may be NULL. */
