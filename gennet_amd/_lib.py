@@ -31,6 +31,7 @@ _SIGS = {
     'gn_act_dropout_bwd': [vp, vp, vp, vp, sz, i32, f32, f32, vp],
     'gn_set_conv_math': [i32, vp, sz],
     'gn_conv_fold_bn': [vp, vp, vp, vp, vp, vp, sz, i32, vp],
+    'gn_bn_apply_dropgen': [vp, vp, vp, vp, vp, sz, i32, i32, f32, f32, u64, u64, vp],
     'gn_prelu_fwd': [vp, vp, vp, i32, sz, vp],
     'gn_prelu_bwd': [vp, vp, vp, vp, vp, i32, sz, vp],
     'gn_dropout_mask': [vp, sz, f32, u64, u64, vp],

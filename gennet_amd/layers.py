@@ -11,6 +11,9 @@ import torch
 from . import ops
 from .engine import Layer, Model, device, device_rng, glorot_uniform
 
+import os as _os
+_NO_DROPGEN = bool(_os.environ.get('GN_NO_DROPGEN'))      # A/B switch: separate dropout-mask kernel instead of drawing it inside bn_apply
+
 _ACT_NAMES = {'relu': ('relu', 0.0), 'tanh': ('tanh', 0.0), 'sigmoid': ('sigmoid', 0.0), 'linear': ('linear', 0.0), None: ('linear', 0.0)}
 
 
@@ -258,8 +261,14 @@ class BatchNormalization(Layer):
         scale, shift, smean, sinv = ops.bn_finalize(sums, count, self.gamma.data, self.beta.data, self.epsilon, self.momentum,
                                                     self.moving_mean.data, self.moving_variance.data)
         mask, rate = None, 0.0
-        if node.fused_drop is not None:
+        if node.fused_drop is not None and node.fused_drop[0] > 0.0:
             rate, drop_layer = node.fused_drop
+            if ctx.dropout_masks.get(drop_layer.name) is None and C % 4 == 0 and not _NO_DROPGEN:
+                # no injected mask: draw it inside the apply pass (same Philox stream as Dropout.make_mask would take)
+                seed, off = device_rng().take(x2.numel())
+                y, mask = ops.bn_apply_dropgen(x2, scale, shift, act[0], act[1], rate, seed, off)
+                ctx.tape[node.index] = (x2, y, mask, smean, sinv, count, act, rate)
+                return y.reshape(x.shape)
             mask = drop_layer.make_mask(ctx, x2.shape)
         y = ops.bn_apply(x2, scale, shift, mask, act[0], act[1], rate)
         ctx.tape[node.index] = (x2, y, mask, smean, sinv, count, act, rate)

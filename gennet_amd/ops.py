@@ -376,6 +376,17 @@ def bn_apply(x2d, scale, shift, mask=None, act='linear', act_param=0.0, rate=0.0
     return y
 
 
+def bn_apply_dropgen(x2d, scale, shift, act, act_param, rate, seed, offset):
+    """bn_apply + activation + dropout with the keep-mask drawn in the same pass (dropout_mask's stream); -> (y, mask)."""
+    _chk(x2d)
+    rows, Cc = x2d.shape
+    y = torch.empty_like(x2d)
+    mask = torch.empty((rows, Cc), dtype=torch.uint8, device=x2d.device)
+    _lib.call('gn_bn_apply_dropgen', _p(x2d), _p(scale), _p(shift), _p(mask), _p(y), rows, Cc, ACT[act], float(act_param), float(rate), int(seed), int(offset),
+              _stream())
+    return y, mask
+
+
 def bn_bwd_stats(dy2d, y2d, x2d, mask, smean, sinv, act='linear', act_param=0.0, rate=0.0):
     _chk(dy2d, y2d, x2d, mask)
     rows, Cc = x2d.shape

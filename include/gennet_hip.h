@@ -114,6 +114,10 @@ int gn_act_fwd(const float* x, float* y, size_t n, int act, float act_param, voi
 int gn_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float act_param, void* stream);
 /* backward of [activation -> dropout] in one pass through the post-dropout output y: dx = mask ? dy/(1-rate) * act'(y*(1-rate)) : 0 */
 int gn_act_dropout_bwd(const float* dy, const float* y, const uint8_t* mask, float* dx, size_t n, int act, float act_param, float rate, void* stream);
+/* gn_bn_apply with the Dropout keep-mask GENERATED in the same pass (the draw of gn_dropout_mask, bit for bit) and written to
+ * mask_out for the backward pass: y = mask ? act(x * scale + shift) / (1 - rate) : 0.  C % 4 == 0. */
+int gn_bn_apply_dropgen(const float* x, const float* scale, const float* shift, uint8_t* mask_out, float* y, size_t rows, int C,
+                        int act, float act_param, float rate, uint64_t seed, uint64_t offset, void* stream);
 /* Inference-phase BatchNormalization folded into the preceding convolution (generator.predict, bbhMahoGANy.py:1248, :1330):
  * w_out[r, n] = w[r, n] * scale[n] (r over taps * Cin rows), bias_out[n] = bias[n] * scale[n] + shift[n], with scale / shift
  * from gn_bn_infer_coeffs; conv(x; w_out, bias_out) then equals BN_infer(conv(x; w, bias)).  Cout % 4 == 0; bias may be NULL. */
