@@ -157,6 +157,15 @@ def main():
         return (time.perf_counter() - t) / reps
     t_cnn = timed(lambda: bbh.pe_train_step(nets.signal_pe, bank, CNN_BATCH, rank=rank, world=world), 4)
     t_gan = timed(lambda: bbh.gan_train_step(nets, bank, event, GAN_BATCH, rank=rank, world=world, predict_batch=GAN_BATCH), 2)
+    # ... and for the synthesiser (metric iii; BASELINE configs[4] fuses it into the loop): templates/s of OnlineBank.draw -- chirp ->
+    # whiten -> irFFT x2 -> align/crop + white noise, everything in HBM -- with a smooth analytic PSD (no LAL here)
+    from gennet_amd import templates as T
+    f = np.arange(N_PIX * 2 + 1) * 0.25
+    psd = 1e-46 * ((np.maximum(f, 10.0) / 150.0) ** -4.0 + 2.0 + 2.0 * (f / 150.0) ** 2.0)
+    psd[f < 10.0] = 0.0
+    synth = T.OnlineBank(N_PIX, 4, psd, seed=1000 + rank, noise='white')
+    synth.draw(1024)
+    t_syn = timed(lambda: synth.draw(4096), 3)
 
     if rank == 0:
         value = world * WAVES * args.steps / dt
@@ -182,6 +191,7 @@ def main():
                          'step_algorithmic_tflops': world * WAVES * args.steps * (GFLOP_PER_WAVE_CNN + GFLOP_PER_WAVE_GAN) * 1e-3 / dt},
             'breakdown': {'cnn_train_waveforms_per_s': world * CNN_BATCH / t_cnn, 'gan_iteration_waveforms_per_s': world * GAN_BATCH / t_gan,
                           'cnn_ms_per_batch': 1e3 * t_cnn, 'gan_ms_per_iteration': 1e3 * t_gan,
+                          'synth_templates_per_s': world * 4096 / t_syn,
                           'note': 'rank-0 clock, measured after the timed steps; value = B / (t_CNN + t_GAN) comes from the K timed steps only'},
         }
         conv_math = os.environ.get('GENNET_CONV_MATH', 'fp32')
