@@ -8,18 +8,20 @@ One "step" pushes WAVES = 512 synthetic waveforms per GPU through BOTH training 
 so value = N_gpus * 512 * steps / wall_time = B / (t_CNN + t_GAN) of SURVEY section 8d.  Inputs (template bank, labels, event)
 are resident in HBM before the timed region; every optimizer step, BatchNorm update and dropout draw is inside it.
 
-python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
-Prints ONE JSON line on rank 0.
+python bench.py --gpus N --steps K --warmup W
+N > 1: one rank per GPU over RCCL.  Started under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS a
+rank; started plainly it launches `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a CHILD process
+before anything here touches the GPU, relays the child's output and exits with its code.  A rank whose world size differs from
+--gpus fails.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -88,6 +90,25 @@ def cpu_baseline(seconds_budget=25.0):
             'cnn_waveforms_per_s': 1.0 / t_cnn, 'gan_waveforms_per_s': 1.0 / t_gan}
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """python bench.py --gpus N started plainly: run the N ranks as a child torch.distributed.run job (this parent has not imported
+    torch, let alone touched the GPU), pass its stdout/stderr through and return its exit code."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -96,12 +117,23 @@ def main():
     ap.add_argument('--bank', type=int, default=100000, help='synthetic template bank size (BASELINE configs[1]: 100k segments)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
+    global np, torch
+    import numpy as np
+    import torch
     from gennet_amd import bbh, dist, engine, ops
     # RCCL (backend "nccl") over xGMI; GENNET_DIST_BACKEND=gloo only exists to rehearse the N>1 code path on a one-GPU box
-    dp = dist.init(os.environ.get('GENNET_DIST_BACKEND', 'nccl')) if args.gpus > 1 else None
+    backend = os.environ.get('GENNET_DIST_BACKEND', 'nccl')
+    dp = dist.init(backend) if args.gpus > 1 else None
     rank = dp.rank if dp else 0
     world = dp.world_size if dp else 1
+    if world != args.gpus or int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the job has WORLD_SIZE=%s (world size %d)\n' % (args.gpus, os.environ.get('WORLD_SIZE'), world))
+        sys.exit(2)
     dev = engine.device()
     engine.set_init_seed(1)                     # identical initial weights on every rank
     engine.set_device_seed(1000 + rank)         # per-rank dropout / latent / noise streams
@@ -172,7 +204,7 @@ def main():
         ach = conv['flop'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
         out = {
             'metric': 'waveforms/sec (CNN+GAN step, 2048-sample BBH)', 'value': value, 'unit': 'waveforms/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'n_gpus': world, 'ranks': world, 'collective_backend': ('rccl' if backend == 'nccl' else backend) if dp else None, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'per GPU and step: 2 x CNN point-estimator train_on_batch(batch=256) + 1 GAN iteration(batch=512) '
                                    '(G.predict, D step on 2B, G step through frozen D); n_pix=2048; %d-row synthetic template bank in HBM' % bank_n,

@@ -16,6 +16,8 @@ namespace gn {
 // small Cin: y[b, os*m+o0, n] = act(bias[n] + sum_j sum_c x[b, is*m+off_j, c] * w[widx_j, c, n]),  Cin <= 4, Cout % 4 == 0
 // block = 256 threads: NQc = min(Cout/4, 256) float4 columns x (256/NQc) row lanes; MT rows per block.
 // ---------------------------------------------------------------------------------------------
+constexpr int SMALLCIN_WIN = (2 * 255 + 5) * 4 + 4;   // floats of LDS input window: 256 rows at stride 2, 5 taps, 4 channels
+
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvArgs a, int m_tiles, int MT) {
   constexpr int MAXT = 5;
@@ -30,7 +32,7 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvArgs a, int m_ti
   float* yb = a.y + (size_t)b * a.Ly * a.Cout;
   // the input window of the block's rows goes through LDS once (zeros outside [0, Lin)): the row loop then issues one store per
   // row and nothing else on the vector-memory path (it issued ntaps * CIN broadcast loads per row before: 2.3 -> 3.9 TB/s written)
-  __shared__ float xw[(2 * 255 + 5) * 4 + 4];
+  __shared__ float xw[SMALLCIN_WIN];
   int minoff = a.t.off[0], maxoff = a.t.off[0];
   for (int j = 1; j < a.t.ntaps; ++j) {
     minoff = min(minoff, a.t.off[j]);
@@ -86,7 +88,24 @@ int conv_smallcin_dispatch(const ConvArgs& a, hipStream_t s) {
     return GN_EINVAL;
   }
   const int NQ = a.Cout / 4, NQc = NQ < 256 ? NQ : 256, RL = 256 / NQc;
-  const int MT = RL * 16 < 256 ? RL * 16 : 256;  // 16 rows per thread amortise the register-resident weights; <= 256: the LDS input window
+  int MT = RL * 16 < 256 ? RL * 16 : 256;  // 16 rows per thread amortise the register-resident weights; <= 256: the LDS input window
+  // the block's input window (in_stride * (MT-1) + tap span + 1 rows of Cin floats) must fit the kernel's LDS array: strides > 2 and
+  // dilated tap sets get fewer rows per block, and a tap span that does not fit even one row is refused
+  int minoff = a.t.off[0], maxoff = a.t.off[0];
+  for (int j = 1; j < a.t.ntaps; ++j) {
+    minoff = a.t.off[j] < minoff ? a.t.off[j] : minoff;
+    maxoff = a.t.off[j] > maxoff ? a.t.off[j] : maxoff;
+  }
+  if (a.t.in_stride < 1) {
+    set_error("conv_smallcin: in_stride %d < 1", a.t.in_stride);
+    return GN_EINVAL;
+  }
+  auto window = [&](int mt) { return ((long long)a.t.in_stride * (mt - 1) + (maxoff - minoff) + 1) * a.Cin; };
+  while (MT > 1 && window(MT) > SMALLCIN_WIN) MT >>= 1;
+  if (window(MT) > SMALLCIN_WIN) {
+    set_error("conv_smallcin: tap span %d x Cin %d does not fit the %d-float input window", maxoff - minoff + 1, a.Cin, SMALLCIN_WIN);
+    return GN_EINVAL;
+  }
   const int m_tiles = cdiv(a.M, MT);
   const unsigned grid = (unsigned)m_tiles * a.B;
   if (grid == 0) return GN_OK;

@@ -50,7 +50,8 @@ def init(backend=None):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
+        if 'MASTER_PORT' not in os.environ:
+            raise RuntimeError('WORLD_SIZE=%d but MASTER_PORT is unset: start the ranks with torch.distributed.run (bench.py --gpus N does)' % world)
         if backend == 'nccl':
             torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
         dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=world)

@@ -16,7 +16,6 @@ fusions decided once per graph (conv+activation epilogue, BN+activation+dropout 
 model trains live in ONE flat fp32 buffer (plus one flat gradient buffer), so the optimizer is a single fused kernel
 and data-parallel training needs a single all-reduce per step.
 """
-import pickle
 import re
 
 import numpy as np
@@ -786,12 +785,7 @@ class Model(Layer):
         from . import keras_io
         if by_name:
             raise NotImplementedError('load_weights(by_name=True)')
-        if not keras_io.is_hdf5(filepath):     # container written by the first builds of this package
-            with open(filepath, 'rb') as f:
-                blob = pickle.load(f)
-            self.set_weights(blob['weights'])
-            return
-        keras_io.load_weights(self, filepath)
+        keras_io.load_weights(self, filepath)      # raises h5lite.H5Error on anything that is not an HDF5 file (never unpickles)
 
     def save(self, filepath, overwrite=True, include_optimizer=True):
         import os

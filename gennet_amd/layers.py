@@ -117,6 +117,11 @@ class Conv1D(Layer):
 
     def build(self, input_shape):
         L, Cin = input_shape
+        if self.stride < 1 or (Cin > 4 and self.stride > 2):
+            raise NotImplementedError('Conv1D(strides=%d) on %d input channels: the matrix-core kernels implement strides 1 and 2 '
+                                      '(any stride >= 1 runs for <= 4 input channels)' % (self.stride, Cin))
+        if self.k > 5:
+            raise NotImplementedError('Conv1D(kernel_size=%d): at most 5 taps' % self.k)
         self.kernel = self.add_weight('kernel', glorot_uniform((self.k, Cin, self.filters)))
         self.bias = self.add_weight('bias', np.zeros(self.filters, np.float32))
 

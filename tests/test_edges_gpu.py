@@ -67,6 +67,20 @@ def test_smallest_shapes_of_each_conv_family():
         assert np.abs(y - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1.0)
 
 
+def test_small_cin_conv_strides_beyond_two():
+    """The small-Cin kernel stages its input window in a fixed LDS array: strides > 2 get fewer rows per block instead of writing
+    past it (Conv1D(16,5,strides=3) on 4 channels and Conv1D(64,5,strides=9) on 1 channel: the shapes ADVICE round 1 named)."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(4)
+    for (B, L, Cin, Cout, k, s, padding) in ((2, 4001, 4, 16, 5, 3, 'same'), (1, 5000, 1, 64, 5, 9, 'valid'), (2, 3000, 3, 8, 5, 5, 'same')):
+        x = rng.randn(B, L, Cin).astype(np.float32); w = rng.randn(k, Cin, Cout).astype(np.float32); b = rng.randn(Cout).astype(np.float32)
+        Lout, pl = ops.conv_geometry(L, k, s, padding)
+        ref = K.conv1d_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s, padding)
+        y = ops.conv1d_fwd(torch.tensor(x).to(dev()), torch.tensor(w).to(dev()), torch.tensor(b).to(dev()), s, pl, Lout).cpu().numpy()
+        assert y.shape == ref.shape
+        assert np.abs(y - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1.0)
+
+
 def test_indexing_beyond_2_to_31_elements():
     """Generator conv5 output at batch 512 holds 512 * 2048 * 1024 = 2^30 elements and its input-gradient slabs more; the first
     dense layer's activations at B = 4096 (config 4 on one rank) 2^30.  Run the streaming kernels on a 2^31 + 2^20 element

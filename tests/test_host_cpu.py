@@ -5,6 +5,7 @@ import ctypes
 import os
 import pickle
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -114,6 +115,53 @@ def test_unsupported_configurations_raise():
         UpSampling1D(size=3)
     with pytest.raises(NotImplementedError):
         Dense(4, kernel_initializer='he_normal')
+
+
+def test_conv1d_strides_and_weight_files_fail_loudly(tmp_path):
+    """strides the kernels do not implement are refused when the layer is built (not at launch time); a weights file that is not
+    HDF5 is a format error (it is never unpickled)."""
+    from gennet_amd import h5lite
+    from gennet_amd.engine import Sequential
+    from gennet_amd.layers import Conv1D
+    with pytest.raises(NotImplementedError):
+        Sequential().add(Conv1D(16, 5, strides=3, input_shape=(64, 8)))
+    Sequential().add(Conv1D(16, 5, strides=3, input_shape=(64, 4)))          # small-Cin kernel: any stride
+    with pytest.raises(NotImplementedError):
+        Sequential().add(Conv1D(16, 7, input_shape=(64, 8)))
+    import pickle
+    bad = tmp_path / 'w.h5'
+    bad.write_bytes(pickle.dumps({'weights': []}))
+    m = Sequential(); m.add(Conv1D(16, 5, input_shape=(64, 4)))
+    with pytest.raises(h5lite.H5Error):
+        m.load_weights(str(bad))
+
+
+def test_bench_gpus_n_spawns_n_ranks(monkeypatch):
+    """`python bench.py --gpus N` started plainly launches N ranks itself (child torch.distributed.run, before torch is imported in
+    the parent) and exits with the child's code; a rank whose WORLD_SIZE differs from --gpus exits non-zero."""
+    import importlib
+    import subprocess
+    bench = importlib.import_module('bench')
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'] = cmd; seen['env'] = env
+        return 7
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1'])
+    monkeypatch.delenv('RANK', raising=False); monkeypatch.delenv('WORLD_SIZE', raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+    assert cmd[-6:] == ['--gpus', '4', '--steps', '3', '--warmup', '1'] and cmd[-7].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # inside a rank: world size must equal --gpus
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, RANK='0', WORLD_SIZE='1'))
+    assert r.returncode == 2 and 'WORLD_SIZE' in r.stderr
 
 
 def test_synth_host_helpers_match_reference_golden():
