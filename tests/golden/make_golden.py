@@ -11,9 +11,26 @@ exist on the GPU box):      python tests/golden/make_golden.py
   gen_noise        gw_template_maker.py:161-193
   whiten_data      gw_template_maker.py:243-286
   hunt_constrain   gw_template_maker.py:329-338   (body of gen_masses, dedented; the py2 print on :328 is skipped)
+
+indexing_golden.npz (sample indexing: north_star's "bit-exact for sample indexing" rests on these):
+  bbhparams        gw_template_maker.py:69-85
+  gen_masses       gw_template_maker.py:289-370
+  gen_par          gw_template_maker.py:372-460   (draw order of the legacy MT19937 stream, idx, the event-like branch)
+  gen_bbh          gw_template_maker.py:462, :493-498, :518-547, :553-575 executed as written; the LALSuite lines :499-516 is replaced by
+                   SUPPLIED frequency-domain spectra hp.data.data / hc.data.data, and the make_bbh call :551 (pylal antenna response +
+                   LAL time delay; its return value :630 is the un-shifted ht = hp*Fp + hc*Fc, hp, hc) by that expression with SUPPLIED
+                   constants Fp, Fc.  Everything else -- whiten_data('fd'), irfft, roll, ref_idx = argmax, sidx, the window placement,
+                   the python slice [ref_idx - par.idx - 11:], zero fill, window -- is the reference's own text.
+  sim_data         gw_template_maker.py:632-740   executed as written (Nnoise = 0) on top of the functions above: the crop :695, the trim
+                   quirk :718-722, the permutation :725-727, the event-like template appended last :730-739
+Run-time text handling (nothing of it is stored): tabs expanded to 8 columns (the files mix tabs and spaces: Python 2 semantics), and
+lines that are Python 2 `print '...'` statements (with or without the `if verb:` prefix) replaced by `pass`.  Integer `/` in those
+lines only ever divides even ints by 2 or feeds int(): Python 3's true division gives the same values for T_obs = 4 and even fs.
 """
 import os
+import re
 import textwrap
+import time
 
 import numpy as np
 
@@ -77,6 +94,123 @@ def main():
     np.savez_compressed(OUT, **out)
     print('wrote', OUT, {k: np.asarray(v).shape for k, v in out.items()})
     posterior_golden()
+    indexing_golden()
+
+
+_PY2_PRINT = re.compile(r"^(\s*)(if verb:\s*)?print\s+'")
+
+
+def ref_text(lines, a, b):
+    """Reference lines a..b (1-based, inclusive) as Python-3-parsable text: tabs expanded, py2 print statements -> pass."""
+    out = []
+    for ln in lines[a - 1:b]:
+        ln = ln.expandtabs(8)
+        m = _PY2_PRINT.match(ln)
+        out.append(m.group(1) + 'pass\n' if m else ln)
+    return ''.join(out)
+
+
+class _FD(object):
+    """Shape of a LAL COMPLEX16FrequencySeries as gen_bbh reads it: .data.data is the complex spectrum."""
+
+    def __init__(self, a):
+        self.data = type('d', (), {})()
+        self.data.data = a
+
+
+def reference_namespace():
+    """The reference's synthesiser functions, executed from its own text, with the two LALSuite touch points supplied by the caller
+    through ns['_supplied_fd_waveform'](par, fs, T_obs) -> (hp, hc) and ns['_Fp'], ns['_Fc']."""
+    lines = open(REF).read().splitlines(True)
+    ns = {'np': np, 'time': time, 'safe': 2, 'verb': False, 'gw_tmp': True, 'do_time_grid': False, 'N_time_grid': 25, 'sample_num': 50000,
+          '_captured': {}}
+    for a, b in ((69, 85), (87, 113), (133, 159), (243, 286), (289, 370), (372, 460)):
+        exec(compile(ref_text(lines, a, b), '%s:%d-%d' % (REF, a, b), 'exec'), ns)
+    src = (ref_text(lines, 462, 462) + ref_text(lines, 493, 498)
+           + '    hp, hc = _supplied_fd_waveform(par, fs, T_obs)        # stands in for :499-516 (lalsimulation)\n'
+           + ref_text(lines, 518, 547)
+           + '    for det in dets:\n'
+           + '        ht_shift, hp_shift, hc_shift = orig_hp*_Fp + orig_hc*_Fc, orig_hp, orig_hc     # stands in for :551 (make_bbh -> :613, :630)\n'
+           + ref_text(lines, 553, 573)
+           + '    _captured.update(ref_idx=int(ref_idx), sidx=sidx, win=win.copy(), start=int(ref_idx-par.idx-11))\n'
+           + ref_text(lines, 575, 575))
+    assert lines[548 - 1].strip() == 'for det in dets:' and 'make_bbh' in lines[551 - 1] and lines[575 - 1].strip() == 'return ts, hp, hc, ts'
+    exec(compile(src, '%s:gen_bbh' % REF, 'exec'), ns)
+    exec(compile(ref_text(lines, 632, 740), '%s:632-740' % REF, 'exec'), ns)
+    return ns
+
+
+def indexing_golden():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+    from oracle import synth_ref as S          # only for the SUPPLIED inputs (this project's chirp model, PSD curve and Fp/Fc constants)
+    ns = reference_namespace()
+    Fp, Fc = S.antenna_response(S.EVENT_TIME, S.RA, S.DEC, S.PSI)
+    ns['_Fp'], ns['_Fc'] = Fp, Fc
+    out = {'Fp': Fp, 'Fc': Fc}
+    T_obs = 4
+
+    # --- gen_par: draw order and values, both branches, three sample rates; stream position afterwards
+    rows = []
+    for fs, seed in ((1024, 1), (2048, 2), (4096, 3), (256, 4)):
+        np.random.seed(seed)
+        for k in range(40):
+            p = ns['gen_par'](fs, T_obs, mdist='hunt_constrain', beta=[0.45, 0.55], gw_tmp=(k % 13 == 12))
+            rows.append([fs, seed, p.mc, p.M, p.eta, p.m1, p.m2, p.ra, p.dec, p.iota, p.phi, p.psi, p.idx])
+        rows.append([fs, seed, -1] + list(np.random.uniform(0, 1, 3)) + [0] * 7)          # marker row: the next three uniforms
+    out['gen_par_rows'] = np.array(rows, dtype=np.float64)
+    np.random.seed(5)
+    out['gen_par_beta_75_95'] = np.array([ns['gen_par'](1024, T_obs, mdist='hunt_constrain', beta=[0.75, 0.95]).idx for _ in range(20)])
+
+    # --- gen_bbh downstream of the spectra: chirps from this project's model AND adversarial random spectra (ref_idx anywhere, so the
+    # python slice start goes negative / beyond N - len(window) and the zero fill is exercised), per sample rate
+    cases = []
+    for fs in (256, 1024, 2048, 4096):
+        N = fs * T_obs; Nf = N // 2 + 1
+        psd = S.analytic_psd(Nf, 1.0 / T_obs)
+        rng = np.random.RandomState(100 + fs)
+        np.random.seed(fs)
+        n_chirp = 4 if fs <= 2048 else 2
+        for k in range(n_chirp + 3):
+            par = ns['gen_par'](fs, T_obs, mdist='hunt_constrain', beta=[0.45, 0.55], gw_tmp=(k == 1))
+            if k < n_chirp:
+                hp, hc = S.chirp_fd(par.m1, par.m2, Nf, 1.0 / T_obs, iota=par.iota, phi=par.phi)
+            else:                                                  # random spectra scaled like a strain spectrum
+                hp = (rng.randn(Nf) + 1j * rng.randn(Nf)) * 1e-24; hc = (rng.randn(Nf) + 1j * rng.randn(Nf)) * 1e-24
+                par.idx = [3, N - 5, N // 2][k - n_chirp]          # slide start far negative / far positive / central
+            ns['_supplied_fd_waveform'] = lambda par_, fs_, T_, hp=hp, hc=hc: (_FD(hp.copy()), _FD(hc.copy()))
+            ts, hp_t, hc_t, _ = ns['gen_bbh'](fs, T_obs, psd, dets=['H1'], beta=[0.45, 0.55], par=par, gw_tmp=(k == 1))
+            cap = dict(ns['_captured'])
+            cases.append((fs, par.idx, cap['ref_idx'], cap['sidx'], cap['start'], hp, hc, ts[0], cap['win']))
+    out['bbh_meta'] = np.array([[c[0], c[1], c[2], c[3], c[4]] for c in cases], dtype=np.int64)       # fs, idx, ref_idx, sidx, slice start
+    for n, c in enumerate(cases):
+        out['bbh_hp_%02d' % n] = c[5]; out['bbh_hc_%02d' % n] = c[6]
+        fs = c[0]
+        out['bbh_crop_%02d' % n] = c[7][int(1.5 * fs):int(2.5 * fs)]
+        nz = np.flatnonzero(c[7])
+        out['bbh_support_%02d' % n] = np.array([nz.min() if nz.size else -1, nz.max() if nz.size else -1, float(np.abs(c[7]).sum()), float((c[7] ** 2).sum())])
+    wins = {}
+    for c in cases:
+        wins.setdefault(c[0], c[8])
+    for fs, w in wins.items():                                     # window placement: first/last non-zero sample, flat region, checksum
+        nz = np.flatnonzero(w); flat = np.flatnonzero(w == 1.0)
+        out['win_%d' % fs] = np.array([nz.min(), nz.max(), flat.min(), flat.max(), w.sum()])
+
+    # --- sim_data, whole, seeded, with chirps from this project's model as the supplied spectra
+    for fs, size, seed in ((256, 14, 1), (1024, 6, 1)):
+        N = fs * T_obs; Nf = N // 2 + 1
+        psd = S.analytic_psd(Nf, 1.0 / T_obs)
+        ns['_supplied_fd_waveform'] = lambda par_, fs_, T_: tuple(_FD(a) for a in S.chirp_fd(par_.m1, par_.m2, fs_ * T_ // 2 + 1, 1.0 / T_, iota=par_.iota, phi=par_.phi))
+        np.random.seed(seed)
+        (ts, yval), pars = ns['sim_data'](fs, T_obs, psd, dets=['H1'], Nnoise=0, size=size, mdist='hunt_constrain', beta=[0.45, 0.55])
+        out['sim_%d_next_uniform' % fs] = np.random.uniform(0, 1, 3)
+        out['sim_%d_ts' % fs] = ts
+        out['sim_%d_yval' % fs] = yval
+        out['sim_%d_pars' % fs] = np.array([[p.mc, p.M, p.eta, p.m1, p.m2, p.ra, p.dec, p.iota, p.phi, p.psi, p.idx] for p in pars])
+        out['sim_%d_meta' % fs] = np.array([fs, size, seed])
+    path = os.path.join(os.path.dirname(OUT), 'indexing_golden.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes;', len(cases), 'gen_bbh cases')
 
 
 def posterior_golden():

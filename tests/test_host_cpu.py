@@ -178,6 +178,25 @@ def test_synth_host_helpers_match_reference_golden():
     assert np.array_equal(G['wh_fd_in'] * s, G['wh_fd_out'])
 
 
+def test_gen_par_matches_reference_execution():
+    """templates.gen_par (host numpy, legacy MT19937 stream) against what gw_template_maker.py:372-460 produced when executed
+    (tests/golden/indexing_golden.npz): every field bit-exact, idx exact, same stream position afterwards."""
+    from gennet_amd import templates as T
+    IG = np.load(os.path.join(ROOT, 'tests', 'golden', 'indexing_golden.npz'))
+    rows = IG['gen_par_rows']
+    k = 0
+    for fs, seed in ((1024, 1), (2048, 2), (4096, 3), (256, 4)):
+        np.random.seed(seed)
+        for j in range(40):
+            p = T.gen_par(fs, 4, mdist='hunt_constrain', beta=[0.45, 0.55], gw_tmp=(j % 13 == 12))
+            assert [p.mc, p.M, p.eta, p.m1, p.m2, p.ra, p.dec, p.iota, p.phi, p.psi, p.idx] == list(rows[k][2:13])
+            k += 1
+        assert np.array_equal(np.random.uniform(0, 1, 3), rows[k][3:6])
+        k += 1
+    np.random.seed(5)
+    assert [T.gen_par(1024, 4, mdist='hunt_constrain', beta=[0.75, 0.95]).idx for _ in range(20)] == list(IG['gen_par_beta_75_95'])
+
+
 def test_ts_pars_file_layout_roundtrip(tmp_path):
     """[ts (Ns,1,fs) f64, yval], list of __main__.bbhparams, pickle protocol 2, reference file names."""
     from gennet_amd import templates as T

@@ -122,6 +122,52 @@ def test_align_crop_bit_exact_indexing_given_same_spectra(fs):
         assert rel(out[b], crop) < 1e-12
 
 
+IG = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'indexing_golden.npz'))
+
+
+def test_align_crop_matches_reference_executed_fixtures():
+    """The sample-indexing contract against what the REFERENCE'S OWN gen_bbh text produced (tests/golden/indexing_golden.npz:
+    gw_template_maker.py:518-547, :553-575 executed with supplied spectra): ref_idx and the slice start exact, the cropped series
+    <= 1e-12 -- chirps and the adversarial random spectra with negative / far-positive python slice starts, fs 256 ... 4096."""
+    from gennet_amd import templates as T
+    Fp, Fc = float(IG['Fp']), float(IG['Fc'])
+    for n, (fs, idx, ref_idx, sidx, start) in enumerate(IG['bbh_meta']):
+        fs = int(fs); N = 4 * fs
+        psd = S.analytic_psd(N // 2 + 1, 0.25)
+        syn = T.Synth(fs, 4, psd)
+        assert (syn.Fp, syn.Fc) == (Fp, Fc)
+        whp = T.whiten_data(IG['bbh_hp_%02d' % n], 4, fs, psd, 'fd'); whc = T.whiten_data(IG['bbh_hc_%02d' % n], 4, fs, psd, 'fd')
+        hp_t = T.irfft(c2dev(whp[None]), N); hc_t = T.irfft(c2dev(whc[None]), N)
+        out, ref = syn.align(hp_t, hc_t, [int(idx)], int(1.5 * fs), fs, Fp, Fc)
+        assert int(ref.cpu()[0]) == ref_idx and int(ref.cpu()[0]) - int(idx) - syn.peak_off == start
+        assert rel(out.cpu().numpy()[0], IG['bbh_crop_%02d' % n]) < 1e-12
+        # the full windowed series (gen_bbh's return value): support and checksums of the reference's ts
+        full, _ = syn.align(hp_t, hc_t, [int(idx)], 0, N, Fp, Fc)
+        tw = T.tukey(int((16.0 / 15.0) * N / 2), alpha=1.0 / 8.0)
+        win = np.zeros(N); a = int((N - tw.size) / 2); win[a:a + tw.size] = tw
+        ts = full.cpu().numpy()[0] * win
+        lo, hi, l1, l2 = IG['bbh_support_%02d' % n]
+        nz = np.flatnonzero(ts)
+        assert (nz.min() if nz.size else -1, nz.max() if nz.size else -1) == (lo, hi)
+        assert abs(np.abs(ts).sum() - l1) <= 1e-11 * l1 and abs((ts ** 2).sum() - l2) <= 1e-11 * l2
+
+
+@pytest.mark.parametrize("fs", [256, 1024])
+def test_sim_data_matches_reference_executed_fixture(fs):
+    """templates.sim_data against the reference's sim_data (gw_template_maker.py:632-740 executed as written on the same supplied
+    waveform model): identical draws, shuffle and event-like row (exact), same host-RNG position afterwards, series to 1e-9 (the
+    chirp evaluation: device pow/sincos vs libm, see the module docstring; downstream of the spectra the bar is 1e-12, test above)."""
+    from gennet_amd import templates as T
+    _, size, seed = [int(v) for v in IG['sim_%d_meta' % fs]]
+    psd = S.analytic_psd(fs * 2 + 1, 0.25)
+    np.random.seed(seed)
+    (ts, yval), pars = T.sim_data(fs, 4, psd, ['H1'], 0, size, 'hunt_constrain', [0.45, 0.55])
+    assert np.array_equal(np.random.uniform(0, 1, 3), IG['sim_%d_next_uniform' % fs])
+    got = np.array([[p.mc, p.M, p.eta, p.m1, p.m2, p.ra, p.dec, p.iota, p.phi, p.psi, p.idx] for p in pars])
+    assert np.array_equal(got, IG['sim_%d_pars' % fs]) and np.array_equal(yval, IG['sim_%d_yval' % fs])
+    assert ts.shape == IG['sim_%d_ts' % fs].shape and rel(ts, IG['sim_%d_ts' % fs]) < 1e-9
+
+
 def test_align_python_slice_semantics_edge_cases():
     """start = ref_idx - idx - 11 < 0 (python slices from the end) and start near N (zero fill), on crafted series."""
     from gennet_amd import templates as T
