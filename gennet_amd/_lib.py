@@ -47,6 +47,7 @@ _SIGS = {
     'gn_axpy': [vp, vp, f32, sz, vp],
     'gn_bn_stats': [vp, sz, i32, vp, vp, sz, vp],
     'gn_bn_finalize': [vp, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp],
+    'gn_bn_finalize_zero_debias': [vp, f64, vp, vp, f32, f32, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp],
     'gn_bn_infer_coeffs': [vp, vp, vp, vp, f32, vp, vp, i32, vp],
     'gn_bn_apply': [vp, vp, vp, vp, vp, sz, i32, i32, f32, f32, vp],
     'gn_bn_bwd_stats': [vp, vp, vp, vp, vp, vp, vp, vp, sz, sz, i32, i32, f32, f32, vp],

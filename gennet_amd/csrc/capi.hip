@@ -460,7 +460,18 @@ int gn_bn_finalize(const double* sums, double count, const float* gamma, const f
                    float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream) {
   GN_REQUIRE(sums && gamma && beta && scale && shift && save_mean && save_invstd && C > 0 && count > 1.0, "bn_finalize: bad arguments");
   GN_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving_mean/moving_var must both be given or both be NULL");
-  return bn_finalize(sums, count, gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, save_mean, save_invstd, C, (hipStream_t)stream);
+  return bn_finalize(sums, count, gamma, beta, eps, momentum, moving_mean, moving_var, nullptr, nullptr, 0.f, scale, shift, save_mean, save_invstd, C,
+                     (hipStream_t)stream);
+}
+
+int gn_bn_finalize_zero_debias(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum, float* moving_mean,
+                               float* moving_var, float* biased_mean, float* biased_var, int local_step, float* scale, float* shift, float* save_mean,
+                               float* save_invstd, int C, void* stream) {
+  GN_REQUIRE(sums && gamma && beta && scale && shift && save_mean && save_invstd && C > 0 && count > 1.0, "bn_finalize_zero_debias: bad arguments");
+  GN_REQUIRE(moving_mean && moving_var && biased_mean && biased_var && local_step >= 1,
+             "bn_finalize_zero_debias: needs moving_mean/var, the biased accumulators and the incremented local_step (>= 1, got %d)", local_step);
+  return bn_finalize(sums, count, gamma, beta, eps, momentum, moving_mean, moving_var, biased_mean, biased_var, (float)local_step, scale, shift, save_mean,
+                     save_invstd, C, (hipStream_t)stream);
 }
 int gn_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var, float eps, float* scale, float* shift, int C,
                        void* stream) {

@@ -402,8 +402,13 @@ int colred_run(int mode, ColRedArgs a, void* ws, size_t ws_bytes, double* out_f6
 // ---------------------------------------------------------------------------------------------
 // BatchNorm finalize / apply / backward-apply
 // ---------------------------------------------------------------------------------------------
+// moving statistics, two forms of TF's assign_moving_average (fp32 variables, like TF's):
+//   zd_step == 0 : plain EMA (zero_debias=False):  v -= (v - value) * (1 - m)
+//   zd_step >= 1 : zero_debias=True (keras 2.2.4's TF backend): biased -= (biased - value) * (1 - m);  v -= v - biased / (1 - m^step)
+//                  with `biased` a shadow accumulator that starts at zero and zd_step the already incremented local_step
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float eps, float momentum, float* __restrict__ mm, float* __restrict__ mv, float* __restrict__ scale,
+                                   float eps, float momentum, float* __restrict__ mm, float* __restrict__ mv, float* __restrict__ bm,
+                                   float* __restrict__ bv, float zd_step, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ smean, float* __restrict__ sinv, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -419,13 +424,26 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   sinv[c] = inv;
   if (mm) {
     const float corr = (float)(count / (count - (1.0 + (double)eps)));
-    mm[c] = mm[c] * momentum + meanf * (1.0f - momentum);
-    mv[c] = mv[c] * momentum + varf * corr * (1.0f - momentum);
+    const float decay = (float)(1.0 - (double)momentum);
+    const float varc = varf * corr;
+    if (bm) {
+      const float nbm = bm[c] - (bm[c] - meanf) * decay;
+      const float nbv = bv[c] - (bv[c] - varc) * decay;
+      bm[c] = nbm;
+      bv[c] = nbv;
+      const float unb = 1.0f - powf(1.0f - decay, zd_step);
+      mm[c] = mm[c] - (mm[c] - nbm / unb);
+      mv[c] = mv[c] - (mv[c] - nbv / unb);
+    } else {
+      mm[c] = mm[c] - (mm[c] - meanf) * decay;
+      mv[c] = mv[c] - (mv[c] - varc) * decay;
+    }
   }
 }
 int bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum, float* mm, float* mv,
-                float* scale, float* shift, float* smean, float* sinv, int C, hipStream_t s) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, sums, count, gamma, beta, eps, momentum, mm, mv, scale, shift, smean, sinv, C);
+                float* bm, float* bv, float zd_step, float* scale, float* shift, float* smean, float* sinv, int C, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, sums, count, gamma, beta, eps, momentum, mm, mv, bm, bv, zd_step, scale, shift,
+                     smean, sinv, C);
   return check_launch("bn_finalize");
 }
 

@@ -183,8 +183,9 @@ def device_rng():
 
 
 class RunContext(object):
-    def __init__(self, training, dp=None, dropout_masks=None, train_params=None):
+    def __init__(self, training, dp=None, dropout_masks=None, train_params=None, site=None):
         self.training = training
+        self.site = site                   # name of the model whose train_on_batch runs (BatchNormalization keeps per-site state)
         self.dp = dp
         self.dropout_masks = dropout_masks or {}
         self.train_ids = None if train_params is None else set(id(p) for p in train_params)
@@ -696,7 +697,7 @@ class Model(Layer):
         dp = self.data_parallel
         world = dp.world_size if dp is not None else 1
         masks = {k: to_device(v, torch.uint8) for k, v in (dropout_masks or {}).items()}
-        ctx = RunContext(True, dp, masks, self._train_params)
+        ctx = RunContext(True, dp, masks, self._train_params, self.name)
         outs = self._forward(xs, ctx)
         dps, stats = [], []
         for p, t, kind in zip(outs, ys, self._losses):

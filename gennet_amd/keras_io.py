@@ -344,9 +344,48 @@ def is_hdf5(path):
         return fh.read(8) == h5lite.SIGNATURE
 
 
+STATE_GROUP = 'gennet_amd_state'      # private root group (not a keras layer group: keras' loaders only visit attrs['layer_names'])
+
+
+def _bn_layers(model):
+    return [l for l in model.layers if getattr(l, 'is_batchnorm', False)]
+
+
+def save_private_state(root, model):
+    """BatchNormalization's zero-debias shadow variables (layers.BatchNormalization): TF graph variables that keras itself never saves.
+    Written to <STATE_GROUP>/<layer>/<training model>/{biased_mean, biased_var, local_step} so that a run resumed from a file written
+    HERE continues the same moving averages; a file from real keras has no such group and the state restarts at zero, as in keras."""
+    bns = [l for l in _bn_layers(model) if l.zero_debias]
+    if not bns:
+        return
+    g = root.create_group(STATE_GROUP)
+    for l in bns:
+        lg = g.create_group(l.name)
+        for site, (bm, bv, step) in sorted(l.zero_debias.items()):
+            sg = lg.create_group(site)
+            sg.create_dataset('biased_mean', np.ascontiguousarray(bm.cpu().numpy(), np.float32))
+            sg.create_dataset('biased_var', np.ascontiguousarray(bv.cpu().numpy(), np.float32))
+            sg.create_dataset('local_step', np.asarray([step], np.int64))
+
+
+def load_private_state(f, model):
+    from .engine import to_device
+    for l in _bn_layers(model):
+        l.zero_debias = {}                       # keras semantics for files without the private group: shadow variables restart at zero
+    if STATE_GROUP not in f:
+        return
+    g = f[STATE_GROUP]
+    for l in _bn_layers(model):
+        if l.name not in g:
+            continue
+        for site, sg in g[l.name].items():
+            l.zero_debias[site] = [to_device(sg['biased_mean'].value), to_device(sg['biased_var'].value), int(np.asarray(sg['local_step'].value).reshape(-1)[0])]
+
+
 def save_weights(model, path):
     w = h5lite.Writer()
     save_weights_to_group(w.root, top_layers(model))
+    save_private_state(w.root, model)
     w.save(path)
 
 
@@ -354,6 +393,7 @@ def load_weights(model, path):
     f = h5lite.File(path)
     g = f['model_weights'] if 'layer_names' not in f.attrs and 'model_weights' in f else f
     load_weights_from_group(g, top_layers(model))
+    load_private_state(f, model)
 
 
 def _loss_json(loss):
@@ -387,6 +427,7 @@ def save_model(model, path, include_optimizer=True):
                     names.append(n)
                     k += 1
             og.attrs['weight_names'] = np.array([n.encode('utf-8') for n in names], dtype='S')
+    save_private_state(w.root, model)
     w.save(path)
 
 
@@ -397,6 +438,7 @@ def load_model(path, custom_objects=None, compile=True):
         raise ValueError('No model found in config file.')
     model = model_from_config(json.loads(mc.decode('utf-8') if isinstance(mc, bytes) else mc), custom_objects)
     load_weights_from_group(f['model_weights'], top_layers(model))
+    load_private_state(f, model)
     tc = f.attrs.get('training_config')
     if compile and tc is not None:
         tc = json.loads(tc.decode('utf-8') if isinstance(tc, bytes) else tc)

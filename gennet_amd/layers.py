@@ -120,8 +120,6 @@ class Conv1D(Layer):
         if self.stride < 1 or (Cin > 4 and self.stride > 2):
             raise NotImplementedError('Conv1D(strides=%d) on %d input channels: the matrix-core kernels implement strides 1 and 2 '
                                       '(any stride >= 1 runs for <= 4 input channels)' % (self.stride, Cin))
-        if self.k > 5:
-            raise NotImplementedError('Conv1D(kernel_size=%d): at most 5 taps' % self.k)
         self.kernel = self.add_weight('kernel', glorot_uniform((self.k, Cin, self.filters)))
         self.bias = self.add_weight('bias', np.zeros(self.filters, np.float32))
 
@@ -226,19 +224,44 @@ class Conv2D(Layer):
         return None
 
 
+BN_MOVING_AVERAGE = 'tf_zero_debias'       # default form of the moving-statistics update (BatchNormalization docstring)
+
+
 class BatchNormalization(Layer):
     """bbhMahoGANy.py:235,:251,:260,:268,:276,:284 (momentum=0.99).  Train phase: batch mean / biased variance (fp64
     accumulation), moving statistics updated with keras' n/(n-(1+eps)) variance correction; inference: moving statistics.
     A following Activation and Dropout run in the same pass (one read, one write).  Under data parallelism the
-    statistics are all-reduced (SyncBN) so that N ranks x B/N rows reproduce a single-device batch of B."""
+    statistics are all-reduced (SyncBN) so that N ranks x B/N rows reproduce a single-device batch of B.
+
+    moving_average = 'tf_zero_debias' (default) reproduces keras 2.2.4 on its TF 1.12 backend: K.moving_average_update calls
+    tf moving_averages.assign_moving_average(x, value, momentum, zero_debias=True), which keeps a zero-initialised `biased` shadow
+    accumulator and a `local_step` counter and sets moving = biased / (1 - momentum^local_step): the moving statistics forget their
+    0 / 1 initial values at the first update (what generator.predict sees early in training, bbhMahoGANy.py:1248).  TF creates one
+    such pair PER CALL SITE of the layer (the generator's layers are called again when the generator is added to another
+    Sequential, :517, :537), and only the call site inside the model being trained is updated: the state is therefore kept per
+    (layer, training model).  The pairs are not keras weights: real keras never writes them to .h5 files and starts them from zero
+    after load_weights; keras_io keeps them in a private section of files written here.
+    moving_average = 'ema': the plain exponential average (zero_debias=False; what tf.keras and later keras versions do)."""
     fusable_act = True
     fusable_drop = True
 
-    def __init__(self, axis=-1, momentum=0.99, epsilon=1e-3, **kw):
+    def __init__(self, axis=-1, momentum=0.99, epsilon=1e-3, moving_average=None, **kw):
         Layer.__init__(self, **kw)
         if axis != -1:
             raise NotImplementedError('BatchNormalization(axis=%r)' % (axis,))
         self.momentum, self.epsilon = float(momentum), float(epsilon)
+        self.moving_average = moving_average or BN_MOVING_AVERAGE
+        if self.moving_average not in ('tf_zero_debias', 'ema'):
+            raise ValueError("BatchNormalization(moving_average=%r): 'tf_zero_debias' or 'ema'" % (moving_average,))
+        self.zero_debias = {}              # training-model name -> [biased_mean, biased_var (device fp32), local_step (int)]
+
+    def zero_debias_state(self, site):
+        st = self.zero_debias.get(site)
+        if st is None:
+            C = self.gamma.shape[0]
+            st = [torch.zeros(C, dtype=torch.float32, device=device()), torch.zeros(C, dtype=torch.float32, device=device()), 0]
+            self.zero_debias[site] = st
+        return st
 
     def build(self, input_shape):
         C = input_shape[-1]
@@ -263,8 +286,13 @@ class BatchNormalization(Layer):
         if ctx.dp is not None:
             ctx.dp.all_reduce_sum(sums)
             count *= ctx.dp.world_size
+        zd = None
+        if self.moving_average == 'tf_zero_debias':
+            st = self.zero_debias_state(ctx.site)
+            st[2] += 1
+            zd = (st[0], st[1], st[2])
         scale, shift, smean, sinv = ops.bn_finalize(sums, count, self.gamma.data, self.beta.data, self.epsilon, self.momentum,
-                                                    self.moving_mean.data, self.moving_variance.data)
+                                                    self.moving_mean.data, self.moving_variance.data, zd)
         mask, rate = None, 0.0
         if node.fused_drop is not None and node.fused_drop[0] > 0.0:
             rate, drop_layer = node.fused_drop

@@ -352,12 +352,19 @@ def bn_stats(x2d):
     return sums
 
 
-def bn_finalize(sums, count, gamma, beta, eps, momentum, moving_mean, moving_var):
+def bn_finalize(sums, count, gamma, beta, eps, momentum, moving_mean, moving_var, zero_debias=None):
+    """zero_debias = (biased_mean, biased_var, local_step): TF's assign_moving_average(zero_debias=True) with local_step the already
+    incremented update count; None: the plain exponential average."""
     Cc = gamma.numel()
     dev = gamma.device
     scale, shift, smean, sinv = (torch.empty((Cc,), dtype=torch.float32, device=dev) for _ in range(4))
-    _lib.call('gn_bn_finalize', _p(sums), float(count), _p(gamma), _p(beta), float(eps), float(momentum), _p(moving_mean), _p(moving_var),
-              _p(scale), _p(shift), _p(smean), _p(sinv), Cc, _stream())
+    if zero_debias is not None:
+        bm, bv, step = zero_debias
+        _lib.call('gn_bn_finalize_zero_debias', _p(sums), float(count), _p(gamma), _p(beta), float(eps), float(momentum), _p(moving_mean), _p(moving_var),
+                  _p(bm), _p(bv), int(step), _p(scale), _p(shift), _p(smean), _p(sinv), Cc, _stream())
+    else:
+        _lib.call('gn_bn_finalize', _p(sums), float(count), _p(gamma), _p(beta), float(eps), float(momentum), _p(moving_mean), _p(moving_var),
+                  _p(scale), _p(shift), _p(smean), _p(sinv), Cc, _stream())
     return scale, shift, smean, sinv
 
 

@@ -155,11 +155,21 @@ int gn_axpy(float* y, const float* x, float a, size_t n, void* stream);
 size_t gn_bn_stats_workspace(size_t rows, int C);
 int gn_bn_stats(const float* x, size_t rows, int C, double* sums, void* ws, size_t ws_bytes, void* stream);
 /* mean = S1/n, var = S2/n - mean^2 (biased); scale = gamma/sqrt(var+eps), shift = beta - mean*scale;
- * moving_mean = moving_mean*m + mean*(1-m); moving_var = moving_var*m + var*n/(n-(1+eps))*(1-m)  (keras 2.2.4).
+ * moving statistics as a plain exponential average, TF's assign_moving_average(zero_debias=False):
+ *   moving_mean -= (moving_mean - mean)*(1-m); moving_var -= (moving_var - var*n/(n-(1+eps)))*(1-m)   (keras normalization.py variance factor).
  * save_mean/save_invstd are kept for the backward pass. */
 int gn_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
                    float* moving_mean, float* moving_var, float* scale, float* shift,
                    float* save_mean, float* save_invstd, int C, void* stream);
+/* the same with the moving statistics updated as keras 2.2.4's TF backend does (K.moving_average_update ->
+ * tf moving_averages.assign_moving_average(x, value, momentum, zero_debias=True); bbhMahoGANy.py:223 momentum, :1248 the
+ * generator.predict that consumes them): biased_* are shadow accumulators that start at ZERO,
+ *   biased -= (biased - value)*(1-m);  moving -= moving - biased/(1 - m^local_step)
+ * with local_step the ALREADY incremented update count (1 for the first update): the moving statistic is the debiased average
+ * of the batch values and forgets its 0/1 initial value at the first update. */
+int gn_bn_finalize_zero_debias(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
+                               float* moving_mean, float* moving_var, float* biased_mean, float* biased_var, int local_step,
+                               float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream);
 /* inference phase: scale/shift from the moving statistics */
 int gn_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
                        float eps, float* scale, float* shift, int C, void* stream);

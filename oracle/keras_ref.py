@@ -197,10 +197,29 @@ def bn_train_fwd(x, gamma, beta, eps=BN_EPS):
 
 
 def bn_moving_update(moving_mean, moving_var, mean, var, n, momentum, eps=BN_EPS):
-    """moving = moving*m + value*(1-m); the variance is first scaled by n/(n-(1+eps))."""
+    """Plain exponential moving average, TF's assign_moving_average(zero_debias=False): v -= (v - value)*(1 - m); the variance is first
+    scaled by n/(n-(1+eps)) (keras 2.2.4 normalization.py, "sample variance")."""
     var_c = var * (n / (n - (1.0 + eps)))
-    return (moving_mean * momentum + mean * (1 - momentum),
-            moving_var * momentum + var_c * (1 - momentum))
+    d = 1.0 - momentum
+    return (moving_mean - (moving_mean - mean) * d, moving_var - (moving_var - var_c) * d)
+
+
+def bn_moving_update_zero_debias(moving_mean, moving_var, zd, mean, var, n, momentum, eps=BN_EPS):
+    """TF 1.12 moving_averages.assign_moving_average(variable, value, decay, zero_debias=True), which is what keras 2.2.4's TF backend
+    calls from K.moving_average_update (recollection of tensorflow_backend.py; neither source is in the container):
+        biased     -= (biased - value) * (1 - m)           # shadow accumulator, initialised to ZERO whatever the variable holds
+        local_step += 1
+        variable   -= variable - biased / (1 - m**local_step)
+    i.e. the moving statistic is the debiased average of the batch values seen so far and keeps no memory of its 0 / 1 initial value.
+    `zd` = [biased_mean, biased_var, local_step] (one per call site of the layer in TF; see layers.BatchNormalization).  Returns the new
+    (moving_mean, moving_var, zd)."""
+    var_c = var * (n / (n - (1.0 + eps)))
+    d = 1.0 - momentum
+    bm = zd[0] - (zd[0] - mean) * d
+    bv = zd[1] - (zd[1] - var_c) * d
+    t = zd[2] + 1
+    corr = 1.0 - momentum ** t
+    return (moving_mean - (moving_mean - bm / corr), moving_var - (moving_var - bv / corr), [bm, bv, t])
 
 
 def bn_train_bwd(dy, cache, gamma):

@@ -61,9 +61,11 @@ class Stack(object):
     """Parameters: self.params = list of arrays in keras weight order per layer
     (conv/dense: kernel, bias; bn: gamma, beta [+ moving_mean, moving_var in self.state])."""
 
-    def __init__(self, spec, rng=None, dtype=np.float64):
+    def __init__(self, spec, rng=None, dtype=np.float64, moving_average='tf_zero_debias'):
         self.spec = spec
         self.dtype = dtype
+        self.moving_average = moving_average      # 'tf_zero_debias' (keras 2.2.4 TF backend) | 'ema'; K.bn_moving_update*
+        self.zd = {}              # layer index -> [biased_mean, biased_var, local_step] (zero-debias shadow variables)
         self.params = []          # trainable, in order
         self.pidx = []            # per layer: indices into params
         self.state = {}           # layer index -> [moving_mean, moving_var]
@@ -79,6 +81,7 @@ class Stack(object):
             elif s[0] == 'bn':
                 idx = self._add(np.ones(s[1], dtype), np.zeros(s[1], dtype))
                 self.state[li] = [np.zeros(s[1], dtype), np.ones(s[1], dtype)]
+                self.zd[li] = [np.zeros(s[1], dtype), np.zeros(s[1], dtype), 0]
             self.pidx.append(idx)
 
     def _add(self, *arrs):
@@ -103,7 +106,11 @@ class Stack(object):
                     y, cache, mean, var = K.bn_train_fwd(x, p[0], p[1])
                     if update_moving:
                         n = x.size // x.shape[-1]
-                        self.state[li] = list(K.bn_moving_update(self.state[li][0], self.state[li][1], mean, var, n, momentum))
+                        if self.moving_average == 'ema':
+                            self.state[li] = list(K.bn_moving_update(self.state[li][0], self.state[li][1], mean, var, n, momentum))
+                        else:
+                            mm, mv, self.zd[li] = K.bn_moving_update_zero_debias(self.state[li][0], self.state[li][1], self.zd[li], mean, var, n, momentum)
+                            self.state[li] = [mm, mv]
                     self.tape.append(cache); x = y
                 else:
                     self.tape.append(None)
@@ -201,10 +208,10 @@ class PENet(object):
 # GAN: generator G, discriminator D, combined G -> MyLayer(event) -> D(frozen)
 # ----------------------------------------------------------------------------------------------
 class GAN(object):
-    def __init__(self, n_pix, event, rng=None, dtype=np.float64):
+    def __init__(self, n_pix, event, rng=None, dtype=np.float64, moving_average='tf_zero_debias'):
         rng = rng or np.random.RandomState(2)
         self.n_pix = n_pix
-        self.G = Stack(generator_spec(n_pix), rng, dtype)
+        self.G = Stack(generator_spec(n_pix), rng, dtype, moving_average)
         self.D = Stack(discriminator_spec(n_pix), rng, dtype)
         self.event = np.asarray(event, dtype).reshape(n_pix, 1)
         self.opt_g = AdamState(self.G.params)      # signal_discriminator_on_generator (:1107), D frozen

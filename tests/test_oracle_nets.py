@@ -265,3 +265,27 @@ def test_pe_train_step_matches_torch():
     lr_t = 9e-5 * np.sqrt(1 - 0.999) / (1 - 0.5)
     for p_new, p_old, g in zip(pe.mc.params + pe.q.params, p0, gts):
         close(p_new, p_old - lr_t * 0.5 * g / (np.sqrt(0.001 * g * g) + 1e-7), 1e-9)
+
+
+def test_bn_zero_debias_is_the_debiased_average_of_the_batch_values():
+    """oracle/keras_ref.bn_moving_update_zero_debias restates TF 1.12's assign_moving_average(zero_debias=True): after t updates the
+    moving value equals (1-m) * sum_k m^(t-k) v_k / (1 - m^t) whatever it was initialised to; the plain form keeps m^t of its start."""
+    from oracle import keras_ref as K
+    rng = np.random.RandomState(0)
+    C, n, m = 5, 40, 0.99
+    mm, mv = np.zeros(C), np.ones(C)
+    zd = [np.zeros(C), np.zeros(C), 0]
+    em, ev = np.zeros(C), np.ones(C)
+    means, vars_ = [], []
+    for t in range(1, 31):
+        mean, var = rng.randn(C), rng.rand(C) + 0.5
+        means.append(mean); vars_.append(var * n / (n - (1 + K.BN_EPS)))
+        mm, mv, zd = K.bn_moving_update_zero_debias(mm, mv, zd, mean, var, n, m)
+        em, ev = K.bn_moving_update(em, ev, mean, var, n, m)
+        w = np.array([(1 - m) * m ** (t - k) for k in range(1, t + 1)])
+        assert np.allclose(mm, (w[:, None] * np.array(means)).sum(0) / (1 - m ** t), rtol=1e-12, atol=1e-14)
+        assert np.allclose(mv, (w[:, None] * np.array(vars_)).sum(0) / (1 - m ** t), rtol=1e-12)
+        assert np.allclose(ev, m ** t * 1.0 + (w[:, None] * np.array(vars_)).sum(0), rtol=1e-12)
+        if t == 1:
+            assert np.allclose(mv, vars_[0], rtol=1e-13)
+    assert zd[2] == 30
