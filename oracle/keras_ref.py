@@ -75,7 +75,7 @@ def conv1d_bwd(x, W, dy, stride=1, padding='valid'):
     for j in range(k):
         sl = slice(j, j + stride * (out - 1) + 1, stride)
         xs = xp[:, sl]
-        dW[j] = np.einsum('btc,btd->cd', xs, dy)
+        dW[j] = xs.reshape(-1, Cin).T @ dy.reshape(-1, Cout)          # sum over (b, t): one dgemm
         dxp[:, sl] += dy @ W[j].T
     dx = dxp[:, pl:pl + x.shape[1]]
     db = dy.sum(axis=(0, 1))
@@ -125,7 +125,7 @@ def conv2d_bwd(x, W, dy, strides=(1, 1), padding='same'):
         for j in range(kw):
             s0 = slice(i, i + sh * (oh - 1) + 1, sh)
             s1 = slice(j, j + sw * (ow - 1) + 1, sw)
-            dW[i, j] = np.einsum('bhwc,bhwd->cd', xp[:, s0, s1], dy)
+            dW[i, j] = xp[:, s0, s1].reshape(-1, Cin).T @ dy.reshape(-1, Cout)
             dxp[:, s0, s1] += dy @ W[i, j].T
     return dxp[:, pt:pt + H, pl:pl + Wd], dW, dy.sum(axis=(0, 1, 2))
 
