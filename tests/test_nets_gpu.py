@@ -65,8 +65,10 @@ def masks_by_name(stack, masks, layers):
     return {l.name: masks[li].astype(np.uint8) for l, li in zip(drops, idx)}
 
 
-@pytest.mark.parametrize("n_pix,B", [(128, 6), (256, 5)])
-def test_pe_train_on_batch_matches_oracle(n_pix, B):
+@pytest.mark.parametrize("n_pix,B,steps", [(128, 6, 3), (256, 5, 3),
+                                          (2048, 4, 2),        # BASELINE configs 1-4 size: the 64 000- and 519 168-input Dense heads, 2048-row convs
+                                          (4096, 2, 1)])       # BASELINE config 5 size (129 536- and 1 043 456-input heads)
+def test_pe_train_on_batch_matches_oracle(n_pix, B, steps):
     from gennet_amd import bbh
     from gennet_amd.engine import Adam
     rng = np.random.RandomState(n_pix)
@@ -85,7 +87,7 @@ def test_pe_train_on_batch_matches_oracle(n_pix, B):
     p_ref = ref.predict(x)
     p = model.predict(x)
     assert rel(p[0], p_ref[0]) < 2e-5 and rel(p[1], p_ref[1]) < 2e-5
-    for step in range(3):
+    for step in range(steps):
         out_ref = ref.train_on_batch(x, y_mc, y_q)
         out = model.train_on_batch(x, [y_mc, y_q])
         assert len(out) == 5                                          # [total, mc_loss, q_loss, mc_acc, q_acc]
@@ -101,6 +103,10 @@ def test_pe_train_on_batch_matches_oracle(n_pix, B):
     ws = [p_.data.cpu().numpy() for l in with_params for p_ in l.params]
     for w, wr in zip(ws, ref.mc.params + ref.q.params):
         assert np.abs(w - wr).max() <= 1e-4 * np.abs(wr).max() + 0.01 * 3 * 9e-5
+    # predict after the updates: the whole graph again, with the updated weights
+    p_ref = ref.predict(x)
+    p = model.predict(x)
+    assert rel(p[0], p_ref[0]) < 5e-5 and rel(p[1], p_ref[1]) < 5e-5
 
 
 def _build_gan(n_pix, rng):
@@ -118,12 +124,14 @@ def _build_gan(n_pix, rng):
     return ref, nets, event
 
 
-def test_gan_iteration_matches_oracle():
-    """One full GAN iteration (bbhMahoGANy.py:1241-1299) with injected masks: D step on [real | fake], then G step through the
-    frozen D; then a second iteration to exercise the moving statistics and both Adam states."""
+@pytest.mark.parametrize("n_pix,B,iters", [(64, 4, 2),
+                                          (2048, 4, 1)])       # BASELINE size: Dense(100 -> 262 144) + feature-BN over B, the 524 288-input head,
+                                                               # channel-BN over 2048*B rows, fused dgrad epilogues, fold_bn predict inside the graph
+def test_gan_iteration_matches_oracle(n_pix, B, iters):
+    """Full GAN iterations (bbhMahoGANy.py:1241-1299) with injected masks: D step on [real | fake], then G step through the
+    frozen D; at the small size a second iteration exercises the moving statistics and both Adam states."""
     from gennet_amd import bbh
     from gennet_amd.engine import to_device
-    n_pix, B = 64, 4
     rng = np.random.RandomState(3)
     ref, nets, event = _build_gan(n_pix, rng)
     ev_dev = to_device(event.reshape(-1))
@@ -131,7 +139,7 @@ def test_gan_iteration_matches_oracle():
     # the combined model trains exactly the generator's weights; the discriminator model its own
     assert set(id(p) for p in DG._train_params) == set(id(p) for l in G.layers for p in l.params)
     assert set(id(p) for p in D._train_params) == set(id(p) for l in D.layers for p in l.params)
-    for it in range(2):
+    for it in range(iters):
         z = f32(rng.uniform(-1, 1, (B, 100)))
         fake_ref = ref.generate(z)
         fake = G.predict(z)
@@ -171,6 +179,9 @@ def test_gan_iteration_matches_oracle():
         ws = [p.data.cpu().numpy() for l in model.layers for p in l.params]
         for w, wr in zip(ws, st.params):
             assert np.abs(w - wr).max() <= 2e-4 * np.abs(wr).max() + 0.02 * 2 * 9e-5      # see the Adam note in the PE test
+    # generator.predict after the update(s): moving statistics through fold_bn inside the full graph
+    z3 = f32(rng.uniform(-1, 1, (B, 100)))
+    assert rel(G.predict(z3), ref.generate(z3)) < 1e-4
     bns = [l for l in G.layers if hasattr(l, 'moving_mean')]
     bn_idx = [li for li, s in enumerate(ref.G.spec) if s[0] == 'bn']
     for l, li in zip(bns, bn_idx):

@@ -63,3 +63,55 @@ def test_gan_loop_runs_stably_and_discriminator_learns():
             assert np.isfinite(mv).all() and np.isfinite(mm).all() and (mv > 0).all()
     fake = nets.generator.predict(np.random.RandomState(2).uniform(-1, 1, (8, 100)).astype(np.float32))
     assert fake.shape == (8, n_pix, 1) and np.isfinite(fake).all()
+
+
+def test_config5_both_loops_at_n_pix_4096_with_synthesis_in_the_loop():
+    """BASELINE configs[4]: srate 4096, templates synthesised on the GPU inside the training loop (templates.OnlineBank ->
+    bbh.pe_train_step_online; the GAN loop takes its real half from the same generator).  No oracle at this size for the loops as a
+    whole (the PE step alone is compared at 4096 in test_nets_gpu); size-independent properties: shapes (generator Dense 100 -> 524 288,
+    q-branch head of 1 043 456 inputs), finite losses, keras-ordered outputs, BN moving statistics updated and finite, D frozen in the
+    G step, the CNN loss goes down on a repeated batch."""
+    import torch
+    from gennet_amd import bbh, engine, ops, templates as T
+    fs = 4096
+    f = np.arange(fs * 2 + 1) * 0.25
+    psd = 1e-46 * ((np.maximum(f, 10.0) / 150.0) ** -4.0 + 2.0 + 2.0 * (f / 150.0) ** 2.0)
+    psd[f < 10.0] = 0.0
+    ob = T.OnlineBank(fs, 4, psd, seed=11, noise='coloured')
+    engine.set_init_seed(4); engine.set_device_seed(5)
+    event = np.random.RandomState(1).randn(fs, 1).astype(np.float32)
+    nets = bbh.build_and_compile(event, fs)
+    G, D, DG, PE = nets.generator, nets.signal_discriminator, nets.signal_discriminator_on_generator, nets.signal_pe
+    dense = [l for l in G.layers if l.weights][0]
+    assert dense.kernel.shape == (100, 256 * fs // 2) and G.output_shape == (None, fs, 1)
+    heads = [l for l in PE.layers if l.__class__.__name__ == 'Dense']
+    assert [h.kernel.shape for h in heads] == [(129536, 1), (1043456, 1)]
+    heads[0].bias.assign(np.array([25.0], np.float32)); heads[1].bias.assign(np.array([0.6], np.float32))     # inside relu / relu(max 1)'s active range
+    B = 8
+    first = bbh.pe_train_step_online(PE, ob, B)
+    assert len(first) == 5 and np.isfinite(first).all()
+    x, y = ob.draw(B)
+    assert x.shape == (B, fs) and y.shape == (B, 2)
+    xs = x.reshape(B, fs, 1)
+    ys = [y[:, 0].contiguous(), y[:, 1].contiguous()]
+    losses = [PE.train_on_batch(xs, ys)[0] for _ in range(6)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    p = PE.predict(x.cpu().numpy().reshape(B, fs, 1))
+    assert p[0].shape == (B, 1) and p[1].shape == (B, 1) and np.all(p[1] >= 0) and np.all(p[1] <= 1)
+    # GAN iteration with the real half synthesised in the loop
+    bank = bbh.DeviceBank(*ob.draw(16))
+    ev = engine.to_device(event.reshape(-1))
+    d_before = [q.data.clone() for l in D.layers for q in l.params]
+    r = bbh.gan_train_step(nets, bank, ev, 4, predict_batch=4)
+    assert len(r) == 4 and np.isfinite(r).all() and 0.0 <= r[1] <= 1.0 and 0.0 <= r[3] <= 1.0
+    assert any(not torch.equal(a, q.data) for a, q in zip(d_before, [q for l in D.layers for q in l.params]))       # the D step moved D
+    d_mid = [q.data.clone() for l in D.layers for q in l.params]
+    z = ops.fill_uniform((4, 100), -1.0, 1.0, 3, 0, engine.device())
+    DG.train_on_batch(z, np.ones(4, np.float32))
+    assert all(torch.equal(a, q.data) for a, q in zip(d_mid, [q for l in D.layers for q in l.params]))              # frozen in the G step
+    for l in G.layers:
+        if getattr(l, 'is_batchnorm', False):
+            assert torch.isfinite(l.moving_mean.data).all() and torch.isfinite(l.moving_variance.data).all()
+            assert not torch.equal(l.moving_variance.data, torch.ones_like(l.moving_variance.data))
+    fake = G.predict_device(z, batch_size=4)
+    assert fake.shape == (4, fs, 1) and torch.isfinite(fake).all()
