@@ -186,6 +186,7 @@ class RunContext(object):
     def __init__(self, training, dp=None, dropout_masks=None, train_params=None, site=None):
         self.training = training
         self.site = site                   # name of the model whose train_on_batch runs (BatchNormalization keeps per-site state)
+        self.capture = None                # testing hook: dict that receives {layer name: output tensor} of every executed node
         self.dp = dp
         self.dropout_masks = dropout_masks or {}
         self.train_ids = None if train_params is None else set(id(p) for p in train_params)
@@ -576,6 +577,8 @@ class Model(Layer):
                 vals[n.index] = xs[0]
                 continue
             vals[n.index] = n.layer.forward(ctx, n, xs[0] if len(xs) == 1 else xs)
+            if ctx.capture is not None:
+                ctx.capture[n.layer.name] = vals[n.index]
         return [vals[i] for i in self.output_ids]
 
     def _backward(self, out_grads, ctx):
@@ -685,9 +688,10 @@ class Model(Layer):
         assert len(ys) == n_out, 'model has %d outputs' % n_out
         return [to_device(a).reshape(B, 1) for a in ys]
 
-    def train_on_batch(self, x, y, dropout_masks=None):
+    def train_on_batch(self, x, y, dropout_masks=None, capture=None):
         """One optimizer step.  Returns [loss, (per-output losses,) (accuracies)] as python floats, keras order.
-        `dropout_masks` ({dropout layer name: uint8 keep mask}) is a testing hook that replaces the Philox draws."""
+        `dropout_masks` ({dropout layer name: uint8 keep mask}) is a testing hook that replaces the Philox draws; `capture` (a dict) is
+        another: it receives {layer name: output tensor} of every executed layer (outputs include the fused activation / dropout)."""
         if self.optimizer is None:
             raise RuntimeError('compile() the model before train_on_batch')
         self._ensure_bound()
@@ -698,6 +702,7 @@ class Model(Layer):
         world = dp.world_size if dp is not None else 1
         masks = {k: to_device(v, torch.uint8) for k, v in (dropout_masks or {}).items()}
         ctx = RunContext(True, dp, masks, self._train_params, self.name)
+        ctx.capture = capture
         outs = self._forward(xs, ctx)
         dps, stats = [], []
         for p, t, kind in zip(outs, ys, self._losses):

@@ -89,9 +89,18 @@ class Stack(object):
         self.params.extend(arrs)
         return list(range(i0, i0 + len(arrs)))
 
-    def forward(self, x, training, masks=None, momentum=0.99, update_moving=True):
-        """masks: dict layer-index -> keep mask for dropout layers (training only)."""
+    DECISION_BAND = 1e-5      # |pre-activation| <= band * max|pre-activation|: the piecewise-linear branch is "within rounding of the kink"
+
+    def forward(self, x, training, masks=None, momentum=0.99, update_moving=True, decisions=None):
+        """masks: dict layer-index -> keep mask for dropout layers (training only).
+        decisions: dict act-layer-index -> the fp32 implementation's OUTPUT of that relu / relu_max / LeakyReLU layer (zeros from a
+        following dropout allowed).  ReLU-type derivatives are discontinuous: an element whose pre-activation is within fp32 rounding
+        of zero can legitimately take the other branch in fp32, and with millions of activations at full size a few do -- each flips a
+        whole gradient value.  Like dropout masks, those branch decisions are therefore INJECTED: inside the band the oracle takes the
+        implementation's branch; outside the band its own, and a disagreement there is counted in self.decision_stats[li] =
+        (elements in band, flipped in band, disagreements outside band) -- the tests require the last to be 0."""
         self.tape = []
+        self.decision_stats = {}
         for li, s in enumerate(self.spec):
             p = [self.params[i] for i in self.pidx[li]]
             kind = s[0]
@@ -116,7 +125,20 @@ class Stack(object):
                     self.tape.append(None)
                     x = K.bn_infer_fwd(x, p[0], p[1], self.state[li][0], self.state[li][1])
             elif kind == 'act':
-                x = K.act_fwd(x, s[1], s[2]); self.tape.append(x)
+                pre = x
+                x = K.act_fwd(x, s[1], s[2])
+                if decisions is not None and li in decisions and s[1] in ('relu', 'relu_max', 'leaky'):
+                    gy = np.asarray(decisions[li]).reshape(pre.shape)
+                    known = (gy != 0) if s[1] == 'leaky' else np.ones(pre.shape, bool)       # leaky: 0 = dropped afterwards, no information
+                    theirs = gy > 0
+                    band = np.abs(pre) <= self.DECISION_BAND * np.abs(pre).max()
+                    mism = known & ((pre > 0) != theirs)
+                    flip = mism & band
+                    self.decision_stats[li] = (int(band.sum()), int(flip.sum()), int((mism & ~band).sum()))
+                    if flip.any():
+                        x = x.copy()
+                        x[flip] = np.where(theirs[flip], 1e-300, 0.0 if s[1] != 'leaky' else -1e-300)
+                self.tape.append(x)
             elif kind == 'drop':
                 if training:
                     m = masks[li]
@@ -192,10 +214,10 @@ class PENet(object):
     def predict(self, x):
         return [self.mc.forward(x, False), self.q.forward(x, False)]
 
-    def train_on_batch(self, x, y_mc, y_q):
-        """Returns [total, mc_loss, q_loss, mc_acc, q_acc] (keras multi-output order)."""
+    def train_on_batch(self, x, y_mc, y_q, decisions=(None, None)):
+        """Returns [total, mc_loss, q_loss, mc_acc, q_acc] (keras multi-output order).  decisions: (mc, q) dicts for Stack.forward."""
         y_mc = np.asarray(y_mc, x.dtype).reshape(-1, 1); y_q = np.asarray(y_q, x.dtype).reshape(-1, 1)
-        pm = self.mc.forward(x, True); pq = self.q.forward(x, True)
+        pm = self.mc.forward(x, True, decisions=decisions[0]); pq = self.q.forward(x, True, decisions=decisions[1])
         lm, dm = K.mse_loss(pm, y_mc); lq, dq = K.mse_loss(pq, y_q)
         out = [lm + lq, lm, lq, K.binary_accuracy(pm, y_mc), K.binary_accuracy(pq, y_q)]
         _, gm = self.mc.backward(dm); _, gq = self.q.backward(dq)
@@ -221,22 +243,22 @@ class GAN(object):
         """generator.predict: inference phase (moving-stat BN, no dropout)."""
         return self.G.forward(z, False)
 
-    def d_train_on_batch(self, sX, sy, masks):
+    def d_train_on_batch(self, sX, sy, masks, decisions=None):
         sy = np.asarray(sy, sX.dtype).reshape(-1, 1)
-        p = self.D.forward(sX, True, masks)
+        p = self.D.forward(sX, True, masks, decisions=decisions)
         loss, dp = K.bce_loss(p, sy)
         _, g = self.D.backward(dp)
         self.last_d_grads = g
         self.opt_d.step(self.D.params, g)
         return [loss, K.binary_accuracy(p, sy)]
 
-    def g_train_on_batch(self, z, sy, g_masks, d_masks):
+    def g_train_on_batch(self, z, sy, g_masks, d_masks, d_decisions=None):
         """combined model: learning phase 1 for the whole graph (G batch-stat BN + dropout, D dropout active),
         gradients only into G (D collected as frozen at compile time)."""
         sy = np.asarray(sy, z.dtype).reshape(-1, 1)
         x = self.G.forward(z, True, g_masks)
         img = K.mylayer_fwd(x, self.event)
-        p = self.D.forward(img, True, d_masks)
+        p = self.D.forward(img, True, d_masks, decisions=d_decisions)
         loss, dp = K.bce_loss(p, sy)
         dimg, _ = self.D.backward(dp)
         dx = K.mylayer_bwd(dimg)
