@@ -1,0 +1,342 @@
+// Fused template synthesiser: ONE workgroup per template goes from (m1, m2, idx) to the cropped detector strain without touching HBM
+// in between (gw_template_maker.py:507-565 + the crop of sim_data :695).  The unfused entry points of synth.hip (chirp spectrum ->
+// irFFT x2 -> align/crop) stay for whiten_data / gen_noise / the single-template gen_bbh surface; they move ~0.5 MB per template
+// through HBM for 8 KB of output.  Here HBM sees the whitening scale (L2-resident, shared by every block), the twiddle table and
+// the output row.
+//
+// Math.  Both polarisations come from the same complex spectrum S[k] = h~(f_k) * whiten(f_k) (k = 1..M-1, M = N/2; S[0] = 0):
+//     h+~ = fp * S,  hx~ = -i * ci * S       (fp = (1 + cos^2 iota)/2, ci = cos iota)
+// so with the one-sided complex series a[n] = sum_{k<M} S[k] exp(+2 pi i k n / N):
+//     irfft(h+~)[n] = fp/N * (2 Re a[n] + Re S[M] (-1)^n),   irfft(hx~)[n] = ci/N * (2 Im a[n] + Im S[M] (-1)^n)
+// and a[] splits by sample parity into two M-point complex inverse FFTs: a[2n'] = IFFT_M(S)[n'], a[2n'+1] = IFFT_M(S * W_N^k)[n'].
+// The block keeps its M spectrum bins in registers (the cbrt / pow / sincos are evaluated once), runs the M-point transform in LDS
+// (in-place decimation in time, radix-8 stages plus one radix-2/4 stage: 4-5 barriers per transform instead of 12-13) and makes
+// three passes over the ONE LDS buffer: even samples (arg-max only), odd samples (arg-max, emit the odd half of the crop), even
+// samples again (emit the even half) -- a third transform is cheaper than a second 64 KiB buffer, which would halve the blocks per CU.
+// ref_idx = argmax(h+^2 + hx^2) over the rolled series (first maximum), slide = ref_idx - idx - peak_off with python slice
+// semantics, zero fill past the end, exactly as align_crop_kernel (synth.hip) does.
+#include "common.h"
+
+namespace gn {
+
+struct ChirpCoeffsF {
+  double piM, f_merg, f_ring, sigma, f_cut, amp0, t0, wnorm;
+  double psi[6];
+  double nyq_re, nyq_im;
+};
+
+struct SynthArgs {
+  const double* m1;
+  const double* m2;
+  const int32_t* idx;
+  const double* scale;      // whitening scale per bin (Nf = M + 1)
+  const double2* W;         // exp(+2 pi i k / N), k < M
+  double* out64;            // (nb, crop_len) or NULL
+  float* out32;             // (nb, crop_len) or NULL
+  int32_t* ref_out;         // (nb,) or NULL
+  int nb, N, roll, crop0, crop_len, peak_off;
+  double df, f_low, dist_mpc, iota, phi0, Fp, Fc, g;
+};
+
+__constant__ double kFf[4][3] = {{2.9740e-1, 4.4810e-2, 9.5560e-2}, {5.9411e-1, 8.9794e-2, 1.9111e-1}, {5.0801e-1, 7.7515e-2, 2.2369e-2}, {8.4845e-1, 1.2848e-1, 2.7299e-1}};
+__constant__ double kPsif[6][3] = {{1.7516e-1, 7.9483e-2, -7.2390e-2}, {-5.1571e1, -1.7595e1, 1.3253e1}, {6.5866e2, 1.7803e2, -1.5972e2},
+                                   {-3.9031e3, -7.7493e2, 8.8195e2},   {-2.4874e4, -1.4892e3, 4.4588e3}, {2.5196e4, 3.3970e2, -3.9573e3}};
+__constant__ int kOrdf[6] = {0, 2, 3, 4, 6, 7};
+
+static constexpr double kPiF = 3.141592653589793238462643383279502884;
+static constexpr double kMtsunF = 4.925491025543576e-06;
+static constexpr double kMpcSecF = 3.085677581491367e22 / 299792458.0;
+
+// same closed form as chirp_coeffs / chirp_fd_kernel of synth.hip (this project's own PhenomA-form model, oracle/synth_ref.chirp_fd)
+__device__ void chirp_coeffs_f(double m1, double m2, double dist_mpc, ChirpCoeffsF* c) {
+  const double Mt = m1 + m2;
+  const double eta = m1 * m2 / (Mt * Mt);
+  c->piM = kPiF * Mt * kMtsunF;
+  double fk[4];
+  for (int i = 0; i < 4; ++i) fk[i] = (kFf[i][0] * eta * eta + kFf[i][1] * eta + kFf[i][2]) / c->piM;
+  c->f_merg = fk[0]; c->f_ring = fk[1]; c->sigma = fk[2]; c->f_cut = fk[3];
+  for (int i = 0; i < 6; ++i) c->psi[i] = (kPsif[i][0] * eta * eta + kPsif[i][1] * eta + kPsif[i][2]) / eta;
+  c->amp0 = pow(Mt * kMtsunF, 5.0 / 6.0) / (dist_mpc * kMpcSecF * pow(kPiF, 2.0 / 3.0)) * sqrt(5.0 * eta / 24.0) * pow(c->f_merg, -7.0 / 6.0);
+  const double v = pow(c->piM * c->f_ring, 1.0 / 3.0);
+  double dsum = 0.0;
+  for (int i = 0; i < 6; ++i) dsum += c->psi[i] * ((kOrdf[i] - 5) / 3.0) * pow(v, (double)(kOrdf[i] - 5)) / c->f_ring;
+  c->t0 = -dsum / (2.0 * kPiF);
+  c->wnorm = (kPiF * c->sigma / 2.0) * pow(c->f_ring / c->f_merg, -2.0 / 3.0);
+}
+
+// S[k] = h~(k df) * scale[k]  (complex; zero outside [f_low, f_cut) and at k = 0)
+__device__ __forceinline__ double2 chirp_bin(const ChirpCoeffsF& c, int k, double df, double f_low, double phi0, const double* __restrict__ scale) {
+  const double f = k * df;
+  if (!(f >= f_low && f > 0.0 && f < c.f_cut && k > 0)) return make_double2(0.0, 0.0);
+  const double v = cbrt(c.piM * f);
+  const double v2 = v * v, iv = 1.0 / v;
+  const double iv2 = iv * iv;
+  const double pw[6] = {iv2 * iv2 * iv, iv2 * iv, iv2, iv, v, v2};
+  double phase = 2.0 * kPiF * f * c.t0 + 2.0 * phi0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) phase = phase + c.psi[i] * pw[i];
+  const double r = f / c.f_merg;
+  double shape;
+  if (f < c.f_merg) shape = pow(r, -7.0 / 6.0);
+  else if (f < c.f_ring) shape = pow(r, -2.0 / 3.0);
+  else shape = c.wnorm * ((1.0 / (2.0 * kPiF)) * c.sigma / ((f - c.f_ring) * (f - c.f_ring) + 0.25 * c.sigma * c.sigma));
+  const double amp = c.amp0 * shape;
+  double sn, cs;
+  sincos(phase, &sn, &cs);
+  const double w = scale[k];
+  return make_double2(amp * cs * w, -amp * sn * w);       // h = amp * exp(-i phase)
+}
+
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cmulf(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 muli(double2 a) { return make_double2(-a.y, a.x); }         // i * a
+
+// inverse (exp(+i ..)) 8-point DFT, natural order in and out
+__device__ __forceinline__ void dft8_inv(double2 (&a)[8]) {
+  const double r = 0.70710678118654752440;
+  const double2 t0 = cadd(a[0], a[4]), t1 = csub(a[0], a[4]), t2 = cadd(a[2], a[6]), t3 = csub(a[2], a[6]);
+  const double2 t4 = cadd(a[1], a[5]), t5 = csub(a[1], a[5]), t6 = cadd(a[3], a[7]), t7 = csub(a[3], a[7]);
+  const double2 e0 = cadd(t0, t2), e1 = csub(t0, t2), e2 = cadd(t4, t6), e3 = muli(csub(t4, t6));
+  a[0] = cadd(e0, e2); a[4] = csub(e0, e2); a[2] = cadd(e1, e3); a[6] = csub(e1, e3);
+  const double2 v1 = make_double2((t5.x - t5.y) * r, (t5.x + t5.y) * r), v2 = muli(t3), v3 = make_double2((-t7.x - t7.y) * r, (t7.x - t7.y) * r);
+  const double2 f0 = cadd(t1, v2), f1 = csub(t1, v2), f2 = cadd(v1, v3), f3 = muli(csub(v1, v3));
+  a[1] = cadd(f0, f2); a[5] = csub(f0, f2); a[3] = cadd(f1, f3); a[7] = csub(f1, f3);
+}
+
+// LDS image: one complex slot of padding after every 8 (the span-1 stage reads 8 consecutive values per thread: 144-byte lane stride
+// instead of 128 keeps ds_read_b128 conflict-free; later stages read consecutive values across lanes)
+__device__ __forceinline__ int PH(int i) { return i + (i >> 3); }
+
+// Stage radices: LOGM/3 radix-8 stages (span 1, 8, 64, ...) then one radix-2 (LOGM % 3 == 1) or radix-4 (== 2) stage.  Storage position
+// of input bin k for the in-place decimation-in-time transform = mixed-radix digit reversal: the LAST stage's digit is the least
+// significant digit of k and selects the outermost block.
+template <int LOGM>
+__device__ __forceinline__ int digitrev(int k) {
+  constexpr int NR8 = LOGM / 3, REM = LOGM % 3;
+  int p = 0;
+  if (REM) {
+    p = (k & ((1 << REM) - 1)) << (3 * NR8);
+    k >>= REM;
+  }
+#pragma unroll
+  for (int j = NR8 - 1; j >= 0; --j) {
+    p += (k & 7) << (3 * j);
+    k >>= 3;
+  }
+  return p;
+}
+
+template <int LOGM, int NT>
+__device__ void ifft_lds(double2* d, const double2* __restrict__ W) {
+  constexpr int M = 1 << LOGM, NR8 = LOGM / 3, REM = LOGM % 3;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int s = 0; s < NR8; ++s) {
+    const int lspan = 3 * s, span = 1 << lspan;
+    const int lstep = LOGM + 1 - lspan - 3;                  // table step N / (8 span), N = 2 M
+    for (int bf = tid; bf < M / 8; bf += NT) {
+      const int g = bf >> lspan, pos = bf & (span - 1);
+      const int base = (g << (lspan + 3)) + pos;
+      double2 a[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a[q] = d[PH(base + (q << lspan))];
+      if (s > 0) {
+        const int i1 = pos << lstep;
+        const double2 w1 = W[i1], w2 = W[2 * i1], w4 = W[4 * i1];
+        const double2 w3 = cmulf(w1, w2);
+        a[1] = cmulf(a[1], w1); a[2] = cmulf(a[2], w2); a[3] = cmulf(a[3], w3); a[4] = cmulf(a[4], w4);
+        a[5] = cmulf(a[5], cmulf(w4, w1)); a[6] = cmulf(a[6], cmulf(w4, w2)); a[7] = cmulf(a[7], cmulf(w4, w3));
+      }
+      dft8_inv(a);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) d[PH(base + (q << lspan))] = a[q];
+    }
+    __syncthreads();
+  }
+  if (REM == 1) {
+    constexpr int lspan = 3 * NR8, span = 1 << lspan;        // last stage: span = M / 2, table step N / (2 span) = 2
+    for (int bf = tid; bf < M / 2; bf += NT) {
+      const int pos = bf & (span - 1);
+      const double2 x0 = d[PH(pos)], x1 = cmulf(d[PH(pos + span)], W[pos << 1]);
+      d[PH(pos)] = cadd(x0, x1);
+      d[PH(pos + span)] = csub(x0, x1);
+    }
+    __syncthreads();
+  } else if (REM == 2) {
+    constexpr int lspan = 3 * NR8, span = 1 << lspan;        // last stage: span = M / 4, table step N / (4 span) = 2
+    for (int bf = tid; bf < M / 4; bf += NT) {
+      const int pos = bf & (span - 1);
+      const int i1 = pos << 1;
+      const double2 w1 = W[i1], w2 = W[2 * i1];
+      const double2 u0 = d[PH(pos)], u1 = cmulf(d[PH(pos + span)], w1), u2 = cmulf(d[PH(pos + 2 * span)], w2), u3 = cmulf(d[PH(pos + 3 * span)], cmulf(w1, w2));
+      const double2 s02 = cadd(u0, u2), d02 = csub(u0, u2), s13 = cadd(u1, u3), d13 = muli(csub(u1, u3));
+      d[PH(pos)] = cadd(s02, s13);
+      d[PH(pos + span)] = cadd(d02, d13);
+      d[PH(pos + 2 * span)] = csub(s02, s13);
+      d[PH(pos + 3 * span)] = csub(d02, d13);
+    }
+    __syncthreads();
+  }
+}
+
+template <int LOGM, int NT>
+__global__ __launch_bounds__(NT, 2) void synth_fused_kernel(SynthArgs a) {
+  constexpr int M = 1 << LOGM, N = 2 * M, KPT = M / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double2* d = reinterpret_cast<double2*>(smem_raw);                                           // PH(M) padded complex values
+  ChirpCoeffsF* cf = reinterpret_cast<ChirpCoeffsF*>(smem_raw + (size_t)(M + M / 8) * sizeof(double2));
+  double* rv = reinterpret_cast<double*>(cf + 1);                                              // per-wave arg-max partials
+  int* ri = reinterpret_cast<int*>(rv + 16);
+  const int tid = threadIdx.x, b = blockIdx.x;
+
+  if (tid == 0) {
+    chirp_coeffs_f(a.m1[b], a.m2[b], a.dist_mpc, cf);
+    const double2 nq = chirp_bin(*cf, M, a.df, a.f_low, a.phi0, a.scale);                      // Nyquist bin: irfft uses its real part only
+    cf->nyq_re = nq.x; cf->nyq_im = nq.y;
+  }
+  __syncthreads();
+  const ChirpCoeffsF c = *cf;
+
+  double2 S[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) S[j] = chirp_bin(c, tid + j * NT, a.df, a.f_low, a.phi0, a.scale);
+
+  const double ci = cos(a.iota);
+  const double fpn = 0.5 * (1.0 + ci * ci) / (double)N, cin = ci / (double)N;
+  double best = -1.0;
+  int bi = 0x7fffffff;
+
+  auto load_pass = [&](int parity) {
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int k = tid + j * NT;
+      double2 v = S[j];
+      if (parity) v = cmulf(v, a.W[k]);
+      d[PH(digitrev<LOGM>(k))] = v;
+    }
+    __syncthreads();
+  };
+  auto argmax_pass = [&](int parity) {
+    const double sg = parity ? -1.0 : 1.0;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int np = tid + j * NT;
+      const double2 z = d[PH(np)];
+      const double hp = fpn * (2.0 * z.x + c.nyq_re * sg), hc = cin * (2.0 * z.y + c.nyq_im * sg);
+      const double pw = hp * hp + hc * hc;
+      int n = 2 * np + parity - a.roll;                       // rolled index: rolled[n] = series[(n + roll) mod N]
+      if (n < 0) n += N;
+      if (pw > best || (pw == best && n < bi)) { best = pw; bi = n; }
+    }
+  };
+  long start = 0;
+  auto emit = [&](int parity) {
+    const double sg = parity ? -1.0 : 1.0;
+    for (int n = tid; n < a.crop_len; n += NT) {
+      const long sidx = start + a.crop0 + n;
+      int s = (int)((sidx + a.roll) % N);
+      if ((s & 1) != parity && sidx < N) continue;            // the other pass owns this sample (zero fill is written by the odd pass)
+      double v = 0.0;
+      if (sidx < N) {
+        const double2 z = d[PH(s >> 1)];
+        const double hp = fpn * (2.0 * z.x + c.nyq_re * sg), hc = cin * (2.0 * z.y + c.nyq_im * sg);
+        const double t1 = hp * a.Fp, t2 = hc * a.Fc;
+        v = (t1 + t2) * a.g;
+      } else if (!parity) {
+        continue;
+      }
+      const size_t o = (size_t)b * a.crop_len + n;
+      if (a.out64) a.out64[o] = v;
+      if (a.out32) a.out32[o] = (float)v;
+    }
+  };
+
+  // pass 1: even samples, arg-max only
+  load_pass(0);
+  ifft_lds<LOGM, NT>(d, a.W);
+  argmax_pass(0);
+  __syncthreads();
+  // pass 2: odd samples
+  load_pass(1);
+  ifft_lds<LOGM, NT>(d, a.W);
+  argmax_pass(1);
+  // block arg-max (first maximum): wave shuffle, then one wave over the per-wave partials
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ov = __shfl_down(best, off, 64);
+    const int oi = __shfl_down(bi, off, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if ((tid & 63) == 0) { rv[tid >> 6] = best; ri[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid < 64) {
+    best = tid < NT / 64 ? rv[tid] : -2.0;
+    bi = tid < NT / 64 ? ri[tid] : 0x7fffffff;
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      const double ov = __shfl_down(best, off, 64);
+      const int oi = __shfl_down(bi, off, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (tid == 0) ri[0] = bi;
+  }
+  __syncthreads();
+  const int ref = ri[0];
+  if (tid == 0 && a.ref_out) a.ref_out[b] = ref;
+  start = (long)ref - a.idx[b] - a.peak_off;                  // python slice ht[start:]: negative counts from the end, clamped at 0
+  if (start < 0) { start += N; if (start < 0) start = 0; }
+  emit(1);
+  __syncthreads();
+  // pass 3: even samples again, emit
+  load_pass(0);
+  ifft_lds<LOGM, NT>(d, a.W);
+  emit(0);
+}
+
+template <int LOGM, int NT>
+static int launch_synth(const SynthArgs& a, hipStream_t s) {
+  constexpr int M = 1 << LOGM;
+  const size_t lds = (size_t)(M + M / 8) * sizeof(double2) + sizeof(ChirpCoeffsF) + 16 * sizeof(double) + 16 * sizeof(int);
+  static bool attr = false;
+  if (!attr && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)synth_fused_kernel<LOGM, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  prof_begin(s);
+  hipLaunchKernelGGL((synth_fused_kernel<LOGM, NT>), dim3(a.nb), dim3(NT), lds, s, a);
+  // algorithmic bytes: per template 2 spectra of Nf complex128 + the PSD read, the cropped row written
+  prof_end(s, 0.0, 3, (double)a.nb * (2.0 * (M + 1) * 16.0 + (M + 1) * 8.0 + (double)a.crop_len * (a.out64 ? 8.0 : 4.0)));
+  return check_launch("synth_fused");
+}
+
+int synth_templates(const SynthArgs& a, hipStream_t s) {
+  if (a.nb == 0) return GN_OK;
+  switch (a.N) {
+    case 1024: return launch_synth<9, 128>(a, s);
+    case 2048: return launch_synth<10, 256>(a, s);
+    case 4096: return launch_synth<11, 256>(a, s);
+    case 8192: return launch_synth<12, 256>(a, s);
+    case 16384: return launch_synth<13, 512>(a, s);
+    default:
+      set_error("synth_templates: N %d unsupported (1024, 2048, 4096, 8192, 16384)", a.N);
+      return GN_EINVAL;
+  }
+}
+
+}  // namespace gn
+
+using namespace gn;
+
+extern "C" int gn_synth_templates(const double* m1, const double* m2, const int32_t* idx, const double* scale, const double* twiddle, double* out_f64,
+                                  float* out_f32, int32_t* ref_idx, int nb, int N, int roll, int crop0, int crop_len, int peak_off, double df, double f_low,
+                                  double dist_mpc, double iota, double phi0, double Fp, double Fc, double g, void* stream) {
+  GN_REQUIRE(m1 && m2 && idx && scale && twiddle && (out_f64 || out_f32) && nb >= 0, "synth_templates: bad arguments");
+  GN_REQUIRE(roll >= 0 && roll < N && crop0 >= 0 && crop_len > 0 && crop0 + crop_len <= N && df > 0, "synth_templates: bad window (N %d roll %d crop %d+%d)", N,
+             roll, crop0, crop_len);
+  SynthArgs a;
+  a.m1 = m1; a.m2 = m2; a.idx = idx; a.scale = scale; a.W = (const double2*)twiddle; a.out64 = out_f64; a.out32 = out_f32; a.ref_out = ref_idx;
+  a.nb = nb; a.N = N; a.roll = roll; a.crop0 = crop0; a.crop_len = crop_len; a.peak_off = peak_off;
+  a.df = df; a.f_low = f_low; a.dist_mpc = dist_mpc; a.iota = iota; a.phi0 = phi0; a.Fp = Fp; a.Fc = Fc; a.g = g;
+  return synth_templates(a, (hipStream_t)stream);
+}

@@ -248,17 +248,44 @@ class Synth(object):
                   int(crop0), int(crop_len), self.peak_off, float(Fp), float(Fc), float(g), _s())
         return out, ref
 
-    def templates(self, m1, m2, idx, g=1.0, chunk=4096):
-        """Central 1-s crops [1.5 fs, 2.5 fs) of the detector strain for a batch of (m1, m2, idx): (nb, fs) fp64 device tensor
-        and the reference indices (nb,) int32.  (gen_bbh + the crop of sim_data :695; the Tukey window equals 1.0 there.)"""
+    FUSED_N = (1024, 2048, 4096, 8192, 16384)
+
+    def templates(self, m1, m2, idx, g=1.0, chunk=4096, dtype=torch.float64, fused=None):
+        """Central 1-s crops [1.5 fs, 2.5 fs) of the detector strain for a batch of (m1, m2, idx): (nb, fs) device tensor (fp64, or
+        fp32 with dtype=torch.float32) and the reference indices (nb,) int32.  (gen_bbh + the crop of sim_data :695; the Tukey window
+        equals 1.0 there.)  One fused kernel per batch (gn_synth_templates: spectrum, both inverse FFTs, arg-max, slide and crop in
+        LDS); fused=False, or a series length the fused kernel does not cover, runs the separate kernels (chirp -> irFFT x2 -> align)."""
         m1 = np.atleast_1d(np.asarray(m1, np.float64)); m2 = np.atleast_1d(np.asarray(m2, np.float64)); idx = np.atleast_1d(idx)
-        outs, refs = [], []
         c0 = int((self.T_obs / 2) * self.fs - self.fs / 2)
+        if fused is None:
+            fused = self.N in self.FUSED_N
+        if fused:
+            nb = m1.size
+            out = torch.empty((nb, self.fs), dtype=dtype, device=device())
+            ref = torch.empty((nb,), dtype=torch.int32, device=device())
+            if nb == 0:
+                return out, ref
+            m1d, m2d = _d64(m1), _d64(m2)
+            idx_t = torch.as_tensor(np.ascontiguousarray(idx, np.int32)).to(device())
+            o64 = out.data_ptr() if dtype == torch.float64 else None
+            o32 = out.data_ptr() if dtype == torch.float32 else None
+            _lib.call('gn_synth_templates', m1d.data_ptr(), m2d.data_ptr(), idx_t.data_ptr(), self.scale.data_ptr(), twiddles(self.N).data_ptr(), o64, o32,
+                      ref.data_ptr(), nb, self.N, self.fs, c0, self.fs, self.peak_off, 1.0 / self.T_obs, self.f_low, self.dist_mpc, float(IOTA), float(PHI),
+                      float(self.Fp), float(self.Fc), float(g), _s())
+            return out, ref
+        if m1.size == 0:
+            return torch.empty((0, self.fs), dtype=dtype, device=device()), torch.empty((0,), dtype=torch.int32, device=device())
+        outs, refs = [], []
         for s in range(0, m1.size, chunk):
             hp_t, hc_t, _ = self.series(m1[s:s + chunk], m2[s:s + chunk])
             o, r = self.align(hp_t, hc_t, idx[s:s + chunk], c0, self.fs, self.Fp, self.Fc, g)
             outs.append(o); refs.append(r)
-        return torch.cat(outs), torch.cat(refs)
+        out = torch.cat(outs)
+        if dtype == torch.float32:
+            o32 = torch.empty(out.shape, dtype=torch.float32, device=out.device)
+            _lib.call('gn_f64_to_f32', out.data_ptr(), o32.data_ptr(), 1.0, out.numel(), _s())
+            out = o32
+        return out, torch.cat(refs)
 
 
 def make_bbh(hp, hc, fs, ra, dec, psi, det):
@@ -459,17 +486,18 @@ class OnlineBank(object):
         """-> (images (batch, fs) fp32, labels (batch, 2) fp32), both device tensors."""
         m1, m2 = self.draw_masses(batch)
         idx = self.rng.randint(self.lo, self.hi, batch) if self.hi > self.lo else np.full(batch, self.lo)
-        ts, _ = self.syn.templates(m1, m2, idx, g=self.g)
         c0 = int((self.T_obs / 2) * self.fs - self.fs / 2)
         if self.noise == 'coloured':
+            ts, _ = self.syn.templates(m1, m2, idx, g=self.g)
             nz = gen_noise_device(self.fs, self.T_obs, self.psd, batch, self.seed, self.counter)
             self.counter += batch * (self.N // 2 + 1)
             _mul(nz, self._win, False)
             X = _mul(rfft(nz), self.syn.scale, True)
-            ts = ts + irfft(X, self.N)[:, c0:c0 + self.fs]
-        out = torch.empty((batch, self.fs), dtype=torch.float32, device=device())
-        ts = ts.contiguous()
-        _lib.call('gn_f64_to_f32', ts.data_ptr(), out.data_ptr(), 1.0, ts.numel(), _s())
+            ts = (ts + irfft(X, self.N)[:, c0:c0 + self.fs]).contiguous()
+            out = torch.empty((batch, self.fs), dtype=torch.float32, device=device())
+            _lib.call('gn_f64_to_f32', ts.data_ptr(), out.data_ptr(), 1.0, ts.numel(), _s())
+        else:
+            out, _ = self.syn.templates(m1, m2, idx, g=self.g, dtype=torch.float32)      # fp32 rows straight from the fused kernel
         if self.noise == 'white':
             _lib.call('gn_fill_normal', (nz32 := torch.empty_like(out)).data_ptr(), out.numel(), 0.0, 1.0, self.seed, self.counter, _s())
             self.counter += out.numel()

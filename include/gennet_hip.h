@@ -225,6 +225,17 @@ int gn_rfft_f64(const double* x, double* X, const double* twiddle, int nb, int N
  *   ref_out[b] receives ref. */
 int gn_align_crop(const double* hp, const double* hc, const int32_t* idx, double* out, int32_t* ref_out,
                   int nb, int N, int roll, int crop0, int crop_len, int peak_off, double Fp, double Fc, double g, void* stream);
+/* gen_bbh + the crop of sim_data for a batch, FUSED (gw_template_maker.py:507-565, :695): one workgroup per template evaluates the
+ * whitened chirp spectrum once (the same closed form as gn_chirp_fd_whitened), obtains both polarisations from M = N/2-point
+ * complex inverse FFTs resident in LDS, finds ref = argmax(hp^2 + hc^2) of the rolled series (first maximum) and writes
+ *   out[b, n] = g * (Fp*hp + Fc*hc)_rolled[ref - idx[b] - peak_off + crop0 + n],  n in [0, crop_len), 0 past the end
+ * to out_f64 and/or out_f32 (either may be NULL; not both) and ref to ref_idx (may be NULL).  No intermediate spectrum or time
+ * series ever reaches HBM.  scale: (N/2+1,) whitening scale sqrt(2/(psd*fs)) (0 where psd <= 0; gw_template_maker.py:273-281);
+ * twiddle as for gn_irfft_f64.  N in {1024, 2048, 4096, 8192, 16384}. */
+int gn_synth_templates(const double* m1, const double* m2, const int32_t* idx, const double* scale, const double* twiddle,
+                       double* out_f64, float* out_f32, int32_t* ref_idx, int nb, int N, int roll, int crop0, int crop_len,
+                       int peak_off, double df, double f_low, double dist_mpc, double iota, double phi0, double Fp, double Fc, double g,
+                       void* stream);
 /* gen_noise (gw_template_maker.py:161-193) spectrum: X[b,f] = amp[f]*(xi_re + i xi_im), DC = 0 (Philox normals, re block then im block) */
 int gn_noise_fd(const double* amp, double* X, int nb, int Nf, uint64_t seed, uint64_t offset, void* stream);
 /* x *= s (fp64), used for N*df and gw_norm_constant scalings; and fp64 -> fp32 narrowing with scale */

@@ -40,7 +40,16 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.reps
     alg_bytes = a.nb * (2 * Nf * 16 + Nf * 8 + fs * 8)
-    print('templates : fs=%d nb=%d  %.3f ms  %.0f templates/s  (%.1f GB/s algorithmic)' % (fs, a.nb, dt * 1e3, a.nb / dt, alg_bytes / dt / 1e9))
+    print('templates (fused kernel)   : fs=%d nb=%d  %.3f ms  %.0f templates/s  (%.1f GB/s algorithmic)' % (fs, a.nb, dt * 1e3, a.nb / dt, alg_bytes / dt / 1e9))
+    syn.templates(m1[:64], m2[:64], idx[:64], fused=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        ts_u, _ = syn.templates(m1, m2, idx, fused=False)
+    torch.cuda.synchronize()
+    du = (time.perf_counter() - t0) / a.reps
+    print('templates (separate kernels): fs=%d nb=%d  %.3f ms  %.0f templates/s  -> fused / separate = %.2fx; max |diff| / max = %.2e'
+          % (fs, a.nb, du * 1e3, a.nb / du, du / dt, float((ts - ts_u).abs().max() / ts_u.abs().max())))
     T.gen_noise_device(fs, Tobs, psd, 64, 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -168,6 +168,53 @@ def test_sim_data_matches_reference_executed_fixture(fs):
     assert ts.shape == IG['sim_%d_ts' % fs].shape and rel(ts, IG['sim_%d_ts' % fs]) < 1e-9
 
 
+@pytest.mark.parametrize("fs", [256, 512, 1024, 2048, 4096])
+def test_fused_synthesiser_equals_separate_kernels_and_oracle(fs):
+    """gn_synth_templates (spectrum, both inverse FFTs, arg-max, slide and crop in one workgroup, nothing through HBM) against the
+    separate kernels (chirp -> irFFT x2 -> align/crop): ref_idx exact, crops <= 1e-12; against the fp64 oracle <= 1e-9 (chirp
+    evaluation, see the module docstring); fp32 output = the fp64 output rounded once.  Masses include light systems whose spectrum
+    reaches the Nyquist bin at low sample rates (the (-1)^n term) and heavy ones that end far below it."""
+    from gennet_amd import templates as T
+    Tobs = 4
+    N = fs * Tobs
+    psd = S.analytic_psd(N // 2 + 1, 1.0 / Tobs)
+    syn = T.Synth(fs, Tobs, psd)
+    np.random.seed(fs + 1)
+    pars = [T.gen_par(fs, Tobs, mdist='hunt_constrain', beta=[0.45, 0.55]) for _ in range(37)]
+    m1 = np.array([p.m1 for p in pars] + [6.0, 7.5, 90.0, 36.0]); m2 = np.array([p.m2 for p in pars] + [5.5, 6.0, 9.0, 29.0])
+    lo, hi = T.convert_beta([0.45, 0.55], fs, Tobs)
+    idx = np.array([p.idx for p in pars] + [lo, hi - 1, N // 2, 3])                   # the last slide start is far from the usual window
+    a, ra = syn.templates(m1, m2, idx, g=1.7, fused=True)
+    b, rb = syn.templates(m1, m2, idx, g=1.7, fused=False)
+    assert torch.equal(ra, rb) and a.shape == b.shape == (41, fs) and a.dtype == torch.float64
+    assert rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-12
+    for k in range(41):
+        assert rel(a[k].cpu().numpy(), b[k].cpu().numpy()) < 1e-11, k                # per row too (rows differ in scale)
+    a32, r32 = syn.templates(m1, m2, idx, g=1.7, dtype=torch.float32)
+    assert torch.equal(r32, ra) and torch.equal(a32, a.float())
+    Fp, Fc = syn.Fp, syn.Fc
+    for k in (0, 5, 36, 37, 38, 39, 40):
+        p = S.bbhparams(0, m1[k] + m2[k], 0, m1[k], m2[k], S.RA, S.DEC, S.IOTA, S.PHI, S.PSI, int(idx[k]), None, None)
+        crop, ref_idx = S.gen_bbh(fs, Tobs, psd, p, Fp, Fc)
+        assert int(ra[k]) == ref_idx
+        assert rel(a[k].cpu().numpy() / 1.7, crop) < 1e-9
+    if fs == 256:
+        hp, _ = S.chirp_fd(6.0, 5.5, N // 2 + 1, 1.0 / Tobs)
+        assert hp[-1] != 0                                                             # the Nyquist-bin term was really exercised
+
+
+def test_fused_synthesiser_empty_and_unsupported_lengths():
+    from gennet_amd import _lib, templates as T
+    syn = T.Synth(256, 4, S.analytic_psd(513, 0.25))
+    out, ref = syn.templates(np.zeros(0), np.zeros(0), np.zeros(0, np.int32))
+    assert out.shape == (0, 256) and ref.shape == (0,)
+    syn64 = T.Synth(64, 4, np.ones(129))                                               # N = 256: below the fused kernel's range -> separate kernels
+    o, r = syn64.templates([30.0], [25.0], [130])
+    assert o.shape == (1, 64) and torch.isfinite(o).all()
+    with pytest.raises(_lib.GennetHipError):
+        syn64.templates([30.0], [25.0], [130], fused=True)
+
+
 def test_align_python_slice_semantics_edge_cases():
     """start = ref_idx - idx - 11 < 0 (python slices from the end) and start near N (zero fill), on crafted series."""
     from gennet_amd import templates as T
