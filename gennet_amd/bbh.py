@@ -231,11 +231,19 @@ def assemble_discriminator_batch(real, noise, fake, event):
     return sX, sy
 
 
-def gan_train_step(nets, bank, event, batch, rng=_pyrandom, rank=0, world=1, predict_batch=32):
+def gan_train_step_online(nets, online_bank, event, batch, predict_batch=32):
+    """The GAN loop body with the real half of the discriminator batch synthesised on the GPU for this iteration (BASELINE config 5;
+    templates.OnlineBank) instead of gathered from a stored bank; otherwise identical to gan_train_step."""
+    real, _ = online_bank.draw(batch)
+    return gan_train_step(nets, None, event, batch, predict_batch=predict_batch, real=real)
+
+
+def gan_train_step(nets, bank, event, batch, rng=_pyrandom, rank=0, world=1, predict_batch=32, real=None):
     """One iteration of the GAN loop, bbhMahoGANy.py:1243-1299.  Returns [sg_loss, sg_acc, sd_loss, sd_acc] (:1299)."""
-    n = bank.n_pix
-    it = bank.sample(batch, rng, rank, world)
-    real = ops.gather_rows(bank.images, it)
+    if real is None:
+        it = bank.sample(batch, rng, rank, world)
+        real = ops.gather_rows(bank.images, it)
+    n = real.shape[1]
     seed, off = device_rng().take(batch * 100)
     z = ops.fill_uniform((batch, 100), -1.0, 1.0, seed, off, device())
     fake = nets.generator.predict_device(z, batch_size=predict_batch)                    # inference phase (:1248)

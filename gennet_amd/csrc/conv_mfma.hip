@@ -716,7 +716,7 @@ static int launch_wgrad(WgradArgs a, float* dw, hipStream_t s) {
   dim3 grid(cdiv(a.Cin, TC), cdiv(a.Cout, TN), splits);
   prof_begin(s);
   hipLaunchKernelGGL((wgrad_mfma_kernel<WAVES_C, WAVES_N, WNT, NTAPS, KT>), grid, dim3(64 * WAVES_C * WAVES_N), lds, s, a);
-  prof_end(s, 2.0 * a.B * (double)a.M * NTAPS * a.Cin * a.Cout, 1);
+  prof_end(s, 2.0 * a.B * (double)a.M * NTAPS * a.Cin * a.Cout, 1, 4.0 * ((double)a.B * a.Lin * a.Cin + (double)a.B * a.M * a.Cout + (double)NTAPS * a.Cin * a.Cout));
   int rc = check_launch("wgrad_mfma");
   if (rc) return rc;
   const size_t n = (size_t)NTAPS * a.Cin * a.Cout;

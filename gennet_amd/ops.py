@@ -440,7 +440,7 @@ def prof_reset():
 
 
 def prof_collect(kind=-1):
-    """kind 0: conv_mfma_kernel (forward + data gradient), 1: wgrad_mfma_kernel, -1: both."""
+    """kind 0: conv_mfma kernels (forward + data gradient), 1: wgrad_mfma_kernel, 2: bf16x3 conv (opt-in), 3: fused synthesiser, -1: all."""
     import ctypes
     out = (ctypes.c_double * 4)()
     _lib.call('gn_prof_collect', int(kind), ctypes.cast(out, ctypes.c_void_p))
