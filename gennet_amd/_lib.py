@@ -40,6 +40,8 @@ _SIGS = {
     'gn_upsample2_bwd': [vp, vp, i32, i32, i32, vp],
     'gn_subtract_stack_fwd': [vp, vp, vp, i32, i32, vp],
     'gn_subtract_stack_bwd': [vp, vp, i32, i32, vp],
+    'gn_affine_stack_fwd': [vp, vp, vp, f32, f32, vp, i32, i32, vp],
+    'gn_affine_stack_bwd': [vp, f32, f32, vp, i32, i32, vp],
     'gn_assemble_d_batch': [vp, vp, vp, vp, vp, i32, i32, vp],
     'gn_fill_uniform': [vp, sz, f32, f32, u64, u64, vp],
     'gn_fill_normal': [vp, sz, f32, f32, u64, u64, vp],

@@ -426,6 +426,14 @@ int gn_subtract_stack_bwd(const float* dimg, float* dx, int B, int n, void* stre
   GN_REQUIRE(dimg && dx, "subtract_stack_bwd: null pointer");
   return subtract_stack_bwd(dimg, dx, B, n, (hipStream_t)stream);
 }
+int gn_affine_stack_fwd(const float* x, const float* b0, const float* b1, float a0, float a1, float* img, int B, int n, void* stream) {
+  GN_REQUIRE(x && img && B >= 0 && n > 0, "affine_stack_fwd: bad arguments");
+  return affine_stack_fwd(x, b0, b1, a0, a1, img, B, n, (hipStream_t)stream);
+}
+int gn_affine_stack_bwd(const float* dimg, float a0, float a1, float* dx, int B, int n, void* stream) {
+  GN_REQUIRE(dimg && dx && B >= 0 && n > 0, "affine_stack_bwd: bad arguments");
+  return affine_stack_bwd(dimg, a0, a1, dx, B, n, (hipStream_t)stream);
+}
 int gn_assemble_d_batch(const float* real, const float* noise, const float* fake, const float* event, float* sX, int B, int n, void* stream) {
   GN_REQUIRE(real && noise && fake && event && sX && B >= 0 && n > 0, "assemble_d_batch: bad arguments");
   return assemble_d_batch(real, noise, fake, event, sX, B, n, (hipStream_t)stream);

@@ -112,6 +112,8 @@ int upsample2_fwd(const float* x, float* y, int B, int L, int C, hipStream_t s);
 int upsample2_bwd(const float* dy, float* dx, int B, int L, int C, hipStream_t s);
 int subtract_stack_fwd(const float* x, const float* ev, float* img, int B, int n, hipStream_t s);
 int subtract_stack_bwd(const float* dimg, float* dx, int B, int n, hipStream_t s);
+int affine_stack_fwd(const float* x, const float* b0, const float* b1, float a0, float a1, float* img, int B, int n, hipStream_t s);
+int affine_stack_bwd(const float* dimg, float a0, float a1, float* dx, int B, int n, hipStream_t s);
 int assemble_d_batch(const float* real, const float* noise, const float* fake, const float* ev, float* sX, int B, int n, hipStream_t s);
 int gather_rows(const float* src, const int64_t* idx, float* out, int rows, int width, hipStream_t s);
 int axpy(float* y, const float* x, float a, size_t n, hipStream_t s);

@@ -156,6 +156,35 @@ __global__ void subtract_stack_bwd_kernel(const float2* __restrict__ d, float* _
     dx[i] = v.x - v.y;
   }
 }
+// user-defined Layer.call of the form K.stack([a0*x + b0, a1*x + b1], axis=2) (keras/backend.py lowers it here); MyLayer is (1, 0, -1, event)
+__global__ void affine_stack_fwd_kernel(const float* __restrict__ x, const float* __restrict__ b0, const float* __restrict__ b1, float a0, float a1,
+                                        float2* __restrict__ img, size_t total, int n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float v = x[i];
+    const int t = (int)(i % n);
+    img[i] = make_float2(a0 * v + (b0 ? b0[t] : 0.f), a1 * v + (b1 ? b1[t] : 0.f));
+  }
+}
+__global__ void affine_stack_bwd_kernel(const float2* __restrict__ d, float a0, float a1, float* __restrict__ dx, size_t total) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float2 v = d[i];
+    dx[i] = a0 * v.x + a1 * v.y;
+  }
+}
+int affine_stack_fwd(const float* x, const float* b0, const float* b1, float a0, float a1, float* img, int B, int n, hipStream_t s) {
+  const size_t total = (size_t)B * n;
+  if (!total) return GN_OK;
+  hipLaunchKernelGGL(affine_stack_fwd_kernel, dim3(stream_grid(total)), dim3(256), 0, s, x, b0, b1, a0, a1, (float2*)img, total, n);
+  return check_launch("affine_stack_fwd");
+}
+int affine_stack_bwd(const float* dimg, float a0, float a1, float* dx, int B, int n, hipStream_t s) {
+  const size_t total = (size_t)B * n;
+  if (!total) return GN_OK;
+  hipLaunchKernelGGL(affine_stack_bwd_kernel, dim3(stream_grid(total)), dim3(256), 0, s, (const float2*)dimg, a0, a1, dx, total);
+  return check_launch("affine_stack_bwd");
+}
 int subtract_stack_fwd(const float* x, const float* ev, float* img, int B, int n, hipStream_t s) {
   const size_t total = (size_t)B * n;
   if (!total) return GN_OK;

@@ -287,15 +287,38 @@ class Layer(object):
     def compute_output_shape(self, input_shape):
         return input_shape
 
+    # A subclass that defines keras' `call(self, x)` (and not this engine's forward/backward) is a USER-DEFINED layer in keras'
+    # conventions (bbhMahoGANy.py:164-188): its build / compute_output_shape see shapes WITH the batch axis, and its call is traced
+    # once on a symbolic operand and lowered to a HIP kernel (gennet_amd/keras/backend.py).
+    def _is_user_layer(self):
+        return callable(getattr(type(self), 'call', None)) and type(self).forward is Layer.forward
+
     def _ensure_built(self, input_shape):
         if not self.built:
-            self.build(tuple(input_shape))
+            self.build((None,) + tuple(input_shape) if self._is_user_layer() else tuple(input_shape))
             self.built = True
+
+    def _shape_after(self, input_shape):
+        """Output shape without the batch axis for an input shape without the batch axis."""
+        if self._is_user_layer():
+            out = tuple(self.compute_output_shape((None,) + tuple(input_shape)))[1:]
+            self._lower(tuple(input_shape), out)
+            return out
+        return tuple(self.compute_output_shape(tuple(input_shape)))
+
+    def _lower(self, input_shape, out_shape):
+        if getattr(self, '_lowered', None) is None or self._lowered_for != input_shape:
+            from .keras import backend as K
+            self._lowered = K.lower_layer_call(self, input_shape)
+            self._lowered_for = input_shape
+            if tuple(out_shape) != (input_shape[0], 2, 1):
+                raise ValueError('%s.compute_output_shape gives %r; its call produces %r' % (type(self).__name__, (None,) + tuple(out_shape), (None, input_shape[0], 2, 1)))
+        return self._lowered
 
     # -- functional API
     def __call__(self, x):
         self._ensure_built(x.shape)
-        return SymTensor(self.compute_output_shape(x.shape), self, (x,))
+        return SymTensor(self._shape_after(x.shape), self, (x,))
 
     # -- execution
     fusable_act = False      # can take an activation epilogue
@@ -304,10 +327,16 @@ class Layer(object):
     drop_rate = None         # rate if this layer IS a dropout
 
     def forward(self, ctx, node, x):
-        raise NotImplementedError
+        if not self._is_user_layer():
+            raise NotImplementedError
+        low = self._lower(tuple(x.shape[1:]), tuple(node.out_shape))
+        b0, b1 = low.betas()
+        return ops.affine_stack_fwd(x.contiguous(), low.a0, b0, low.a1, b1)
 
     def backward(self, ctx, node, dy, need_dx, need_dw):
-        raise NotImplementedError
+        if not self._is_user_layer():
+            raise NotImplementedError
+        return ops.affine_stack_bwd(dy.contiguous(), self._lowered.a0, self._lowered.a1)
 
 
 class Node(object):
@@ -616,9 +645,15 @@ class Model(Layer):
         self.loss = loss
         n_out = len(self.output_ids)
         losses = list(loss) if isinstance(loss, (list, tuple)) else [loss] * n_out
-        for l in losses:
-            if l not in LOSSES:
-                raise NotImplementedError('loss %r: only %s run on the HIP path' % (l, LOSSES))
+        self._loss_scales = []
+        for k, l in enumerate(losses):
+            scale = 1.0
+            if callable(l):                # e.g. the script's chisquare_Loss (bbhMahoGANy.py:146-162): traced once and lowered
+                from .keras import backend as K
+                losses[k], scale = K.lower_loss(l)
+            elif l not in LOSSES:
+                raise NotImplementedError('loss %r: only %s (or a callable squared-error loss) run on the HIP path' % (l, LOSSES))
+            self._loss_scales.append(scale)
         self._losses = losses
         self.metrics = list(metrics or [])
         for m in self.metrics:
@@ -705,8 +740,10 @@ class Model(Layer):
         ctx.capture = capture
         outs = self._forward(xs, ctx)
         dps, stats = [], []
-        for p, t, kind in zip(outs, ys, self._losses):
+        for p, t, kind, scale in zip(outs, ys, self._losses, self._loss_scales):
             d, o = ops.loss(kind, p.reshape(B, 1), t, B * world)
+            if scale != 1.0:
+                ops.axpy(d, d.clone(), scale - 1.0)
             dps.append(d.reshape(p.shape)); stats.append(o)
         for grp, a, b in segments(self._train_params):
             grp.grad[a:b].zero_()
@@ -718,7 +755,7 @@ class Model(Layer):
             dp.all_reduce_sum(stats)
         self.optimizer.step()
         st = stats.cpu().numpy().astype(np.float64)
-        losses = [float(v) for v in st[:, 0]]
+        losses = [float(v) * sc for v, sc in zip(st[:, 0], self._loss_scales)]
         res = [float(sum(losses))]
         if len(losses) > 1:
             res += losses
@@ -831,7 +868,7 @@ class Sequential(Model):
             out_shape = layer.nodes[layer.output_ids[0]].out_shape
         else:
             layer._ensure_built(prev_shape)
-            out_shape = tuple(layer.compute_output_shape(prev_shape))
+            out_shape = layer._shape_after(prev_shape)
         idx = self._append(layer, [prev], out_shape)
         self._top.append(layer)
         self.output_ids = [idx]

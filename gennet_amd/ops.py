@@ -305,6 +305,23 @@ def subtract_stack_bwd(dimg):
     return dx
 
 
+def affine_stack_fwd(x, a0, b0, a1, b1):
+    """x (B, n, 1) -> img (B, n, 2, 1): [a0*x + b0 | a1*x + b1], b0 / b1 (n,) device vectors or None."""
+    _chk(x)
+    B, n = x.shape[0], x.shape[1]
+    img = torch.empty((B, n, 2, 1), dtype=torch.float32, device=x.device)
+    _lib.call('gn_affine_stack_fwd', _p(x), _p(b0), _p(b1), float(a0), float(a1), _p(img), B, n, _stream())
+    return img
+
+
+def affine_stack_bwd(dimg, a0, a1):
+    _chk(dimg)
+    B, n = dimg.shape[0], dimg.shape[1]
+    dx = torch.empty((B, n, 1), dtype=torch.float32, device=dimg.device)
+    _lib.call('gn_affine_stack_bwd', _p(dimg), float(a0), float(a1), _p(dx), B, n, _stream())
+    return dx
+
+
 def assemble_d_batch(real, noise, fake, event):
     """[real | fake] discriminator batch (2B, n, 2, 1); fake half reversed like the reference's prepend loop."""
     _chk(real, noise, fake, event)

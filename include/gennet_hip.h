@@ -138,6 +138,11 @@ int gn_upsample2_bwd(const float* dy, float* dx, int B, int L, int C, void* stre
 /* MyLayer (bbhMahoGANy.py:180-184): img[b,t,0] = x[b,t]; img[b,t,1] = event[t] - x[b,t];  adjoint dx = d0 - d1 */
 int gn_subtract_stack_fwd(const float* x, const float* event, float* img, int B, int n, void* stream);
 int gn_subtract_stack_bwd(const float* dimg, float* dx, int B, int n, void* stream);
+/* A user-defined keras Layer whose call() is K.stack([a0*x + b0, a1*x + b1], axis=2) on x (B, n, 1) -- the form of the script's own
+ * MyLayer.call (bbhMahoGANy.py:180-184: diff = self.const - x; K.stack([x, diff], axis=2) is a0 = 1, b0 = NULL, a1 = -1, b1 = const):
+ *   img[b, t, 0] = a0*x[b,t] + b0[t],  img[b, t, 1] = a1*x[b,t] + b1[t]   (b0 / b1 may be NULL = 0);   dx = a0*dimg[...,0] + a1*dimg[...,1]. */
+int gn_affine_stack_fwd(const float* x, const float* b0, const float* b1, float a0, float a1, float* img, int B, int n, void* stream);
+int gn_affine_stack_bwd(const float* dimg, float a0, float a1, float* dx, int B, int n, void* stream);
 /* discriminator batch assembly (bbhMahoGANy.py:1268-1289): sX (2B, n, 2, 1): rows [0,B) = [real[b,t], noise[b,t]], rows [B,2B) =
  * [fake[j,t], event[t]-fake[j,t]] with j = 2B-1-row (the reference's np.append prepends, so the fake half is in reversed order) */
 int gn_assemble_d_batch(const float* real, const float* noise, const float* fake, const float* event, float* sX, int B, int n, void* stream);
