@@ -40,11 +40,12 @@ class DataParallel(object):
             self.broadcast(p.data)
 
 
-def init(backend=None):
+def init(backend=None, allow_single=False):
     """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
-    Returns a DataParallel, or None when WORLD_SIZE is 1 or unset."""
+    Returns a DataParallel, or None when WORLD_SIZE is 1 or unset (allow_single=True initialises a one-rank group anyway: the
+    collectives then really go through the backend, which is how the RCCL path is exercised on a one-GPU box)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1:
+    if world <= 1 and not (allow_single and 'MASTER_PORT' in os.environ):
         return None
     if not dist.is_initialized():
         if backend is None:
@@ -54,5 +55,5 @@ def init(backend=None):
             raise RuntimeError('WORLD_SIZE=%d but MASTER_PORT is unset: start the ranks with torch.distributed.run (bench.py --gpus N does)' % world)
         if backend == 'nccl':
             torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=world)
+        dist.init_process_group(backend=backend, rank=int(os.environ.get('RANK', '0')), world_size=world)
     return DataParallel()

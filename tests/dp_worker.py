@@ -6,6 +6,9 @@ mode 'cpu'  : gloo on CPU tensors; the arithmetic is the fp64 oracle, the commun
               statistics and their backward sums; rank-sliced host sampling) without a GPU.
 mode 'gpu'  : gloo on CUDA tensors, every rank on cuda:0 (one-GPU box; RCCL refuses two ranks on one device): the real HIP
               path, N ranks x B/N rows versus 1 rank x B rows.
+mode 'rccl1': the same HIP path with backend "nccl" (= RCCL) and a ONE-rank group: every gradient / SyncBN / scalar all-reduce
+              and the weight broadcast really go through RCCL (communicator set-up, stream ordering against the HIP kernels,
+              fp32 and fp64 buffers); must reproduce the plain single-process run bit for bit.
 Writes a pickle with losses and final weights to argv[2].<rank>.
 """
 import os
@@ -73,10 +76,10 @@ def run_cpu(out):
         torch.distributed.barrier()
 
 
-def run_gpu(out):
+def run_gpu(out, backend='gloo'):
     from gennet_amd import bbh, dist, engine
     from gennet_amd.layers import Dropout
-    dp = dist.init('gloo')
+    dp = dist.init(backend, allow_single=(backend == 'nccl'))
     rank, world = (dp.rank, dp.world_size) if dp else (0, 1)
     engine.set_init_seed(3)
     n_pix, B = 64, 8
@@ -107,10 +110,15 @@ def run_gpu(out):
             masks[l.name] = (rng.rand(*shp) >= 0.4).astype(np.uint8)
         res['losses'].append(DG.train_on_batch(z[lo:hi], np.ones(hi - lo), dropout_masks={k: v[lo:hi] for k, v in masks.items()}))
     res['weights'] = {'G': G.get_weights(), 'D': D.get_weights(), 'PE': PE.get_weights()}
+    if dp:
+        for m in (G, D, PE):
+            dp.sync_model(m)               # broadcast from rank 0 (a no-op in value; exercises the collective)
+        res['backend'] = torch.distributed.get_backend()
     pickle.dump(res, open('%s.%d' % (out, rank), 'wb'))
     if dp:
         torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':
-    {'cpu': run_cpu, 'gpu': run_gpu}[sys.argv[1]](sys.argv[2])
+    {'cpu': run_cpu, 'gpu': run_gpu, 'rccl1': lambda out: run_gpu(out, 'nccl')}[sys.argv[1]](sys.argv[2])

@@ -76,3 +76,22 @@ def test_two_ranks_equal_one_rank_on_gpu(tmp_path):
     for name in ('G', 'D', 'PE'):
         for w0, w1 in zip(two[0]['weights'][name], two[1]['weights'][name]):
             assert np.array_equal(w0, w1)                   # replicas stay bit-identical
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_group_reproduces_the_plain_run(tmp_path):
+    """backend "nccl" IS RCCL on ROCm.  A one-GPU box cannot host two RCCL ranks, but a one-rank RCCL group can: all the collectives
+    of the data-parallel path (flat gradient SUM, fp64 SyncBN sums, loss scalars, weight broadcast) execute through RCCL on the HIP
+    stream and must leave every loss and weight bit-identical to the run without a process group."""
+    one = launch('gpu', str(tmp_path / 'plain'), 1)[0]
+    env = dict(os.environ)
+    env.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = str(tmp_path / 'rccl')
+    r = subprocess.run([sys.executable, WORKER, 'rccl1', out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    got = pickle.load(open(out + '.0', 'rb'))
+    assert got['backend'] == 'nccl'
+    assert got['losses'] == one['losses']
+    for name in ('G', 'D', 'PE'):
+        for w, wr in zip(got['weights'][name], one['weights'][name]):
+            assert np.array_equal(w, wr)
