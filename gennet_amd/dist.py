@@ -17,20 +17,21 @@ import torch.distributed as dist
 
 
 class DataParallel(object):
-    def __init__(self, group=None):
+    def __init__(self, group=None, always=False):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised; call gennet_amd.dist.init() first')
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.always = always               # issue the collectives even in a one-rank group (init(allow_single=True))
 
     def all_reduce_sum(self, t):
-        if self.world_size > 1:
+        if self.world_size > 1 or self.always:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def broadcast(self, t, src=0):
-        if self.world_size > 1:
+        if self.world_size > 1 or self.always:
             dist.broadcast(t, src, group=self.group)
         return t
 
@@ -56,4 +57,4 @@ def init(backend=None, allow_single=False):
         if backend == 'nccl':
             torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
         dist.init_process_group(backend=backend, rank=int(os.environ.get('RANK', '0')), world_size=world)
-    return DataParallel()
+    return DataParallel(always=allow_single and world <= 1)
