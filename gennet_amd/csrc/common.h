@@ -89,6 +89,9 @@ struct ColRedArgs {
 int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s);
 size_t wgrad_workspace_bytes(int B, int Cin, int Cout, int ntaps);
 int wgrad_mfma_dispatch(WgradArgs a, float* dw, size_t ws_bytes, hipStream_t s);
+// conv_pipe.hip / wgrad_pipe.hip (hand-scheduled variants selected by the two dispatchers above)
+int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched);
+void wgrad_pipe_launch(const WgradArgs& a, dim3 grid, bool narrow, hipStream_t s);
 // conv_bf16x3.hip (experimental bf16 x 3 operand-split convolution, opt-in)
 size_t conv_bf16x3_workspace_bytes(int B, int Lin, int Cin, int Cout, int w_taps);
 bool conv_bf16x3_supported(const ConvArgs& a);

@@ -429,247 +429,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_dma_kerne
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------
-// Software-pipelined variant of the all-DMA kernel: same tile, same LDS-DMA staging, same one-barrier double-stage chunk loop and
-// the same epilogue, but the MFMA block of a chunk is HAND-SCHEDULED.  hipcc turns the source-level operand double buffering of
-// conv_mfma_dma_kernel into "ds_read, s_waitcnt lgkmcnt(0), 2-4 MFMAs" (reads sunk next to their use, every wait a full drain), so a
-// wave exposes one LDS latency per 128-256 cycles of matrix work and the pipe only stays busy through the other waves of the SIMD.
-// Here each group of four MFMAs is one asm statement: the four ds_read_b32 of the NEXT group are issued first, a counted
-// s_waitcnt lgkmcnt(4) retires exactly the CURRENT group's operands (issued one group = 256 matrix cycles earlier), then the four
-// v_mfma_f32_32x32x2_f32 issue back to back.  All LDS addresses are chunk-invariant VGPRs (one per tap for the input slab, one for
-// the weight tile) plus compile-time 16-bit offsets (stage, channel pair, tile), so the block has no address arithmetic at all.
-// The layout is compile-time: IS (input stride) is a template parameter and the slab holds IS*(TM-1)+NTAPS rows (consecutive taps).
-// Descriptor and tile indices go through readfirstlane so that the buffer_load ... lds of the slab are not wrapped in waterfall loops.
-// ---------------------------------------------------------------------------------------------
-template <int OA0, int OA1, int OB0, int OB1>
-__device__ __forceinline__ void pipe_group(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, float a0, float a1, float b0, float b1, float& na0, float& na1,
-                                           float& nb0, float& nb1, unsigned addr_a, unsigned addr_b) {
-  asm volatile(
-      "ds_read_b32 %4, %12 offset:%14\n\t"
-      "ds_read_b32 %5, %12 offset:%15\n\t"
-      "ds_read_b32 %6, %13 offset:%16\n\t"
-      "ds_read_b32 %7, %13 offset:%17\n\t"
-      "s_waitcnt lgkmcnt(4)\n\t"
-      "v_mfma_f32_32x32x2_f32 %0, %8, %10, %0\n\t"
-      "v_mfma_f32_32x32x2_f32 %1, %8, %11, %1\n\t"
-      "v_mfma_f32_32x32x2_f32 %2, %9, %10, %2\n\t"
-      "v_mfma_f32_32x32x2_f32 %3, %9, %11, %3"
-      : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11), "=&v"(na0), "=&v"(na1), "=&v"(nb0), "=&v"(nb1)
-      : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(addr_a), "v"(addr_b), "i"(OA0), "i"(OA1), "i"(OB0), "i"(OB1)
-      : "memory");
-}
-__device__ __forceinline__ void pipe_last(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, float a0, float a1, float b0, float b1) {
-  asm volatile(
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "v_mfma_f32_32x32x2_f32 %0, %4, %6, %0\n\t"
-      "v_mfma_f32_32x32x2_f32 %1, %4, %7, %1\n\t"
-      "v_mfma_f32_32x32x2_f32 %2, %5, %6, %2\n\t"
-      "v_mfma_f32_32x32x2_f32 %3, %5, %7, %3"
-      : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11)
-      : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
-      : "memory");
-}
-template <int OA0, int OA1, int OB0, int OB1>
-__device__ __forceinline__ void pipe_first(float& na0, float& na1, float& nb0, float& nb1, unsigned addr_a, unsigned addr_b) {
-  asm volatile(
-      "ds_read_b32 %0, %4 offset:%6\n\t"
-      "ds_read_b32 %1, %4 offset:%7\n\t"
-      "ds_read_b32 %2, %5 offset:%8\n\t"
-      "ds_read_b32 %3, %5 offset:%9"
-      : "=&v"(na0), "=&v"(na1), "=&v"(nb0), "=&v"(nb1)
-      : "v"(addr_a), "v"(addr_b), "i"(OA0), "i"(OA1), "i"(OB0), "i"(OB1)
-      : "memory");
-}
-
-template <int TN, int KC, int NTAPS, int STAGE_BYTES, int STAGE>
-struct PipeChunk {
-  static constexpr int SLOTS = NTAPS * (KC / 2);
-  static constexpr int oa(int g) { return STAGE * STAGE_BYTES + 8 * (g % (KC / 2)); }                                   // + the tap's address register
-  static constexpr int ob(int g) { return STAGE * STAGE_BYTES + ((g / (KC / 2)) * KC + 2 * (g % (KC / 2))) * TN * 4; }
-  // groups G..SLOTS-1; operand set P (= G & 1) is current, the other one receives group G+1
-  template <int G>
-  static __device__ __forceinline__ void run(f32x16 (&acc)[2][2], float (&s0)[4], float (&s1)[4], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
-    float(&cur)[4] = (G & 1) ? s1 : s0;
-    float(&nxt)[4] = (G & 1) ? s0 : s1;
-    if constexpr (G + 1 < SLOTS) {
-      pipe_group<oa(G + 1), oa(G + 1) + 32 * KC * 4, ob(G + 1), ob(G + 1) + 128>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], cur[0], cur[1], cur[2], cur[3], nxt[0], nxt[1],
-                                                                                   nxt[2], nxt[3], addr_a[(G + 1) / (KC / 2)], addr_b);
-      run<G + 1>(acc, s0, s1, addr_a, addr_b);
-    } else {
-      pipe_last(acc[0][0], acc[0][1], acc[1][0], acc[1][1], cur[0], cur[1], cur[2], cur[3]);
-    }
-  }
-  static __device__ __forceinline__ void chunk(f32x16 (&acc)[2][2], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
-    float s0[4], s1[4];
-    pipe_first<oa(0), oa(0) + 32 * KC * 4, ob(0), ob(0) + 128>(s0[0], s0[1], s0[2], s0[3], addr_a[0], addr_b);
-    run<0>(acc, s0, s1, addr_a, addr_b);
-  }
-};
-
-template <int WAVES_M, int WAVES_N, int NTAPS, int IS>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_pipe_kernel(ConvArgs a, int m_tiles, int n_tiles) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int WM = 2, WN = 2, KC = 8;
-  constexpr int TM = WAVES_M * WM * 32;
-  constexpr int TN = WAVES_N * WN * 32;
-  constexpr int NT = 64 * WAVES_M * WAVES_N;
-  constexpr int R = IS * (TM - 1) + NTAPS;                 // staged input rows: the launcher checks that the taps are consecutive
-  constexpr int RPER = (R + IS - 1) / IS;
-  constexpr int SLAB = IS * RPER * KC;                     // floats
-  constexpr int BUF = SLAB + NTAPS * KC * TN;
-  constexpr int STAGE_BYTES = BUF * 4;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int i32 = lane & 31, h = lane >> 5;
-  const int bid = blockIdx.x;
-  const int n_tile = __builtin_amdgcn_readfirstlane(bid % n_tiles);
-  const int rest = bid / n_tiles;
-  const int m_tile = __builtin_amdgcn_readfirstlane(rest % m_tiles);
-  const int b = __builtin_amdgcn_readfirstlane(rest / m_tiles);
-  const int m0 = m_tile * TM, n0 = n_tile * TN;
-
-  int minoff = a.t.off[0];
-#pragma unroll
-  for (int j = 1; j < NTAPS; ++j) minoff = min(minoff, a.t.off[j]);
-
-  f32x16 acc[WM][WN];
-#pragma unroll
-  for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < WN; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  const int t_base = IS * m0 + minoff;
-  // descriptor inputs made PROVABLY wave-uniform (pointer halves and byte count through readfirstlane): otherwise hipcc wraps every
-  // buffer_load ... lds in a waterfall loop (v_readfirstlane x4, compare, saveexec, load, loop), ~12 instructions per DMA piece
-  const uintptr_t xbp = (uintptr_t)(a.x + (size_t)b * a.Lin * a.Cin);
-  const unsigned xb_lo = __builtin_amdgcn_readfirstlane((unsigned)xbp), xb_hi = __builtin_amdgcn_readfirstlane((unsigned)(xbp >> 32));
-  const int xbytes = __builtin_amdgcn_readfirstlane(a.Lin * a.Cin * 4);
-  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)xb_hi << 32) | xb_lo), 0, xbytes, 0x00020000);
-
-  constexpr int S_COUNT = SLAB / 4;                        // 16-byte granules of one slab stage, in LDS order
-  constexpr int S_ITEMS = (S_COUNT + NT - 1) / NT;
-  constexpr int W_TOTAL = NTAPS * KC * (TN / 4);
-  constexpr int W_ITEMS = (W_TOTAL + NT - 1) / NT;
-  int soff[S_ITEMS];
-#pragma unroll
-  for (int it = 0; it < S_ITEMS; ++it) {
-    const int id = tid + it * NT;
-    const int lr = id / (KC / 4), c4 = id % (KC / 4);
-    const int r = (IS == 1) ? lr : (lr < RPER ? 2 * lr : 2 * (lr - RPER) + 1);
-    soff[it] = (id < S_COUNT && r < R) ? ((t_base + r) * a.Cin + 4 * c4) * 4 : 0x40000000;   // out of range -> the descriptor returns 0
-  }
-  const float* wp[W_ITEMS];
-#pragma unroll
-  for (int it = 0; it < W_ITEMS; ++it) {
-    const int id = min(tid + it * NT, W_TOTAL - 1);
-    const int n4 = id % (TN / 4);
-    const int kk = (id / (TN / 4)) % KC;
-    const int j = id / ((TN / 4) * KC);
-    wp[it] = a.w + ((size_t)a.t.widx[j] * a.Cin + kk) * a.Cout + n0 + 4 * n4;
-  }
-  auto dma_chunk = [&](int c0, float* stage) {
-#pragma unroll
-    for (int it = 0; it < S_ITEMS; ++it) {
-      if ((it + 1) * NT <= S_COUNT || tid + it * NT < S_COUNT)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stage + (it * NT + (tid & ~63)) * 4), 16, soff[it] + c0 * 4, 0, 0, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < W_ITEMS; ++it)
-      if ((it + 1) * NT <= W_TOTAL || (tid & ~63) + it * NT < W_TOTAL)
-        __builtin_amdgcn_global_load_lds((gptr_t)(wp[it] + (size_t)c0 * a.Cout), (lptr_t)(stage + SLAB + (it * NT + (tid & ~63)) * 4), 16, 0, 0);
-  };
-
-  // chunk-invariant LDS byte addresses of this lane's operands in stage 0
-  const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  unsigned addr_a[NTAPS];
-#pragma unroll
-  for (int j = 0; j < NTAPS; ++j) {
-    const int d = a.t.off[j] - minoff;
-    const int rowbase = (IS == 1) ? d : ((d & 1) * RPER + (d >> 1));
-    addr_a[j] = lds0 + ((rowbase + wm * WM * 32 + i32) * KC + h) * 4;
-  }
-  const unsigned addr_b = lds0 + (SLAB + h * TN + wn * WN * 32 + i32) * 4;
-
-  const int n_chunks = a.Cin / KC;
-  dma_chunk(0, smem);
-  __syncthreads();                                         // drains the LDS-DMA (vmcnt(0)) in front of the barrier
-
-  for (int ch = 0; ch < n_chunks; ch += 2) {
-    dma_chunk(min(ch + 1, n_chunks - 1) * KC, smem + BUF);                        // chunk ch+1 flies during this chunk's MFMAs
-    PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::chunk(acc, addr_a, addr_b);
-    __syncthreads();
-    if (ch + 1 < n_chunks) {
-      dma_chunk(min(ch + 2, n_chunks - 1) * KC, smem);
-      PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::chunk(acc, addr_a, addr_b);
-      __syncthreads();
-    }
-  }
-  // MFMA results written inside asm: the compiler inserts no wait states for its own readers of acc
-  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
-
-  float* yb = a.y + (size_t)b * a.Ly * a.Cout;
-  const uint8_t* mb = a.mask ? a.mask + (size_t)b * a.Ly * a.Cout : nullptr;
-  const float* gyb = a.gy ? a.gy + (size_t)b * a.Ly * a.Cout : nullptr;
-  const uint8_t* gmb = a.gmask ? a.gmask + (size_t)b * a.Ly * a.Cout : nullptr;
-#pragma unroll
-  for (int nt = 0; nt < WN; ++nt) {
-    const int n = n0 + wn * WN * 32 + nt * 32 + i32;
-    const float bias = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < WM; ++mt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int m = m0 + wm * WM * 32 + mt * 32 + row;
-        if (m < a.M) {
-          const size_t o = (size_t)(a.t.out_stride * m + a.t.out_off) * a.Cout + n;
-          float v = act_apply(acc[mt][nt][r] + bias, a.act, a.act_param);
-          if (mb) v = mb[o] ? v * a.keep_scale : 0.f;
-          if (gyb) {
-            const float gv = gyb[o];
-            if (gmb) v = gmb[o] ? v * a.gscale * act_grad_from_y(gv / a.gscale, a.gact, a.gparam) : 0.f;
-            else v *= act_grad_from_y(gv, a.gact, a.gparam);
-          }
-          yb[o] = v;
-        }
-      }
-    }
-  }
-#endif
-}
-
-template <int WAVES_M, int WAVES_N, int NTAPS, int IS>
-static int launch_conv_pipe(const ConvArgs& a, hipStream_t s) {
-  constexpr int KC = 8, TM = WAVES_M * 64, TN = WAVES_N * 64;
-  constexpr int R = IS * (TM - 1) + NTAPS, RPER = (R + IS - 1) / IS;
-  constexpr size_t lds = 2 * sizeof(float) * ((size_t)IS * RPER * KC + (size_t)NTAPS * KC * TN);
-  static_assert(lds + 10240 * 0 <= 160 * 1024, "stage too large");
-  static_assert(lds / 2 + (NTAPS * KC + 8) * TN * 4 < 65536, "ds_read offsets must fit 16 bits");
-  if (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-  }
-  const int m_tiles = (a.M + TM - 1) / TM, n_tiles = a.Cout / TN;
-  const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
-  if (blocks == 0 || blocks > 0x7fffffffull) {
-    set_error("conv_mfma_pipe: bad grid %zu", blocks);
-    return GN_EINVAL;
-  }
-  prof_begin(s);
-  hipLaunchKernelGGL((conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles);
-  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0, 4.0 * ((double)a.B * a.Lin * a.Cin + (double)a.t.ntaps * a.Cin * a.Cout + (double)a.B * a.M * a.Cout));
-  return check_launch("conv_mfma_pipe");
-}
-
 template <int WM, int WN, int WAVES_M, int WAVES_N, int KC, int NTAPS>
 static int launch_conv_dma(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WAVES_M * WM * 32, TN = WAVES_N * WN * 32;
@@ -746,16 +505,9 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
   const bool full = even && ((NTAPS * KC * (TN / 4)) % (64 * WAVES_M * WAVES_N) == 0);       // ... and whole weight items per thread
   if (even && (NTAPS * KC * (TN / 4)) % 64 == 0 && !no_dma && (size_t)a.Lin * a.Cin * 4 < 0x40000000ull) {
     if constexpr (KC == 8 && WM == 2 && WN == 2 && NTAPS >= 2) {
-      static const bool no_pipe = getenv("GN_CONV_NOPIPE") != nullptr;
-      int minoff = a.t.off[0], maxoff = a.t.off[0];
-      for (int j = 1; j < NTAPS; ++j) {
-        minoff = std::min(minoff, a.t.off[j]);
-        maxoff = std::max(maxoff, a.t.off[j]);
-      }
-      if (!no_pipe && maxoff - minoff + 1 <= NTAPS) {        // consecutive taps: the compile-time slab of the pipelined kernel covers them
-        if (a.t.in_stride == 1) return launch_conv_pipe<WAVES_M, WAVES_N, NTAPS, 1>(a, s);
-        if constexpr (NTAPS == 5) return launch_conv_pipe<WAVES_M, WAVES_N, NTAPS, 2>(a, s);
-      }
+      bool launched = false;
+      const int rc = conv_pipe_try(a, WAVES_M == 4, s, &launched);     // conv_pipe.hip: hand-scheduled MFMA block, lean epilogue
+      if (launched || rc) return rc;
     }
     return launch_conv_dma<WM, WN, WAVES_M, WAVES_N, KC, NTAPS>(a, s);
   }
@@ -926,191 +678,6 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N) void wgrad_mfma_kernel(Wgra
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Weight gradient, pipelined: the design of conv_mfma_pipe_kernel applied to wgrad_mfma_kernel (same tile, same split-K slabs, same
-// fixed-order reduce).  Both operands go global -> LDS by LDS-DMA through per-batch-element buffer descriptors whose range check
-// supplies the zeros (x rows outside [0, Lin): the convolution's padding; dy rows >= M: the ragged last K-chunk), two LDS stages,
-// ONE barrier per K-chunk (the register-staged kernel needs two and a ds_write pass), and the MFMA block is hand-scheduled: per
-// k-pair the six ds_read_b32 of the NEXT pair (five taps of x as shifted rows of the slab + one dy value) are issued first, a counted
-// s_waitcnt lgkmcnt(6) retires the current pair's operands, then the five v_mfma_f32_32x32x2_f32 (one per tap) issue back to back.
-// No staging registers: ~110 VGPRs against 220, three blocks per CU against two.  Needs Cin % TC == 0, Cout % TN == 0, 5 consecutive taps.
-// ---------------------------------------------------------------------------------------------
-template <int OA0, int OA1, int OA2, int OA3, int OA4, int OB>
-__device__ __forceinline__ void wg_group(f32x16& c0, f32x16& c1, f32x16& c2, f32x16& c3, f32x16& c4, float a0, float a1, float a2, float a3, float a4, float b0,
-                                         float& na0, float& na1, float& na2, float& na3, float& na4, float& nb0, unsigned addr_a, unsigned addr_b) {
-  asm volatile(
-      "ds_read_b32 %5, %17 offset:%19\n\t"
-      "ds_read_b32 %6, %17 offset:%20\n\t"
-      "ds_read_b32 %7, %17 offset:%21\n\t"
-      "ds_read_b32 %8, %17 offset:%22\n\t"
-      "ds_read_b32 %9, %17 offset:%23\n\t"
-      "ds_read_b32 %10, %18 offset:%24\n\t"
-      "s_waitcnt lgkmcnt(6)\n\t"
-      "v_mfma_f32_32x32x2_f32 %0, %11, %16, %0\n\t"
-      "v_mfma_f32_32x32x2_f32 %1, %12, %16, %1\n\t"
-      "v_mfma_f32_32x32x2_f32 %2, %13, %16, %2\n\t"
-      "v_mfma_f32_32x32x2_f32 %3, %14, %16, %3\n\t"
-      "v_mfma_f32_32x32x2_f32 %4, %15, %16, %4"
-      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "=&v"(na0), "=&v"(na1), "=&v"(na2), "=&v"(na3), "=&v"(na4), "=&v"(nb0)
-      : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(b0), "v"(addr_a), "v"(addr_b), "i"(OA0), "i"(OA1), "i"(OA2), "i"(OA3), "i"(OA4), "i"(OB)
-      : "memory");
-}
-__device__ __forceinline__ void wg_last(f32x16& c0, f32x16& c1, f32x16& c2, f32x16& c3, f32x16& c4, float a0, float a1, float a2, float a3, float a4, float b0) {
-  asm volatile(
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "v_mfma_f32_32x32x2_f32 %0, %5, %10, %0\n\t"
-      "v_mfma_f32_32x32x2_f32 %1, %6, %10, %1\n\t"
-      "v_mfma_f32_32x32x2_f32 %2, %7, %10, %2\n\t"
-      "v_mfma_f32_32x32x2_f32 %3, %8, %10, %3\n\t"
-      "v_mfma_f32_32x32x2_f32 %4, %9, %10, %4"
-      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4)
-      : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(b0)
-      : "memory");
-}
-template <int OA0, int OA1, int OA2, int OA3, int OA4, int OB>
-__device__ __forceinline__ void wg_first(float& na0, float& na1, float& na2, float& na3, float& na4, float& nb0, unsigned addr_a, unsigned addr_b) {
-  asm volatile(
-      "ds_read_b32 %0, %6 offset:%8\n\t"
-      "ds_read_b32 %1, %6 offset:%9\n\t"
-      "ds_read_b32 %2, %6 offset:%10\n\t"
-      "ds_read_b32 %3, %6 offset:%11\n\t"
-      "ds_read_b32 %4, %6 offset:%12\n\t"
-      "ds_read_b32 %5, %7 offset:%13"
-      : "=&v"(na0), "=&v"(na1), "=&v"(na2), "=&v"(na3), "=&v"(na4), "=&v"(nb0)
-      : "v"(addr_a), "v"(addr_b), "i"(OA0), "i"(OA1), "i"(OA2), "i"(OA3), "i"(OA4), "i"(OB)
-      : "memory");
-}
-
-template <int TC, int TN, int KT, int IS, int STAGE_BYTES, int STAGE>
-struct WgChunk {
-  static constexpr int QS = KT / 2;
-  static constexpr int oa(int q, int j) { return STAGE * STAGE_BYTES + (IS * 2 * q + j) * TC * 4; }       // + lane part (h * IS rows, channel)
-  static constexpr int ob(int q) { return STAGE * STAGE_BYTES + 2 * q * TN * 4; }
-  template <int Q>
-  static __device__ __forceinline__ void run(f32x16 (&acc)[5], float (&s0)[6], float (&s1)[6], unsigned addr_a, unsigned addr_b) {
-    float(&cur)[6] = (Q & 1) ? s1 : s0;
-    float(&nxt)[6] = (Q & 1) ? s0 : s1;
-    if constexpr (Q + 1 < QS) {
-      wg_group<oa(Q + 1, 0), oa(Q + 1, 1), oa(Q + 1, 2), oa(Q + 1, 3), oa(Q + 1, 4), ob(Q + 1)>(acc[0], acc[1], acc[2], acc[3], acc[4], cur[0], cur[1], cur[2], cur[3], cur[4],
-                                                                                               cur[5], nxt[0], nxt[1], nxt[2], nxt[3], nxt[4], nxt[5], addr_a, addr_b);
-      run<Q + 1>(acc, s0, s1, addr_a, addr_b);
-    } else {
-      wg_last(acc[0], acc[1], acc[2], acc[3], acc[4], cur[0], cur[1], cur[2], cur[3], cur[4], cur[5]);
-    }
-  }
-  static __device__ __forceinline__ void chunk(f32x16 (&acc)[5], unsigned addr_a, unsigned addr_b) {
-    float s0[6], s1[6];
-    wg_first<oa(0, 0), oa(0, 1), oa(0, 2), oa(0, 3), oa(0, 4), ob(0)>(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], addr_a, addr_b);
-    run<0>(acc, s0, s1, addr_a, addr_b);
-  }
-};
-
-template <int WAVES_C, int WAVES_N, int IS>
-__global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(WgradArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int NTAPS = 5, KT = 32;
-  constexpr int TC = WAVES_C * 32, TN = WAVES_N * 32;
-  constexpr int NT = 64 * WAVES_C * WAVES_N;
-  constexpr int R = IS * (KT - 1) + NTAPS;                 // x rows of one K-chunk (taps consecutive: checked by the launcher)
-  constexpr int SLAB = ((R * TC + 255) / 256) * 256;       // floats, rounded up to whole 1-KiB DMA pieces
-  constexpr int BUF = SLAB + KT * TN;
-  constexpr int STAGE_BYTES = BUF * 4;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wc = wave / WAVES_N, wn = wave % WAVES_N;
-  const int i32 = lane & 31, h = lane >> 5;
-  const int c0 = blockIdx.x * TC, n0 = blockIdx.y * TN, split = blockIdx.z;
-
-  int minoff = a.off[0];
-#pragma unroll
-  for (int j = 1; j < NTAPS; ++j) minoff = min(minoff, a.off[j]);
-
-  f32x16 acc[NTAPS];
-#pragma unroll
-  for (int j = 0; j < NTAPS; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-  const int b_lo = split * a.b_per_split, b_hi = min(a.B, b_lo + a.b_per_split);
-  const int cpb = (a.M + KT - 1) / KT;
-  const int n_chunks = (b_hi - b_lo) * cpb;
-
-  // per-lane byte offsets of the DMA granules inside one batch element, for m0 = 0 (chunk-invariant); the chunk adds m0 rows
-  constexpr int S_COUNT = R * (TC / 4);
-  constexpr int S_ITEMS = (S_COUNT + NT - 1) / NT;
-  constexpr int D_COUNT = KT * (TN / 4);
-  constexpr int D_ITEMS = D_COUNT / NT;
-  static_assert(D_COUNT % NT == 0, "dy tile must be whole DMA pieces per thread");
-  int soff[S_ITEMS], doff[D_ITEMS];
-#pragma unroll
-  for (int it = 0; it < S_ITEMS; ++it) {
-    const int id = tid + it * NT;
-    const int r = id / (TC / 4), c4 = id % (TC / 4);
-    soff[it] = ((minoff + r) * a.Cin + c0 + 4 * c4) * 4;
-  }
-#pragma unroll
-  for (int it = 0; it < D_ITEMS; ++it) {
-    const int id = tid + it * NT;
-    const int r = id / (TN / 4), n4 = id % (TN / 4);
-    doff[it] = (r * a.Cout + n0 + 4 * n4) * 4;
-  }
-  const int xbytes = __builtin_amdgcn_readfirstlane(a.Lin * a.Cin * 4), dybytes = __builtin_amdgcn_readfirstlane(a.M * a.Cout * 4);
-  auto dma_chunk = [&](int ch, float* stage) {
-    const int b = __builtin_amdgcn_readfirstlane(b_lo + ch / cpb), m0 = __builtin_amdgcn_readfirstlane((ch % cpb) * KT);
-    const uintptr_t xp = (uintptr_t)(a.x + (size_t)b * a.Lin * a.Cin), dp = (uintptr_t)(a.dy + (size_t)b * a.M * a.Cout);
-    // (unsigned halves: readfirstlane returns int, and a sign-extended low half would corrupt the high one)
-    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xp), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xp >> 32));
-    const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)dp), dhi = __builtin_amdgcn_readfirstlane((unsigned)(dp >> 32));
-    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)xhi << 32) | xlo), 0, xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ds = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)dhi << 32) | dlo), 0, dybytes, 0x00020000);
-    const int xrow = IS * m0 * a.Cin * 4, drow = m0 * a.Cout * 4;
-#pragma unroll
-    for (int it = 0; it < S_ITEMS; ++it) {
-      if ((it + 1) * NT <= S_COUNT || tid + it * NT < S_COUNT)          // x rows before 0 give a negative (= huge unsigned) offset: out of range -> 0
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lptr_t)(stage + (it * NT + (tid & ~63)) * 4), 16, soff[it] + xrow, 0, 0, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < D_ITEMS; ++it)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ds, (lptr_t)(stage + SLAB + (it * NT + (tid & ~63)) * 4), 16, doff[it] + drow, 0, 0, 0);
-  };
-
-  const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  const unsigned addr_a = lds0 + ((h * IS) * TC + wc * 32 + i32) * 4;
-  const unsigned addr_b = lds0 + (SLAB + h * TN + wn * 32 + i32) * 4;
-
-  if (n_chunks > 0) dma_chunk(0, smem);
-  __syncthreads();
-  for (int ch = 0; ch < n_chunks; ch += 2) {
-    dma_chunk(min(ch + 1, n_chunks - 1), smem + BUF);
-    WgChunk<TC, TN, KT, IS, STAGE_BYTES, 0>::chunk(acc, addr_a, addr_b);
-    __syncthreads();
-    if (ch + 1 < n_chunks) {
-      dma_chunk(min(ch + 2, n_chunks - 1), smem);
-      WgChunk<TC, TN, KT, IS, STAGE_BYTES, 1>::chunk(acc, addr_a, addr_b);
-      __syncthreads();
-    }
-  }
-  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
-
-  const int n = n0 + wn * 32 + i32;
-#pragma unroll
-  for (int j = 0; j < NTAPS; ++j) {
-    // accumulator j belongs to the tap at slab row offset j, i.e. the tap whose off equals minoff + j
-    int tap = 0;
-#pragma unroll
-    for (int t = 0; t < NTAPS; ++t)
-      if (a.off[t] - minoff == j) tap = t;
-    float* pj = a.part + ((size_t)split * NTAPS + tap) * a.Cin * a.Cout;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = c0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      pj[(size_t)c * a.Cout + n] = acc[j][r];
-    }
-  }
-#endif
-}
-
 // dw[e] = sum_s part[s][e]  (fixed order: reproducible); float4 over e
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, size_t n4, int splits, size_t stride4) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1144,22 +711,6 @@ size_t wgrad_workspace_bytes(int B, int Cin, int Cout, int ntaps) {
   return (size_t)s * ntaps * Cin * Cout * sizeof(float);
 }
 
-template <int WAVES_C, int WAVES_N, int IS>
-static void launch_wgrad_pipe(const WgradArgs& a, dim3 grid, hipStream_t s) {
-  constexpr int KT = 32, TC = WAVES_C * 32, TN = WAVES_N * 32;
-  constexpr int R = IS * (KT - 1) + 5, SLAB = ((R * TC + 255) / 256) * 256;
-  constexpr size_t lds = 2 * sizeof(float) * ((size_t)SLAB + (size_t)KT * TN);
-  static_assert(lds / 2 + (size_t)(R * TC + KT * TN) * 4 < 65536, "ds_read offsets must fit 16 bits");
-  if (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)wgrad_pipe_kernel<WAVES_C, WAVES_N, IS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-  }
-  hipLaunchKernelGGL((wgrad_pipe_kernel<WAVES_C, WAVES_N, IS>), grid, dim3(64 * WAVES_C * WAVES_N), lds, s, a);
-}
-
 template <int WAVES_C, int WAVES_N, int WNT, int NTAPS>
 static int launch_wgrad(WgradArgs a, float* dw, hipStream_t s) {
   constexpr int KT = 32, TC = WAVES_C * 32, TN = WAVES_N * WNT * 32;
@@ -1179,8 +730,7 @@ static int launch_wgrad(WgradArgs a, float* dw, hipStream_t s) {
   if constexpr (NTAPS == 5 && WNT == 1) {
     if (!no_pipe && a.Cin % TC == 0 && a.Cout % TN == 0 && maxoff - minoff + 1 == NTAPS && (size_t)a.Lin * a.Cin * 4 < 0x40000000ull &&
         (size_t)a.M * a.Cout * 4 < 0x40000000ull) {
-      if (a.in_stride == 1) launch_wgrad_pipe<WAVES_C, WAVES_N, 1>(a, grid, s);
-      else launch_wgrad_pipe<WAVES_C, WAVES_N, 2>(a, grid, s);
+      wgrad_pipe_launch(a, grid, WAVES_C == 2, s);                       // wgrad_pipe.hip
       piped = true;
     }
   }

@@ -1,0 +1,337 @@
+// Hand-scheduled, software-pipelined implicit-GEMM Conv1D (forward + data gradient) for gfx950; selected by conv_mfma_dispatch.
+#include <stdlib.h>
+#include <algorithm>
+#include "common.h"
+
+namespace gn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined variant of the all-DMA kernel: same tile, same LDS-DMA staging, same one-barrier double-stage chunk loop and
+// the same epilogue, but the MFMA block of a chunk is HAND-SCHEDULED.  hipcc turns the source-level operand double buffering of
+// conv_mfma_dma_kernel into "ds_read, s_waitcnt lgkmcnt(0), 2-4 MFMAs" (reads sunk next to their use, every wait a full drain), so a
+// wave exposes one LDS latency per 128-256 cycles of matrix work and the pipe only stays busy through the other waves of the SIMD.
+// Here each group of four MFMAs is one asm statement: the four ds_read_b32 of the NEXT group are issued first, a counted
+// s_waitcnt lgkmcnt(4) retires exactly the CURRENT group's operands (issued one group = 256 matrix cycles earlier), then the four
+// v_mfma_f32_32x32x2_f32 issue back to back.  All LDS addresses are chunk-invariant VGPRs (one per tap for the input slab, one for
+// the weight tile) plus compile-time 16-bit offsets (stage, channel pair, tile), so the block has no address arithmetic at all.
+// The layout is compile-time: IS (input stride) is a template parameter and the slab holds IS*(TM-1)+NTAPS rows (consecutive taps).
+// Descriptor and tile indices go through readfirstlane so that the buffer_load ... lds of the slab are not wrapped in waterfall loops.
+// ---------------------------------------------------------------------------------------------
+template <int OA0, int OA1, int OB0, int OB1>
+__device__ __forceinline__ void pipe_group(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, float a0, float a1, float b0, float b1, float& na0, float& na1,
+                                           float& nb0, float& nb1, unsigned addr_a, unsigned addr_b) {
+  asm volatile(
+      "ds_read_b32 %4, %12 offset:%14\n\t"
+      "ds_read_b32 %5, %12 offset:%15\n\t"
+      "ds_read_b32 %6, %13 offset:%16\n\t"
+      "ds_read_b32 %7, %13 offset:%17\n\t"
+      "s_waitcnt lgkmcnt(4)\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %8, %10, %0\n\t"
+      "v_mfma_f32_32x32x2_f32 %1, %8, %11, %1\n\t"
+      "v_mfma_f32_32x32x2_f32 %2, %9, %10, %2\n\t"
+      "v_mfma_f32_32x32x2_f32 %3, %9, %11, %3"
+      : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11), "=&v"(na0), "=&v"(na1), "=&v"(nb0), "=&v"(nb1)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(addr_a), "v"(addr_b), "i"(OA0), "i"(OA1), "i"(OB0), "i"(OB1)
+      : "memory");
+}
+__device__ __forceinline__ void pipe_last(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, float a0, float a1, float b0, float b1) {
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %4, %6, %0\n\t"
+      "v_mfma_f32_32x32x2_f32 %1, %4, %7, %1\n\t"
+      "v_mfma_f32_32x32x2_f32 %2, %5, %6, %2\n\t"
+      "v_mfma_f32_32x32x2_f32 %3, %5, %7, %3"
+      : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+      : "memory");
+}
+template <int OA0, int OA1, int OB0, int OB1>
+__device__ __forceinline__ void pipe_first(float& na0, float& na1, float& nb0, float& nb1, unsigned addr_a, unsigned addr_b) {
+  asm volatile(
+      "ds_read_b32 %0, %4 offset:%6\n\t"
+      "ds_read_b32 %1, %4 offset:%7\n\t"
+      "ds_read_b32 %2, %5 offset:%8\n\t"
+      "ds_read_b32 %3, %5 offset:%9"
+      : "=&v"(na0), "=&v"(na1), "=&v"(nb0), "=&v"(nb1)
+      : "v"(addr_a), "v"(addr_b), "i"(OA0), "i"(OA1), "i"(OB0), "i"(OB1)
+      : "memory");
+}
+
+template <int TN, int KC, int NTAPS, int STAGE_BYTES, int STAGE>
+struct PipeChunk {
+  static constexpr int SLOTS = NTAPS * (KC / 2);
+  static constexpr int oa(int g) { return STAGE * STAGE_BYTES + 8 * (g % (KC / 2)); }                                   // + the tap's address register
+  static constexpr int ob(int g) { return STAGE * STAGE_BYTES + ((g / (KC / 2)) * KC + 2 * (g % (KC / 2))) * TN * 4; }
+  // groups G..SLOTS-1; operand set P (= G & 1) is current, the other one receives group G+1
+  template <int G>
+  static __device__ __forceinline__ void run(f32x16 (&acc)[2][2], float (&s0)[4], float (&s1)[4], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
+    float(&cur)[4] = (G & 1) ? s1 : s0;
+    float(&nxt)[4] = (G & 1) ? s0 : s1;
+    if constexpr (G + 1 < SLOTS) {
+      pipe_group<oa(G + 1), oa(G + 1) + 32 * KC * 4, ob(G + 1), ob(G + 1) + 128>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], cur[0], cur[1], cur[2], cur[3], nxt[0], nxt[1],
+                                                                                   nxt[2], nxt[3], addr_a[(G + 1) / (KC / 2)], addr_b);
+      run<G + 1>(acc, s0, s1, addr_a, addr_b);
+    } else {
+      pipe_last(acc[0][0], acc[0][1], acc[1][0], acc[1][1], cur[0], cur[1], cur[2], cur[3]);
+    }
+  }
+  static __device__ __forceinline__ void chunk(f32x16 (&acc)[2][2], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
+    float s0[4], s1[4];
+    pipe_first<oa(0), oa(0) + 32 * KC * 4, ob(0), ob(0) + 128>(s0[0], s0[1], s0[2], s0[3], addr_a[0], addr_b);
+    run<0>(acc, s0, s1, addr_a, addr_b);
+  }
+};
+
+// Epilogue of the pipelined kernel.  The activation kind and the fused variants are dispatched ONCE per wave (template parameters), so
+// the 64 outputs of a lane are straight-line code: the generic epilogue of conv_mfma_kernel re-decides the activation per element and,
+// fully unrolled, is ~22k instructions of branches and waits (15 us per block against ~1 us here; measured with s_memrealtime stamps).
+// Addresses: one buffer descriptor per batch element, a per-lane byte offset (column, row-within-quad) and a scalar row offset per
+// register, so no 64-bit address arithmetic; rows past the end of the output (m >= M) fall outside the descriptor's range and are
+// dropped by the hardware bounds check (out row = out_stride*m + out_off >= Ly exactly when m >= M).
+// MODE 0: y = act(acc + bias);  MODE 1: ... then the fused Dropout keep-mask;  MODE 2: data gradient times the producer's act'(gy);
+// MODE 3: MODE 2 through the producer's dropout.
+template <int ACT, int MODE, int GACT>
+__device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&acc)[2][2], int b, int m_base, int n_base, int i32, int h) {
+  const uintptr_t yp = (uintptr_t)(a.y + (size_t)b * a.Ly * a.Cout);
+  const unsigned ylo = __builtin_amdgcn_readfirstlane((unsigned)yp), yhi = __builtin_amdgcn_readfirstlane((unsigned)(yp >> 32));
+  const int ybytes = __builtin_amdgcn_readfirstlane(a.Ly * a.Cout * 4);
+  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)yhi << 32) | ylo), 0, ybytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t msrd = ysrd, gsrd = ysrd;
+  if (MODE == 1 || MODE == 3) {                            // u8 masks: same element indexing, one byte per element
+    const uintptr_t mp = (uintptr_t)((MODE == 1 ? a.mask : a.gmask) + (size_t)b * a.Ly * a.Cout);
+    const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)mp), mhi = __builtin_amdgcn_readfirstlane((unsigned)(mp >> 32));
+    msrd = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)mhi << 32) | mlo), 0, ybytes >> 2, 0x00020000);
+  }
+  if (MODE >= 2) {
+    const uintptr_t gp = (uintptr_t)(a.gy + (size_t)b * a.Ly * a.Cout);
+    const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gp), ghi = __builtin_amdgcn_readfirstlane((unsigned)(gp >> 32));
+    gsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)ghi << 32) | glo), 0, ybytes, 0x00020000);
+  }
+  const int rowstride = a.t.out_stride * a.Cout;           // elements between consecutive m
+  const float ginv = (MODE == 3) ? 1.0f / a.gscale : 1.0f;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = n_base + nt * 32 + i32;
+    const float bias = a.bias ? a.bias[n] : 0.f;
+    const int voff = rowstride * (4 * h) + a.t.out_off * a.Cout + n;               // element offset of (row 4h, column n)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int soff = rowstride * (m_base + mt * 32 + (r & 3) + 8 * (r >> 2));   // wave-uniform
+        float v = acc[mt][nt][r] + bias;
+        if (ACT == GN_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (ACT == GN_ACT_LEAKY) v = v > 0.f ? v : a.act_param * v;
+        else if (ACT == GN_ACT_TANH) v = tanhf(v);
+        else if (ACT != GN_ACT_LINEAR) v = act_apply(v, a.act, a.act_param);         // rare kinds: runtime switch
+        if (MODE == 1) {
+          const unsigned k = __builtin_amdgcn_raw_buffer_load_b8(msrd, voff, soff, 0);
+          v = k ? v * a.keep_scale : 0.f;
+        }
+        if (MODE >= 2) {
+          const float gv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gsrd, voff * 4, soff * 4, 0));
+          if (MODE == 3) {
+            const unsigned k = __builtin_amdgcn_raw_buffer_load_b8(msrd, voff, soff, 0);
+            const float y0 = gv * ginv;
+            const float dg = GACT == GN_ACT_LEAKY ? (y0 > 0.f ? 1.f : a.gparam) : act_grad_from_y(y0, a.gact, a.gparam);
+            v = k ? v * a.gscale * dg : 0.f;
+          } else {
+            v *= GACT == GN_ACT_RELU ? (gv > 0.f ? 1.f : 0.f) : act_grad_from_y(gv, a.gact, a.gparam);
+          }
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrd, voff * 4, soff * 4, 0);
+      }
+    }
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int NTAPS, int IS>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_pipe_kernel(ConvArgs a, int m_tiles, int n_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int WM = 2, WN = 2, KC = 8;
+  constexpr int TM = WAVES_M * WM * 32;
+  constexpr int TN = WAVES_N * WN * 32;
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int R = IS * (TM - 1) + NTAPS;                 // staged input rows: the launcher checks that the taps are consecutive
+  constexpr int RPER = (R + IS - 1) / IS;
+  constexpr int SLAB = IS * RPER * KC;                     // floats
+  constexpr int BUF = SLAB + NTAPS * KC * TN;
+  constexpr int STAGE_BYTES = BUF * 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int bid = blockIdx.x;
+  const int n_tile = __builtin_amdgcn_readfirstlane(bid % n_tiles);
+  const int rest = bid / n_tiles;
+  const int m_tile = __builtin_amdgcn_readfirstlane(rest % m_tiles);
+  const int b = __builtin_amdgcn_readfirstlane(rest / m_tiles);
+  const int m0 = m_tile * TM, n0 = n_tile * TN;
+
+  int minoff = a.t.off[0];
+#pragma unroll
+  for (int j = 1; j < NTAPS; ++j) minoff = min(minoff, a.t.off[j]);
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const int t_base = IS * m0 + minoff;
+  // descriptor inputs made PROVABLY wave-uniform (pointer halves and byte count through readfirstlane): otherwise hipcc wraps every
+  // buffer_load ... lds in a waterfall loop (v_readfirstlane x4, compare, saveexec, load, loop), ~12 instructions per DMA piece
+  const uintptr_t xbp = (uintptr_t)(a.x + (size_t)b * a.Lin * a.Cin);
+  const unsigned xb_lo = __builtin_amdgcn_readfirstlane((unsigned)xbp), xb_hi = __builtin_amdgcn_readfirstlane((unsigned)(xbp >> 32));
+  const int xbytes = __builtin_amdgcn_readfirstlane(a.Lin * a.Cin * 4);
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)xb_hi << 32) | xb_lo), 0, xbytes, 0x00020000);
+
+  constexpr int S_COUNT = SLAB / 4;                        // 16-byte granules of one slab stage, in LDS order
+  constexpr int S_ITEMS = (S_COUNT + NT - 1) / NT;
+  constexpr int W_TOTAL = NTAPS * KC * (TN / 4);
+  constexpr int W_ITEMS = (W_TOTAL + NT - 1) / NT;
+  int soff[S_ITEMS];
+#pragma unroll
+  for (int it = 0; it < S_ITEMS; ++it) {
+    const int id = tid + it * NT;
+    const int lr = id / (KC / 4), c4 = id % (KC / 4);
+    const int r = (IS == 1) ? lr : (lr < RPER ? 2 * lr : 2 * (lr - RPER) + 1);
+    soff[it] = (id < S_COUNT && r < R) ? ((t_base + r) * a.Cin + 4 * c4) * 4 : 0x40000000;   // out of range -> the descriptor returns 0
+  }
+  const float* wp[W_ITEMS];
+#pragma unroll
+  for (int it = 0; it < W_ITEMS; ++it) {
+    const int id = min(tid + it * NT, W_TOTAL - 1);
+    const int n4 = id % (TN / 4);
+    const int kk = (id / (TN / 4)) % KC;
+    const int j = id / ((TN / 4) * KC);
+    wp[it] = a.w + ((size_t)a.t.widx[j] * a.Cin + kk) * a.Cout + n0 + 4 * n4;
+  }
+  auto dma_chunk = [&](int c0, float* stage) {
+#pragma unroll
+    for (int it = 0; it < S_ITEMS; ++it) {
+      if ((it + 1) * NT <= S_COUNT || tid + it * NT < S_COUNT)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stage + (it * NT + (tid & ~63)) * 4), 16, soff[it] + c0 * 4, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < W_ITEMS; ++it)
+      if ((it + 1) * NT <= W_TOTAL || (tid & ~63) + it * NT < W_TOTAL)
+        __builtin_amdgcn_global_load_lds((gptr_t)(wp[it] + (size_t)c0 * a.Cout), (lptr_t)(stage + SLAB + (it * NT + (tid & ~63)) * 4), 16, 0, 0);
+  };
+
+  // chunk-invariant LDS byte addresses of this lane's operands in stage 0
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  unsigned addr_a[NTAPS];
+#pragma unroll
+  for (int j = 0; j < NTAPS; ++j) {
+    const int d = a.t.off[j] - minoff;
+    const int rowbase = (IS == 1) ? d : ((d & 1) * RPER + (d >> 1));
+    addr_a[j] = lds0 + ((rowbase + wm * WM * 32 + i32) * KC + h) * 4;
+  }
+  const unsigned addr_b = lds0 + (SLAB + h * TN + wn * WN * 32 + i32) * 4;
+
+  const int n_chunks = a.Cin / KC;
+  dma_chunk(0, smem);
+  __syncthreads();                                         // drains the LDS-DMA (vmcnt(0)) in front of the barrier
+
+  for (int ch = 0; ch < n_chunks; ch += 2) {
+    dma_chunk(min(ch + 1, n_chunks - 1) * KC, smem + BUF);                        // chunk ch+1 flies during this chunk's MFMAs
+    PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::chunk(acc, addr_a, addr_b);
+    __syncthreads();
+    if (ch + 1 < n_chunks) {
+      dma_chunk(min(ch + 2, n_chunks - 1) * KC, smem);
+      PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::chunk(acc, addr_a, addr_b);
+      __syncthreads();
+    }
+  }
+  // MFMA results written inside asm: the compiler inserts no wait states for its own readers of acc
+  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+
+  const int m_base = m0 + __builtin_amdgcn_readfirstlane(wm) * WM * 32, n_base = n0 + wn * WN * 32;
+  // uniform dispatch, decided once; every case is straight-line code.  Specialised: the forms the three networks run (forward
+  // linear / relu / LeakyReLU / tanh, LeakyReLU + dropout, data gradient through relu, through LeakyReLU + dropout); the rest take
+  // the variants that decide the activation per element.
+  const int mode = a.gy ? (a.gmask ? 3 : 2) : (a.mask ? 1 : 0);
+#define GN_EPI(A_, M_, G_) pipe_epilogue<A_, M_, G_>(a, acc, b, m_base, n_base, i32, h)
+  if (mode == 0) {
+    switch (a.act) {
+      case GN_ACT_LINEAR: GN_EPI(GN_ACT_LINEAR, 0, -1); break;
+      case GN_ACT_RELU: GN_EPI(GN_ACT_RELU, 0, -1); break;
+      case GN_ACT_LEAKY: GN_EPI(GN_ACT_LEAKY, 0, -1); break;
+      case GN_ACT_TANH: GN_EPI(GN_ACT_TANH, 0, -1); break;
+      default: GN_EPI(-1, 0, -1); break;
+    }
+  } else if (mode == 1) {
+    if (a.act == GN_ACT_LEAKY) GN_EPI(GN_ACT_LEAKY, 1, -1);
+    else GN_EPI(-1, 1, -1);
+  } else if (mode == 2) {
+    if (a.act == GN_ACT_LINEAR && a.gact == GN_ACT_RELU) GN_EPI(GN_ACT_LINEAR, 2, GN_ACT_RELU);
+    else GN_EPI(-1, 2, -1);
+  } else {
+    if (a.act == GN_ACT_LINEAR && a.gact == GN_ACT_LEAKY) GN_EPI(GN_ACT_LINEAR, 3, GN_ACT_LEAKY);
+    else GN_EPI(-1, 3, -1);
+  }
+#undef GN_EPI
+#endif
+}
+
+template <int WAVES_M, int WAVES_N, int NTAPS, int IS>
+static int launch_conv_pipe(const ConvArgs& a, hipStream_t s) {
+  constexpr int KC = 8, TM = WAVES_M * 64, TN = WAVES_N * 64;
+  constexpr int R = IS * (TM - 1) + NTAPS, RPER = (R + IS - 1) / IS;
+  constexpr size_t lds = 2 * sizeof(float) * ((size_t)IS * RPER * KC + (size_t)NTAPS * KC * TN);
+  static_assert(lds <= 160 * 1024, "stage too large");
+  static_assert(lds / 2 + (NTAPS * KC + 8) * TN * 4 < 65536, "ds_read offsets must fit 16 bits");
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+  }
+  const int m_tiles = (a.M + TM - 1) / TM, n_tiles = a.Cout / TN;
+  const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
+  if (blocks == 0 || blocks > 0x7fffffffull) {
+    set_error("conv_mfma_pipe: bad grid %zu", blocks);
+    return GN_EINVAL;
+  }
+  prof_begin(s);
+  hipLaunchKernelGGL((conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles);
+  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0, 4.0 * ((double)a.B * a.Lin * a.Cin + (double)a.t.ntaps * a.Cin * a.Cout + (double)a.B * a.M * a.Cout));
+  return check_launch("conv_mfma_pipe");
+}
+
+
+// Selection for conv_mfma_dispatch (conv_mfma.hip): tile (tall 256 x 64 or square 128 x 128), tap count, input stride.  *launched stays
+// false when the shape is outside what the pipelined kernel covers (the caller then runs the plain DMA kernel).
+int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
+  static const bool no_pipe = getenv("GN_CONV_NOPIPE") != nullptr;      // A/B switch
+  *launched = false;
+  const int nt = a.t.ntaps;
+  int minoff = a.t.off[0], maxoff = a.t.off[0];
+  for (int j = 1; j < nt; ++j) {
+    minoff = std::min(minoff, a.t.off[j]);
+    maxoff = std::max(maxoff, a.t.off[j]);
+  }
+  if (no_pipe || nt < 2 || nt > 5 || maxoff - minoff + 1 > nt || (size_t)a.Ly * a.Cout * 4 >= 0x40000000ull) return GN_OK;
+  if (a.t.in_stride != 1 && !(a.t.in_stride == 2 && nt == 5)) return GN_OK;
+  *launched = true;
+#define GN_PIPE(NT_, IS_) return tall ? launch_conv_pipe<4, 1, NT_, IS_>(a, s) : launch_conv_pipe<2, 2, NT_, IS_>(a, s)
+  if (a.t.in_stride == 2) { GN_PIPE(5, 2); }
+  switch (nt) {
+    case 2: GN_PIPE(2, 1);
+    case 3: GN_PIPE(3, 1);
+    case 4: GN_PIPE(4, 1);
+    default: GN_PIPE(5, 1);
+  }
+#undef GN_PIPE
+}
+
+}  // namespace gn
