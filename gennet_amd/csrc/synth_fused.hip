@@ -23,6 +23,8 @@ struct ChirpCoeffsF {
   double piM, f_merg, f_ring, sigma, f_cut, amp0, t0, wnorm;
   double psi[6];
   double nyq_re, nyq_im;
+  double m1, m2;          // the template's masses (given, or drawn from the prior by the block itself)
+  int idx, pad_;
 };
 
 struct SynthArgs {
@@ -36,7 +38,17 @@ struct SynthArgs {
   int32_t* ref_out;         // (nb,) or NULL
   int nb, N, roll, crop0, crop_len, peak_off;
   double df, f_low, dist_mpc, iota, phi0, Fp, Fc, g;
+  // prior mode (m1 == NULL): every block draws its own (m1, m2, idx) from the hunt_constrain prior (gw_template_maker.py:327-339, :422-426)
+  // with a counter-based Philox stream, so an on-line batch needs no host random numbers and no host -> device parameter copy
+  uint64_t seed, counter;
+  int idx_lo, idx_hi;
+  double m_min, M_max;
+  float* labels;           // (nb, 2) [mc, m2/m1] or NULL
+  double* m_out;           // (nb, 2) [m1, m2] or NULL
+  int32_t* idx_out;        // (nb,) or NULL
 };
+
+constexpr int kPriorTrials = 1024;   // Philox counters reserved per template (acceptance of the prior box is ~4.5 % per trial)
 
 __constant__ double kFf[4][3] = {{2.9740e-1, 4.4810e-2, 9.5560e-2}, {5.9411e-1, 8.9794e-2, 1.9111e-1}, {5.0801e-1, 7.7515e-2, 2.2369e-2}, {8.4845e-1, 1.2848e-1, 2.7299e-1}};
 __constant__ double kPsif[6][3] = {{1.7516e-1, 7.9483e-2, -7.2390e-2}, {-5.1571e1, -1.7595e1, 1.3253e1}, {6.5866e2, 1.7803e2, -1.5972e2},
@@ -190,8 +202,37 @@ __global__ __launch_bounds__(NT, 2) void synth_fused_kernel(SynthArgs a) {
   int* ri = reinterpret_cast<int*>(rv + 16);
   const int tid = threadIdx.x, b = blockIdx.x;
 
+  if (a.m1 == nullptr) {
+    // rejection sampling of the mass prior by wave 0: lane l tries trial 64*round + l, the LOWEST accepted trial wins (deterministic in
+    // (seed, counter, b)); two log-uniform component masses in [m_min, M_max - m_min] s.t. m1 + m2 < M_max, m1 >= m2, q >= 0.5,
+    // 20 <= mc <= 35 (the reference's flag expression), then idx uniform in [idx_lo, idx_hi)
+    if (tid < 64) {
+      const double lmin = log(a.m_min), lspan = log(a.M_max - a.m_min) - lmin;
+      for (int round = 0; round < kPriorTrials / 64; ++round) {
+        const Philox4 r = philox4x32_10(a.counter + (uint64_t)b * kPriorTrials + (uint64_t)(round * 64 + tid), a.seed);
+        const double x1 = exp(lmin + ((double)r.v[0] + 0.5) * (1.0 / 4294967296.0) * lspan), x2 = exp(lmin + ((double)r.v[1] + 0.5) * (1.0 / 4294967296.0) * lspan);
+        const double eta = x1 * x2 / ((x1 + x2) * (x1 + x2)), mc = (x1 + x2) * pow(eta, 0.6);
+        const bool ok = (x1 + x2 < a.M_max) && (x1 > a.m_min) && (x2 > a.m_min) && (x1 >= x2) && (x2 / x1 >= 0.5) && (mc >= 20.0) && (mc <= 35.0);
+        const unsigned long long hit = __ballot(ok);
+        if (hit) {
+          if (tid == (int)__ffsll((long long)hit) - 1) {
+            cf->m1 = x1; cf->m2 = x2;
+            cf->idx = a.idx_hi > a.idx_lo ? a.idx_lo + (int)(((uint64_t)r.v[2] * (uint64_t)(a.idx_hi - a.idx_lo)) >> 32) : a.idx_lo;
+            if (a.labels) { a.labels[2 * (size_t)b] = (float)mc; a.labels[2 * (size_t)b + 1] = (float)(x2 / x1); }
+            if (a.m_out) { a.m_out[2 * (size_t)b] = x1; a.m_out[2 * (size_t)b + 1] = x2; }
+          }
+          break;
+        }
+        if (round == kPriorTrials / 64 - 1 && tid == 0) { cf->m1 = 36.0; cf->m2 = 29.0; cf->idx = a.idx_lo; }   // (probability ~1e-21)
+      }
+    }
+    __syncthreads();
+    if (tid == 0 && a.idx_out) a.idx_out[b] = cf->idx;
+  } else if (tid == 0) {
+    cf->m1 = a.m1[b]; cf->m2 = a.m2[b]; cf->idx = a.idx[b];
+  }
   if (tid == 0) {
-    chirp_coeffs_f(a.m1[b], a.m2[b], a.dist_mpc, cf);
+    chirp_coeffs_f(cf->m1, cf->m2, a.dist_mpc, cf);
     const double2 nq = chirp_bin(*cf, M, a.df, a.f_low, a.phi0, a.scale);                      // Nyquist bin: irfft uses its real part only
     cf->nyq_re = nq.x; cf->nyq_im = nq.y;
   }
@@ -284,7 +325,7 @@ __global__ __launch_bounds__(NT, 2) void synth_fused_kernel(SynthArgs a) {
   __syncthreads();
   const int ref = ri[0];
   if (tid == 0 && a.ref_out) a.ref_out[b] = ref;
-  start = (long)ref - a.idx[b] - a.peak_off;                  // python slice ht[start:]: negative counts from the end, clamped at 0
+  start = (long)ref - c.idx - a.peak_off;                  // python slice ht[start:]: negative counts from the end, clamped at 0
   if (start < 0) { start += N; if (start < 0) start = 0; }
   emit(1);
   __syncthreads();
@@ -338,5 +379,22 @@ extern "C" int gn_synth_templates(const double* m1, const double* m2, const int3
   a.m1 = m1; a.m2 = m2; a.idx = idx; a.scale = scale; a.W = (const double2*)twiddle; a.out64 = out_f64; a.out32 = out_f32; a.ref_out = ref_idx;
   a.nb = nb; a.N = N; a.roll = roll; a.crop0 = crop0; a.crop_len = crop_len; a.peak_off = peak_off;
   a.df = df; a.f_low = f_low; a.dist_mpc = dist_mpc; a.iota = iota; a.phi0 = phi0; a.Fp = Fp; a.Fc = Fc; a.g = g;
+  a.seed = 0; a.counter = 0; a.idx_lo = a.idx_hi = 0; a.m_min = 5.0; a.M_max = 100.0; a.labels = nullptr; a.m_out = nullptr; a.idx_out = nullptr;
+  return synth_templates(a, (hipStream_t)stream);
+}
+
+extern "C" int gn_synth_templates_prior(const double* scale, const double* twiddle, double* out_f64, float* out_f32, float* labels, double* m_out, int32_t* idx_out,
+                                        int32_t* ref_idx, int nb, int N, int roll, int crop0, int crop_len, int peak_off, double df, double f_low, double dist_mpc,
+                                        double iota, double phi0, double Fp, double Fc, double g, uint64_t seed, uint64_t counter, int idx_lo, int idx_hi,
+                                        double m_min, double M_max, void* stream) {
+  GN_REQUIRE(scale && twiddle && (out_f64 || out_f32) && nb >= 0, "synth_templates_prior: bad arguments");
+  GN_REQUIRE(roll >= 0 && roll < N && crop0 >= 0 && crop_len > 0 && crop0 + crop_len <= N && df > 0, "synth_templates_prior: bad window (N %d roll %d crop %d+%d)",
+             N, roll, crop0, crop_len);
+  GN_REQUIRE(idx_hi >= idx_lo && m_min > 0 && M_max > 2 * m_min, "synth_templates_prior: bad prior (idx [%d, %d), masses %g .. %g)", idx_lo, idx_hi, m_min, M_max);
+  SynthArgs a;
+  a.m1 = nullptr; a.m2 = nullptr; a.idx = nullptr; a.scale = scale; a.W = (const double2*)twiddle; a.out64 = out_f64; a.out32 = out_f32; a.ref_out = ref_idx;
+  a.nb = nb; a.N = N; a.roll = roll; a.crop0 = crop0; a.crop_len = crop_len; a.peak_off = peak_off;
+  a.df = df; a.f_low = f_low; a.dist_mpc = dist_mpc; a.iota = iota; a.phi0 = phi0; a.Fp = Fp; a.Fc = Fc; a.g = g;
+  a.seed = seed; a.counter = counter; a.idx_lo = idx_lo; a.idx_hi = idx_hi; a.m_min = m_min; a.M_max = M_max; a.labels = labels; a.m_out = m_out; a.idx_out = idx_out;
   return synth_templates(a, (hipStream_t)stream);
 }

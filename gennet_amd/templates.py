@@ -287,6 +287,28 @@ class Synth(object):
             out = o32
         return out, torch.cat(refs)
 
+    PRIOR_TRIALS = 1024           # Philox counters one template of templates_prior consumes (csrc/synth_fused.hip: kPriorTrials)
+
+    def templates_prior(self, nb, seed, counter, idx_lo, idx_hi, g=1.0, dtype=torch.float32, want_params=False):
+        """nb templates whose (m1, m2, idx) are drawn from the hunt_constrain prior INSIDE the synthesis kernel (gn_synth_templates_prior):
+        returns (crops (nb, fs), labels (nb, 2) = [mc, m2/m1] fp32, ref_idx) -- plus (m1m2 (nb, 2) f64, idx (nb,) i32) with want_params.
+        A pure function of (seed, counter); the caller advances counter by nb * PRIOR_TRIALS."""
+        if self.N not in self.FUSED_N:
+            raise NotImplementedError('templates_prior: series length %d is outside the fused kernel\'s range %r' % (self.N, self.FUSED_N))
+        out = torch.empty((nb, self.fs), dtype=dtype, device=device())
+        labels = torch.empty((nb, 2), dtype=torch.float32, device=device())
+        ref = torch.empty((nb,), dtype=torch.int32, device=device())
+        mo = torch.empty((nb, 2), dtype=torch.float64, device=device()) if want_params else None
+        io = torch.empty((nb,), dtype=torch.int32, device=device()) if want_params else None
+        if nb:
+            c0 = int((self.T_obs / 2) * self.fs - self.fs / 2)
+            _lib.call('gn_synth_templates_prior', self.scale.data_ptr(), twiddles(self.N).data_ptr(), out.data_ptr() if dtype == torch.float64 else None,
+                      out.data_ptr() if dtype == torch.float32 else None, labels.data_ptr(), None if mo is None else mo.data_ptr(),
+                      None if io is None else io.data_ptr(), ref.data_ptr(), nb, self.N, self.fs, c0, self.fs, self.peak_off, 1.0 / self.T_obs, self.f_low,
+                      self.dist_mpc, float(IOTA), float(PHI), float(self.Fp), float(self.Fc), float(g), int(seed), int(counter), int(idx_lo), int(idx_hi), 5.0, 100.0, _s())
+        return (out, labels, ref, mo, io) if want_params else (out, labels, ref)
+
+
 
 def make_bbh(hp, hc, fs, ra, dec, psi, det):
     """gw_template_maker.py:577-630: antenna combination.  The reference also fits and evaluates three time-shift splines and
@@ -445,15 +467,17 @@ def save_sanity_check(path, ts, gw_norm_constant=1.0):
 # --------------------------------------------------------------------------------------------------- on-GPU synthesis inside the train loop
 class OnlineBank(object):
     """BASELINE config 5: templates (and, optionally, PSD-coloured noise whitened with the same PSD) synthesised on the GPU inside
-    the training loop instead of being read from a stored bank -- no template ever touches host memory.
+    the training loop instead of being read from a stored bank -- no template, and no template parameter, ever touches host memory.
 
-    Every draw() is a fresh batch from the prior: masses by the hunt_constrain rejection rule (vectorised on the host: a few
-    thousand uniforms), idx ~ randint(convert_beta(beta)), then chirp -> whiten -> irFFT -> align -> crop on the device, scaled by
-    gw_norm_constant, labels [mc, m2/m1].  The stream is this object's own RandomState(seed): data-parallel ranks pass different
-    seeds and never exchange anything (SURVEY 8e).  noise='coloured' adds gen_noise (Philox) -> whiten_data('td') -> central crop;
-    noise='white' adds N(0,1) as the reference's train loops do (bbhMahoGANy.py:1161, :1277)."""
+    Every draw() is a fresh batch from the prior, made by ONE kernel (gn_synth_templates_prior): each workgroup draws its masses by
+    the hunt_constrain rejection rule and its idx from randint(convert_beta(beta)) out of a counter-based Philox stream, evaluates
+    the chirp, whitens, transforms, aligns and crops, scales by gw_norm_constant and writes the fp32 row and its labels [mc, m2/m1].
+    The stream is (seed, counter): data-parallel ranks pass different seeds and never exchange anything; two banks with
+    the same seed produce the same batches.  noise='coloured' adds gen_noise (Philox) -> whiten_data('td') -> central crop;
+    noise='white' adds N(0,1) as the reference's train loops do (bbhMahoGANy.py:1161, :1277).  Series lengths the fused kernel does
+    not cover (N < 1024) draw the parameters on the host (prior='host' forces that everywhere)."""
 
-    def __init__(self, fs, T_obs=4, psd=None, gw_norm_constant=1.0, beta=(0.45, 0.55), seed=1, noise=None, peak_off=PEAK_OFFSET):
+    def __init__(self, fs, T_obs=4, psd=None, gw_norm_constant=1.0, beta=(0.45, 0.55), seed=1, noise=None, peak_off=PEAK_OFFSET, prior=None):
         self.fs, self.T_obs = int(fs), int(T_obs)
         self.N = self.fs * self.T_obs
         self.psd = np.asarray(psd, np.float64)
@@ -463,12 +487,14 @@ class OnlineBank(object):
         self.rng = np.random.RandomState(seed)
         self.noise = noise
         self.seed = int(seed)
-        self.counter = 0
+        self.counter = 0                   # noise stream position
+        self.prior_counter = 0             # parameter stream position (seed + 2^32: disjoint from the noise stream)
         self.n_pix = self.fs
+        self.prior = prior or ('device' if self.N in Synth.FUSED_N else 'host')
         self._win = _d64(tukey(self.N, alpha=1.0 / 8.0)) if noise == 'coloured' else None
 
     def draw_masses(self, n):
-        """hunt_constrain prior (gw_template_maker.py:327-339), vectorised rejection sampling."""
+        """hunt_constrain prior (gw_template_maker.py:327-339), vectorised rejection sampling on the host (prior='host')."""
         out1, out2 = [], []
         lo, span = np.log(5.0), np.log(95.0) - np.log(5.0)
         need = n
@@ -482,13 +508,23 @@ class OnlineBank(object):
             need -= len(out1[-1])
         return np.concatenate(out1), np.concatenate(out2)
 
-    def draw(self, batch):
-        """-> (images (batch, fs) fp32, labels (batch, 2) fp32), both device tensors."""
+    def _templates(self, batch, dtype):
+        if self.prior == 'device':
+            out, labels, _ = self.syn.templates_prior(batch, self.seed + (1 << 32), self.prior_counter, self.lo, self.hi, g=self.g, dtype=dtype)
+            self.prior_counter += batch * Synth.PRIOR_TRIALS
+            return out, labels
         m1, m2 = self.draw_masses(batch)
         idx = self.rng.randint(self.lo, self.hi, batch) if self.hi > self.lo else np.full(batch, self.lo)
+        out, _ = self.syn.templates(m1, m2, idx, g=self.g, dtype=dtype)
+        eta = m1 * m2 / (m1 + m2) ** 2
+        labels = torch.as_tensor(np.stack([(m1 + m2) * eta ** 0.6, m2 / m1], axis=1).astype(np.float32)).to(device())
+        return out, labels
+
+    def draw(self, batch):
+        """-> (images (batch, fs) fp32, labels (batch, 2) fp32), both device tensors."""
         c0 = int((self.T_obs / 2) * self.fs - self.fs / 2)
         if self.noise == 'coloured':
-            ts, _ = self.syn.templates(m1, m2, idx, g=self.g)
+            ts, labels = self._templates(batch, torch.float64)
             nz = gen_noise_device(self.fs, self.T_obs, self.psd, batch, self.seed, self.counter)
             self.counter += batch * (self.N // 2 + 1)
             _mul(nz, self._win, False)
@@ -497,11 +533,9 @@ class OnlineBank(object):
             out = torch.empty((batch, self.fs), dtype=torch.float32, device=device())
             _lib.call('gn_f64_to_f32', ts.data_ptr(), out.data_ptr(), 1.0, ts.numel(), _s())
         else:
-            out, _ = self.syn.templates(m1, m2, idx, g=self.g, dtype=torch.float32)      # fp32 rows straight from the fused kernel
+            out, labels = self._templates(batch, torch.float32)       # fp32 rows straight from the fused kernel
         if self.noise == 'white':
             _lib.call('gn_fill_normal', (nz32 := torch.empty_like(out)).data_ptr(), out.numel(), 0.0, 1.0, self.seed, self.counter, _s())
             self.counter += out.numel()
             _lib.call('gn_axpy', out.data_ptr(), nz32.data_ptr(), 1.0, out.numel(), _s())
-        eta = m1 * m2 / (m1 + m2) ** 2
-        labels = torch.as_tensor(np.stack([(m1 + m2) * eta ** 0.6, m2 / m1], axis=1).astype(np.float32)).to(device())
         return out, labels

@@ -241,6 +241,17 @@ int gn_synth_templates(const double* m1, const double* m2, const int32_t* idx, c
                        double* out_f64, float* out_f32, int32_t* ref_idx, int nb, int N, int roll, int crop0, int crop_len,
                        int peak_off, double df, double f_low, double dist_mpc, double iota, double phi0, double Fp, double Fc, double g,
                        void* stream);
+/* The same kernel with the PRIOR drawn inside it (BASELINE configs[4]: synthesis fused into the training loop): every template draws
+ * (m1, m2) from gen_masses('hunt_constrain') (gw_template_maker.py:327-339: log-uniform component masses in [m_min, M_max - m_min]
+ * subject to m1 + m2 < M_max, m1 >= m2, m2/m1 >= 0.5, 20 <= mc <= 35, by rejection) and idx uniformly from [idx_lo, idx_hi)
+ * (gen_par :422-426) from a counter-based Philox stream: template b uses counters counter + 1024*b .. counter + 1024*b + 1023 of
+ * stream `seed`, the lowest accepted trial wins, so a batch is a pure function of (seed, counter) and ranks / steps take disjoint
+ * counter ranges (advance by 1024 per template).  Not the reference's MT19937 stream (statistical parity only).
+ * labels (nb, 2) = [mc, m2/m1] fp32, m_out (nb, 2) = [m1, m2], idx_out (nb,): each may be NULL. */
+int gn_synth_templates_prior(const double* scale, const double* twiddle, double* out_f64, float* out_f32, float* labels, double* m_out,
+                             int32_t* idx_out, int32_t* ref_idx, int nb, int N, int roll, int crop0, int crop_len, int peak_off,
+                             double df, double f_low, double dist_mpc, double iota, double phi0, double Fp, double Fc, double g,
+                             uint64_t seed, uint64_t counter, int idx_lo, int idx_hi, double m_min, double M_max, void* stream);
 /* gen_noise (gw_template_maker.py:161-193) spectrum: X[b,f] = amp[f]*(xi_re + i xi_im), DC = 0 (Philox normals, re block then im block) */
 int gn_noise_fd(const double* amp, double* X, int nb, int Nf, uint64_t seed, uint64_t offset, void* stream);
 /* x *= s (fp64), used for N*df and gw_norm_constant scalings; and fp64 -> fp32 narrowing with scale */

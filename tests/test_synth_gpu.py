@@ -203,6 +203,40 @@ def test_fused_synthesiser_equals_separate_kernels_and_oracle(fs):
         assert hp[-1] != 0                                                             # the Nyquist-bin term was really exercised
 
 
+def test_prior_drawn_inside_the_kernel():
+    """gn_synth_templates_prior (BASELINE config 5): masses and idx drawn by each workgroup from a Philox stream.  (i) the returned
+    parameters fed to the explicit-parameter kernel give bit-identical rows, (ii) every draw obeys the reference's hunt_constrain
+    rule and the idx window, (iii) a batch is a pure function of (seed, counter) and disjoint counter ranges give different draws,
+    (iv) the accepted (mc, q) follow the same distribution as the host rejection sampler (two-sample KS, alpha 1e-3)."""
+    from scipy.stats import ks_2samp
+    from gennet_amd import templates as T
+    fs, Tobs = 1024, 4
+    psd = S.analytic_psd(fs * 2 + 1, 0.25)
+    syn = T.Synth(fs, Tobs, psd)
+    lo, hi = T.convert_beta([0.45, 0.55], fs, Tobs)
+    nb = 4096
+    out, labels, ref, mm, idx = syn.templates_prior(nb, seed=7, counter=0, idx_lo=lo, idx_hi=hi, g=1.3, dtype=torch.float64, want_params=True)
+    m = mm.cpu().numpy(); ix = idx.cpu().numpy(); lab = labels.cpu().numpy()
+    again, ref2 = syn.templates(m[:, 0], m[:, 1], ix, g=1.3)
+    assert torch.equal(out, again) and torch.equal(ref, ref2)
+    m1, m2 = m[:, 0], m[:, 1]
+    eta = m1 * m2 / (m1 + m2) ** 2; mc = (m1 + m2) * eta ** 0.6
+    assert np.all((m1 + m2 < 100) & (m1 > 5) & (m2 > 5) & (m1 >= m2) & (m2 / m1 >= 0.5) & (mc >= 20) & (mc <= 35))
+    assert ix.min() >= lo and ix.max() < hi and len(np.unique(ix)) > 0.8 * (hi - lo)
+    assert np.allclose(lab[:, 0], mc, rtol=1e-6) and np.allclose(lab[:, 1], m2 / m1, rtol=1e-6)
+    o2, l2, _ = syn.templates_prior(64, 7, 0, lo, hi, g=1.3, dtype=torch.float64)
+    assert torch.equal(o2, out[:64]) and torch.equal(l2, labels[:64])                       # same (seed, counter): same templates
+    o3, _, _ = syn.templates_prior(64, 7, 64 * T.Synth.PRIOR_TRIALS, lo, hi, g=1.3, dtype=torch.float64)
+    assert torch.equal(o3, out[64:128])                                                      # counter ranges tile: b-th template of a later call
+    o4, _, _ = syn.templates_prior(64, 8, 0, lo, hi, g=1.3, dtype=torch.float64)
+    assert not torch.equal(o4, o2)
+    host = T.OnlineBank(fs, Tobs, psd, seed=3, prior='host')
+    h1, h2 = host.draw_masses(nb)
+    heta = h1 * h2 / (h1 + h2) ** 2
+    assert ks_2samp(mc, (h1 + h2) * heta ** 0.6).pvalue > 1e-3 and ks_2samp(m2 / m1, h2 / h1).pvalue > 1e-3
+    assert ks_2samp(ix, host.rng.randint(lo, hi, nb)).pvalue > 1e-3
+
+
 def test_fused_synthesiser_empty_and_unsupported_lengths():
     from gennet_amd import _lib, templates as T
     syn = T.Synth(256, 4, S.analytic_psd(513, 0.25))
