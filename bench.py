@@ -44,7 +44,7 @@ def pmc_traffic_per_launch():
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             ks = json.load(open(path))['kernels']
-            sel = [v for k, v in ks.items() if 'conv_mfma_kernel' in k or 'conv_mfma_dma_kernel' in k]
+            sel = [v for k, v in ks.items() if 'conv_mfma' in k]          # conv_mfma_pipe_kernel, conv_mfma_dma_kernel, conv_mfma_kernel
             n = sum(v['launches'] for v in sel)
             b = sum(v['launches'] * v['hbm_bytes_per_launch'] for v in sel)
             return (b / n if n else None), 'profiles/' + name
@@ -260,7 +260,7 @@ def main():
                                       else '%d whitened BBH templates synthesised on the GPU into an HBM-resident bank before the timed region' % bank_n),
                        'name': args.config, 'n_pix': N_PIX, 'cnn_batch': CNN_BATCH, 'gan_batch': GAN_BATCH, 'predict_batch': predict_batch,
                        'waveforms_per_step_per_gpu': WAVES, 'bank_rows': bank_n, 'parallelism': 'dp%d' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_dma_kernel + conv_mfma_kernel (implicit-GEMM Conv1D forward + data gradient, v_mfma_f32_32x32x2_f32; the DMA variant runs every tile without ragged channel edges)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_pipe_kernel (+ conv_mfma_dma_kernel / conv_mfma_kernel for ragged or 1-tap shapes): implicit-GEMM Conv1D forward + data gradient, v_mfma_f32_32x32x2_f32',
                          'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                          'traffic_note': 'fabric-side bytes per conv_mfma launch (2*FETCH_SIZE + WRITE_SIZE KiB, gfx950 FETCH correction) from the separate PMC '
                                          'passes of the default-config command summarised in %s' % traffic_src,

@@ -534,7 +534,8 @@ int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s) {
   // data-gradient phases (130 against 136) and short sequences (M = 125: half a tile idle) keep the square tile.
   static const bool force_wide = getenv("GN_CONV_WIDE") != nullptr;      // A/B switch
   auto fill = [&](int T) { return (double)a.M / ((double)((a.M + T - 1) / T) * T); };
-  const bool tall_ok = a.Cout % 64 == 0 && a.t.ntaps >= 4 && fill(256) >= 0.97 * fill(128) && !force_wide;
+  static const int min_taps_tall = getenv("GN_CONV_TALL_TAPS") ? atoi(getenv("GN_CONV_TALL_TAPS")) : 4;      // A/B switch
+  const bool tall_ok = a.Cout % 64 == 0 && a.t.ntaps >= min_taps_tall && fill(256) >= 0.97 * fill(128) && !force_wide;
   const bool narrow = a.Cout <= 64 || tall_ok;
   // K-chunk: 8 channels for 2-5 taps (stages of 8-25 KiB -> 3-4 blocks/CU; measured on the stride-2 data-gradient phases of 3 and
   // 2 taps: 134 TFLOP/s against 122 with 16-channel chunks at 2 blocks/CU -- occupancy beats MFMAs-per-barrier); 16 for the
