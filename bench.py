@@ -287,7 +287,7 @@ def main():
                           'cnn_ms_per_batch': 1e3 * t_cnn, 'gan_ms_per_iteration': 1e3 * t_gan,
                           'synth_templates_per_s': world * SYN_NB / t_syn,
                           'note': 'rank-0 clock, measured after the timed steps; value = B / (t_CNN + t_GAN) comes from the K timed steps only; '
-                                  'synth_templates_per_s = OnlineBank.draw wall clock (host mass draws + fused kernel)'},
+                                  'synth_templates_per_s = OnlineBank.draw wall clock (ONE kernel: prior draw, chirp, both inverse FFTs, arg-max, slide, crop; no host random numbers)'},
         }
         conv_math = os.environ.get('GENNET_CONV_MATH', 'fp32')
         if conv_math != 'fp32':      # the opt-in experiment: say so in the line; never the default configuration
