@@ -493,19 +493,21 @@ int gn_bn_apply(const float* x, const float* scale, const float* shift, const ui
   return bn_apply(x, scale, shift, mask, y, rows, C, act, p, mask ? rate : 0.f, (hipStream_t)stream);
 }
 int gn_bn_bwd_stats(const float* dy, const float* y, const float* x, const uint8_t* mask, const float* save_mean, const float* save_invstd, double* dsums, void* ws,
-                    size_t ws_bytes, size_t rows, int C, int act, float p, float rate, void* stream) {
-  GN_REQUIRE(dy && y && x && save_mean && save_invstd && dsums && ws && rows > 0 && C > 0, "bn_bwd_stats: bad arguments");
+                    size_t ws_bytes, size_t rows, int C, int act, float p, float rate, const float* scale, const float* shift, void* stream) {
+  GN_REQUIRE(dy && x && save_mean && save_invstd && dsums && ws && rows > 0 && C > 0, "bn_bwd_stats: bad arguments");
+  GN_REQUIRE((scale == nullptr) == (shift == nullptr) && (y || scale), "bn_bwd_stats: needs the layer output y, or scale AND shift to recompute it");
   ColRedArgs r = {};
-  r.a = dy; r.y = y; r.xpre = x; r.mask = mask; r.mean = save_mean; r.invstd = save_invstd;
+  r.a = dy; r.y = y; r.xpre = x; r.mask = mask; r.mean = save_mean; r.invstd = save_invstd; r.scale = scale; r.shift = shift;
   r.rows = rows; r.C = C; r.act = act; r.act_param = p; r.keep_scale = 1.0f / (1.0f - (mask ? rate : 0.f));
   return colred_run(2, r, ws, ws_bytes, dsums, nullptr, (hipStream_t)stream);
 }
 int gn_bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8_t* mask, const float* gamma, const float* save_mean, const float* save_invstd,
                     const double* dsums_global, double count, const double* dsums_local, float* dx, float* dgamma, float* dbeta, size_t rows, int C, int act,
-                    float p, float rate, void* stream) {
-  GN_REQUIRE(dy && y && x && gamma && save_mean && save_invstd && dsums_global && dsums_local && dx && dgamma && dbeta && C > 0, "bn_bwd_apply: bad arguments");
-  return bn_bwd_apply(dy, y, x, mask, gamma, save_mean, save_invstd, dsums_global, count, dsums_local, dx, dgamma, dbeta, rows, C, act, p, mask ? rate : 0.f,
-                      (hipStream_t)stream);
+                    float p, float rate, const float* scale, const float* shift, void* stream) {
+  GN_REQUIRE(dy && x && gamma && save_mean && save_invstd && dsums_global && dsums_local && dx && dgamma && dbeta && C > 0, "bn_bwd_apply: bad arguments");
+  GN_REQUIRE((scale == nullptr) == (shift == nullptr) && (y || scale), "bn_bwd_apply: needs the layer output y, or scale AND shift to recompute it");
+  return bn_bwd_apply(dy, y, x, mask, gamma, save_mean, save_invstd, dsums_global, count, dsums_local, dx, dgamma, dbeta, rows, C, act, p, mask ? rate : 0.f, scale,
+                      shift, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------

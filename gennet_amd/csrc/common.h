@@ -76,6 +76,8 @@ struct ColRedArgs {
   const uint8_t* mask;   // MODE 2: dropout keep mask or NULL
   const float* mean;
   const float* invstd;
+  const float* scale;    // MODE 2, optional: the forward pass' gamma*invstd and beta - mean*gamma*invstd: with them the activation output is
+  const float* shift;    //   RECOMPUTED from xpre (act(fma(x, scale, shift)), bit-identical to the forward) and y is not read
   double* part;
   size_t rows;
   int C;
@@ -130,7 +132,7 @@ int bn_infer_coeffs(const float* gamma, const float* beta, const float* mm, cons
 int bn_apply(const float* x, const float* scale, const float* shift, const uint8_t* mask, float* y, size_t rows, int C, int act, float p, float rate, hipStream_t s);
 int bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8_t* mask, const float* gamma, const float* mean, const float* invstd,
                  const double* dsums_global, double count, const double* dsums_local, float* dx, float* dgamma, float* dbeta, size_t rows, int C,
-                 int act, float p, float rate, hipStream_t s);
+                 int act, float p, float rate, const float* scale, const float* shift, hipStream_t s);
 int loss_run(int kind, const float* p, const float* y, float* dp, float* out, int B, int Bglobal, hipStream_t s);
 int adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s);
 int transpose_w(const float* w, float* wt, int k, int Cin, int Cout, hipStream_t s);

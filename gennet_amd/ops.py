@@ -411,22 +411,24 @@ def bn_apply_dropgen(x2d, scale, shift, act, act_param, rate, seed, offset):
     return y, mask
 
 
-def bn_bwd_stats(dy2d, y2d, x2d, mask, smean, sinv, act='linear', act_param=0.0, rate=0.0):
+def bn_bwd_stats(dy2d, y2d, x2d, mask, smean, sinv, act='linear', act_param=0.0, rate=0.0, scale=None, shift=None):
+    """scale / shift (the forward's bn_finalize outputs): the activation output is recomputed from x2d and y2d (may be None) is not read."""
     _chk(dy2d, y2d, x2d, mask)
     rows, Cc = x2d.shape
     dsums = torch.empty((2 * Cc,), dtype=torch.float64, device=x2d.device)
     nb = _lib.size('gn_bn_stats_workspace', rows, Cc)
     ws = workspace(nb, x2d.device)
     _lib.call('gn_bn_bwd_stats', _p(dy2d), _p(y2d), _p(x2d), _p(mask), _p(smean), _p(sinv), _p(dsums), _p(ws), ws.numel(), rows, Cc,
-              ACT[act], float(act_param), float(rate), _stream())
+              ACT[act], float(act_param), float(rate), _p(scale), _p(shift), _stream())
     return dsums
 
 
-def bn_bwd_apply(dy2d, y2d, x2d, mask, gamma, smean, sinv, dsums_global, count, dsums_local, dgamma, dbeta, act='linear', act_param=0.0, rate=0.0):
+def bn_bwd_apply(dy2d, y2d, x2d, mask, gamma, smean, sinv, dsums_global, count, dsums_local, dgamma, dbeta, act='linear', act_param=0.0, rate=0.0,
+                 scale=None, shift=None):
     rows, Cc = x2d.shape
     dx = torch.empty_like(x2d)
     _lib.call('gn_bn_bwd_apply', _p(dy2d), _p(y2d), _p(x2d), _p(mask), _p(gamma), _p(smean), _p(sinv), _p(dsums_global), float(count),
-              _p(dsums_local), _p(dx), _p(dgamma), _p(dbeta), rows, Cc, ACT[act], float(act_param), float(rate), _stream())
+              _p(dsums_local), _p(dx), _p(dgamma), _p(dbeta), rows, Cc, ACT[act], float(act_param), float(rate), _p(scale), _p(shift), _stream())
     return dx
 
 

@@ -181,16 +181,19 @@ int gn_bn_infer_coeffs(const float* gamma, const float* beta, const float* movin
 /* y = dropout(act(x*scale[c] + shift[c])) in one pass; mask may be NULL (no dropout / inference) */
 int gn_bn_apply(const float* x, const float* scale, const float* shift, const uint8_t* mask, float* y,
                 size_t rows, int C, int act, float act_param, float rate, void* stream);
-/* backward pass 1: g = dy * mask/(1-rate) * act'(y/(mask scale)), xhat = (x-mean)*invstd;
- * dsums[0:C] = sum g, dsums[C:2C] = sum g*xhat (fp64).  A data-parallel caller all-reduces dsums. */
+/* backward pass 1: g = dy * mask/(1-rate) * act'(a), xhat = (x-mean)*invstd, with a = the activation output: taken from the stored
+ * layer output (a = y/(mask scale)) or, when scale and shift (the forward pass' gn_bn_finalize outputs) are given, RECOMPUTED from
+ * the pre-BN tensor as act(fma(x, scale, shift)) -- bit-identical to the forward and one 4-byte read per element less (y may then
+ * be NULL).  dsums[0:C] = sum g, dsums[C:2C] = sum g*xhat (fp64).  A data-parallel caller all-reduces dsums. */
 int gn_bn_bwd_stats(const float* dy, const float* y, const float* x, const uint8_t* mask,
                     const float* save_mean, const float* save_invstd, double* dsums, void* ws, size_t ws_bytes,
-                    size_t rows, int C, int act, float act_param, float rate, void* stream);
-/* backward pass 2: dx = gamma*invstd*(g - dsum/n - xhat*dsum_xhat/n); dgamma = dsums_local[C:2C], dbeta = dsums_local[0:C] */
+                    size_t rows, int C, int act, float act_param, float rate, const float* scale, const float* shift, void* stream);
+/* backward pass 2: dx = gamma*invstd*(g - dsum/n - xhat*dsum_xhat/n); dgamma = dsums_local[C:2C], dbeta = dsums_local[0:C];
+ * scale / shift as above. */
 int gn_bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8_t* mask,
                     const float* gamma, const float* save_mean, const float* save_invstd,
                     const double* dsums_global, double count, const double* dsums_local, float* dx, float* dgamma, float* dbeta,
-                    size_t rows, int C, int act, float act_param, float rate, void* stream);
+                    size_t rows, int C, int act, float act_param, float rate, const float* scale, const float* shift, void* stream);
 
 /* ---- losses + metric (compile(loss='binary_crossentropy'|'mean_squared_error', metrics=['accuracy']),
  *      bbhMahoGANy.py:1101-1119) ---------------------------------------------------------------------------

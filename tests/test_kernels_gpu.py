@@ -221,6 +221,12 @@ def test_batchnorm_train_fwd_bwd(shape, with_drop):
     dx = ops.bn_bwd_apply(dy2, y, x2, mt, g(gamma), smean, sinv, dsums, rows, dsums, dgamma, dbeta, 'tanh', 0.0, rate)
     close(dgamma, dg_ref, 1e-4); close(dbeta, db_ref, 1e-4)
     close(dx, dx_ref.reshape(rows, Cc), 1e-4)
+    # the variant the layer uses: the activation output recomputed from the pre-BN tensor (scale / shift), the stored output not read
+    dsums2 = ops.bn_bwd_stats(dy2, None, x2, mt, smean, sinv, 'tanh', 0.0, rate, scale, shift)
+    close(dsums2, dsums.cpu().numpy(), 1e-6)
+    dx2 = ops.bn_bwd_apply(dy2, None, x2, mt, g(gamma), smean, sinv, dsums2, rows, dsums2, dgamma, dbeta, 'tanh', 0.0, rate, scale, shift)
+    close(dgamma, dg_ref, 1e-4); close(dbeta, db_ref, 1e-4)
+    close(dx2, dx_ref.reshape(rows, Cc), 1e-4)
 
 
 def test_batchnorm_infer():
