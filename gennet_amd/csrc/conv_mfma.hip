@@ -701,13 +701,19 @@ static int wgrad_splits(int B, int Cin, int Cout, int TC, int TN) {
   return (B + bps - 1) / bps;
 }
 
-static void wgrad_tile(int Cout, int* TC, int* TN) {
-  if (Cout <= 64) { *TC = 64; *TN = 64; } else { *TC = 32; *TN = 128; }
+static bool wgrad_square(int Cin, int Cout, int ntaps) {
+  // 64 x 64 block tile (2 x 2 waves) wherever it divides: 34 KiB of LDS per block -> 4 blocks per CU against 3 for 32 x 128, and fewer
+  // staged bytes per flop: 145.8 against 143.9 TFLOP/s on G 512->1024, equal on the stride-2 layers.  GN_WGRAD_SQUARE=0: A/B switch.
+  static const int mode = getenv("GN_WGRAD_SQUARE") ? atoi(getenv("GN_WGRAD_SQUARE")) : 1;
+  return Cout <= 64 || (mode == 1 && ntaps == 5 && Cin % 64 == 0 && Cout % 64 == 0);
+}
+static void wgrad_tile(int Cin, int Cout, int ntaps, int* TC, int* TN) {
+  if (wgrad_square(Cin, Cout, ntaps)) { *TC = 64; *TN = 64; } else { *TC = 32; *TN = 128; }
 }
 
 size_t wgrad_workspace_bytes(int B, int Cin, int Cout, int ntaps) {
   int TC, TN;
-  wgrad_tile(Cout, &TC, &TN);
+  wgrad_tile(Cin, Cout, ntaps, &TC, &TN);
   const int s = wgrad_splits(B, Cin, Cout, TC, TN);
   return (size_t)s * ntaps * Cin * Cout * sizeof(float);
 }
@@ -758,7 +764,7 @@ int wgrad_mfma_dispatch(WgradArgs a, float* dw, size_t ws_bytes, hipStream_t s) 
     set_error("wgrad_mfma: workspace too small");
     return GN_EWORKSPACE;
   }
-  const bool narrow = a.Cout <= 64;
+  const bool narrow = wgrad_square(a.Cin, a.Cout, a.ntaps);
   switch (a.ntaps) {
     // per-wave tile 32 ci x 32 co x taps (WNT = 1): 32 x 64 (WNT = 2) needs 160 accumulator registers, drops to one wave per SIMD
     // and measured 115 vs 128 TFLOP/s on MI355X
