@@ -316,7 +316,9 @@ int gn_conv1d_wgrad(const float* x, const float* dy, float* dw, float* db, void*
     a.x = x; a.dy = dy; a.part = (float*)ws;
     a.B = B; a.Lin = L; a.Cin = Cin; a.Cout = Cout; a.M = Lout; a.ntaps = k; a.in_stride = stride;
     for (int j = 0; j < k; ++j) a.off[j] = j - pad_left;
+    a.db = db;
     rc = wgrad_mfma_dispatch(a, dw, ws_bytes, s);
+    if (!rc && a.db_done) return GN_OK;                  // the weight-gradient kernel summed the bias gradient on the way
   }
   if (rc) return rc;
   if (db) rc = bias_grad(dy, db, (size_t)B * Lout, Cout, ws, ws_bytes, s);

@@ -57,6 +57,9 @@ struct WgradArgs {
   int ntaps, in_stride;
   int off[8];
   int b_per_split;
+  double* db_part;  // optional [splits][Cout]: per-split column sums of dy (the bias gradient), written by the blocks of Cin-tile 0
+  float* db;        // optional: where wgrad_mfma_dispatch puts the bias gradient when the kernel it selects can sum it on the way
+  int db_done;      // set by the dispatcher when db has been written
 };
 
 struct WgradSmallArgs {
@@ -90,7 +93,7 @@ struct ColRedArgs {
 // conv_mfma.hip
 int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s);
 size_t wgrad_workspace_bytes(int B, int Cin, int Cout, int ntaps);
-int wgrad_mfma_dispatch(WgradArgs a, float* dw, size_t ws_bytes, hipStream_t s);
+int wgrad_mfma_dispatch(WgradArgs& a, float* dw, size_t ws_bytes, hipStream_t s);
 // conv_pipe.hip / wgrad_pipe.hip (hand-scheduled variants selected by the two dispatchers above)
 int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched);
 void wgrad_pipe_launch(const WgradArgs& a, dim3 grid, bool narrow, hipStream_t s);
@@ -140,6 +143,18 @@ int conv2d_w2_fold(const float* w, const float* bias, float* wf, float* bf, int 
 int conv2d_w2_unfold(const float* dwf, const float* dbf, float* dw, float* db, int kh, int Cin, int Cout, hipStream_t s);
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// Opt a kernel in to up to 160 KiB of dynamic LDS, once per DEVICE (the attribute is per device and function; `done` is the
+// call site's bit mask of devices already served, so a process that drives several GPUs stays correct).
+static inline void allow_big_lds(const void* kernel, unsigned long long* done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(*done & bit)) {
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    *done |= bit;
+  }
+}
 
 #define GN_REQUIRE(cond, ...)            \
   do {                                   \

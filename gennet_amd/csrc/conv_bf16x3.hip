@@ -325,11 +325,8 @@ static int launch_bf16x3(const ConvArgs& a, int w_taps, void* ws, hipStream_t s)
     set_error("conv_bf16x3: LDS %zu", lds);
     return GN_EINVAL;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_bf16x3_kernel<NTAPS, ASEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static unsigned long long lds_done = 0;
+    allow_big_lds((const void*)conv_bf16x3_kernel<NTAPS, ASEG>, &lds_done);
   const int m_tiles = (a.M + 127) / 128, n_tiles = a.Cout / 64;
   const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
   const size_t xn = (size_t)a.B * (a.Lin + 2) * a.Cin, wn = (size_t)w_taps * a.Cin * a.Cout;

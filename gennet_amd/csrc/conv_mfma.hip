@@ -442,11 +442,8 @@ static int launch_conv_dma(const ConvArgs& a, hipStream_t s) {
   const int Rper = (R + is - 1) / is;
   const size_t lds = 2 * sizeof(float) * ((size_t)is * Rper * KC + (size_t)NTAPS * KC * TN);
   if (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv_mfma_dma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    allow_big_lds((const void*)conv_mfma_dma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS>, &lds_done);
   }
   const int m_tiles = (a.M + TM - 1) / TM, n_tiles = a.Cout / TN;
   const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
@@ -478,11 +475,8 @@ static int launch_conv_impl(const ConvArgs& a, hipStream_t s) {
     return GN_EINVAL;
   }
   if (lds > 64 * 1024) {   // opt in to more than the default 64 KiB of dynamic LDS (once per instantiation)
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS, WGLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    allow_big_lds((const void*)conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, KC, NTAPS, WGLDS>, &lds_done);
   }
   const int m_tiles = (a.M + TM - 1) / TM, n_tiles = (a.Cout + TN - 1) / TN;
   const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
@@ -715,11 +709,20 @@ size_t wgrad_workspace_bytes(int B, int Cin, int Cout, int ntaps) {
   int TC, TN;
   wgrad_tile(Cin, Cout, ntaps, &TC, &TN);
   const int s = wgrad_splits(B, Cin, Cout, TC, TN);
-  return (size_t)s * ntaps * Cin * Cout * sizeof(float);
+  return (size_t)s * ntaps * Cin * Cout * sizeof(float) + (size_t)s * Cout * sizeof(double);      // dw slabs + per-split bias partials
+}
+
+// db[n] = sum_s part[s][n] in fp64, fixed order
+__global__ void bias_reduce_kernel(const double* __restrict__ part, float* __restrict__ db, int C, int splits) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= C) return;
+  double s = 0.0;
+  for (int k = 0; k < splits; ++k) s += part[(size_t)k * C + n];
+  db[n] = (float)s;
 }
 
 template <int WAVES_C, int WAVES_N, int WNT, int NTAPS>
-static int launch_wgrad(WgradArgs a, float* dw, hipStream_t s) {
+static int launch_wgrad(WgradArgs& a, float* dw, hipStream_t s) {
   constexpr int KT = 32, TC = WAVES_C * 32, TN = WAVES_N * WNT * 32;
   const int splits = wgrad_splits(a.B, a.Cin, a.Cout, TC, TN);
   a.b_per_split = (a.B + splits - 1) / splits;
@@ -737,6 +740,8 @@ static int launch_wgrad(WgradArgs a, float* dw, hipStream_t s) {
   if constexpr (NTAPS == 5 && WNT == 1) {
     if (!no_pipe && a.Cin % TC == 0 && a.Cout % TN == 0 && maxoff - minoff + 1 == NTAPS && (size_t)a.Lin * a.Cin * 4 < 0x40000000ull &&
         (size_t)a.M * a.Cout * 4 < 0x40000000ull) {
+      // the bias gradient rides along: the blocks of Cin-tile 0 sum the columns of the dy tiles they stage anyway (no separate pass over dy)
+      a.db_part = a.db ? reinterpret_cast<double*>(reinterpret_cast<char*>(a.part) + (size_t)splits * NTAPS * a.Cin * a.Cout * sizeof(float)) : nullptr;
       wgrad_pipe_launch(a, grid, WAVES_C == 2, s);                       // wgrad_pipe.hip
       piped = true;
     }
@@ -748,10 +753,14 @@ static int launch_wgrad(WgradArgs a, float* dw, hipStream_t s) {
   if (rc) return rc;
   const size_t n = (size_t)NTAPS * a.Cin * a.Cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a.part, dw, n / 4, splits, n / 4);
+  if (piped && a.db_part) {
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3(cdiv(a.Cout, 256)), dim3(256), 0, s, a.db_part, a.db, a.Cout, splits);
+    a.db_done = 1;
+  }
   return check_launch("wgrad_reduce");
 }
 
-int wgrad_mfma_dispatch(WgradArgs a, float* dw, size_t ws_bytes, hipStream_t s) {
+int wgrad_mfma_dispatch(WgradArgs& a, float* dw, size_t ws_bytes, hipStream_t s) {
   if (a.Cin % 4 || a.Cout % 4) {
     set_error("wgrad_mfma: Cin (%d) and Cout (%d) must be multiples of 4", a.Cin, a.Cout);
     return GN_EINVAL;

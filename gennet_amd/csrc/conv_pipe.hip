@@ -290,11 +290,8 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "stage too large");
   static_assert(lds / 2 + (NTAPS * KC + 8) * TN * 4 < 65536, "ds_read offsets must fit 16 bits");
   if (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    allow_big_lds((const void*)conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS>, &lds_done);
   }
   const int m_tiles = (a.M + TM - 1) / TM, n_tiles = a.Cout / TN;
   const size_t blocks = (size_t)m_tiles * n_tiles * a.B;

@@ -165,8 +165,8 @@ int irfft_f64(const double* X, double* out, const double* W, int nb, int N, hipS
   int rc = fft_check(N, &logM);
   if (rc || nb == 0) return rc;
   const size_t lds = (size_t)(N / 2) * sizeof(double2);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)irfft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
+  static unsigned long long lds_done = 0;
+  allow_big_lds((const void*)irfft_kernel, &lds_done);
   const int threads = N / 4 < 1024 ? (N / 4 < 64 ? 64 : N / 4) : 1024;
   hipLaunchKernelGGL(irfft_kernel, dim3(nb), dim3(threads), lds, s, (const double2*)X, out, (const double2*)W, N, logM);
   return check_launch("irfft");
@@ -177,8 +177,8 @@ int rfft_f64(const double* x, double* X, const double* W, int nb, int N, hipStre
   int rc = fft_check(N, &logM);
   if (rc || nb == 0) return rc;
   const size_t lds = (size_t)(N / 2) * sizeof(double2);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)rfft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
+  static unsigned long long lds_done = 0;
+  allow_big_lds((const void*)rfft_kernel, &lds_done);
   const int threads = N / 4 < 1024 ? (N / 4 < 64 ? 64 : N / 4) : 1024;
   hipLaunchKernelGGL(rfft_kernel, dim3(nb), dim3(threads), lds, s, x, (double2*)X, (const double2*)W, N, logM);
   return check_launch("rfft");

@@ -339,11 +339,8 @@ template <int LOGM, int NT>
 static int launch_synth(const SynthArgs& a, hipStream_t s) {
   constexpr int M = 1 << LOGM;
   const size_t lds = (size_t)(M + M / 8) * sizeof(double2) + sizeof(ChirpCoeffsF) + 16 * sizeof(double) + 16 * sizeof(int);
-  static bool attr = false;
-  if (!attr && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)synth_fused_kernel<LOGM, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  static unsigned long long lds_done = 0;
+  allow_big_lds((const void*)synth_fused_kernel<LOGM, NT>, &lds_done);
   prof_begin(s);
   hipLaunchKernelGGL((synth_fused_kernel<LOGM, NT>), dim3(a.nb), dim3(NT), lds, s, a);
   // algorithmic bytes: per template 2 spectra of Nf complex128 + the PSD read, the cropped row written

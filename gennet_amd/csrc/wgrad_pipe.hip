@@ -160,16 +160,40 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(W
   const unsigned addr_a = lds0 + ((h * IS) * TC + wc * 32 + i32) * 4;
   const unsigned addr_b = lds0 + (SLAB + h * TN + wn * 32 + i32) * 4;
 
+  // bias gradient on the way (blocks of Cin-tile 0 only): thread (column tid % TN, row group tid / TN) adds its rows of every staged
+  // dy tile in fp64 (rows >= M were staged as zeros); 8 LDS reads per chunk against the 96 of the MFMA operands
+  const bool do_bias = a.db_part != nullptr && blockIdx.x == 0;
+  constexpr int RG = NT / TN, RPG = KT / RG;
+  double bsum = 0.0;
+  auto bias_chunk = [&](const float* stage) {
+    const float* col = stage + SLAB + (tid / TN) * RPG * TN + (tid % TN);
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) bsum += (double)col[r * TN];
+  };
+
   if (n_chunks > 0) dma_chunk(0, smem);
   __syncthreads();
   for (int ch = 0; ch < n_chunks; ch += 2) {
     dma_chunk(min(ch + 1, n_chunks - 1), smem + BUF);
+    if (do_bias) bias_chunk(smem);
     WgChunk<TC, TN, KT, IS, STAGE_BYTES, 0>::chunk(acc, addr_a, addr_b);
     __syncthreads();
     if (ch + 1 < n_chunks) {
       dma_chunk(min(ch + 2, n_chunks - 1), smem);
+      if (do_bias) bias_chunk(smem + BUF);
       WgChunk<TC, TN, KT, IS, STAGE_BYTES, 1>::chunk(acc, addr_a, addr_b);
       __syncthreads();
+    }
+  }
+  if (do_bias) {                                           // every wave is past the last barrier: the stages are free
+    double* red = reinterpret_cast<double*>(smem);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < TN) {
+      double t = 0.0;
+#pragma unroll
+      for (int g = 0; g < RG; ++g) t += red[g * TN + tid];
+      a.db_part[(size_t)split * a.Cout + n0 + tid] = t;
     }
   }
   asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
@@ -199,11 +223,8 @@ static void launch_wgrad_pipe(const WgradArgs& a, dim3 grid, hipStream_t s) {
   constexpr size_t lds = 2 * sizeof(float) * ((size_t)SLAB + (size_t)KT * TN);
   static_assert(lds / 2 + (size_t)(R * TC + KT * TN) * 4 < 65536, "ds_read offsets must fit 16 bits");
   if (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)wgrad_pipe_kernel<WAVES_C, WAVES_N, IS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    allow_big_lds((const void*)wgrad_pipe_kernel<WAVES_C, WAVES_N, IS>, &lds_done);
   }
   hipLaunchKernelGGL((wgrad_pipe_kernel<WAVES_C, WAVES_N, IS>), grid, dim3(64 * WAVES_C * WAVES_N), lds, s, a);
 }
