@@ -207,6 +207,33 @@ int gn_set_conv_math(int mode, void* workspace, size_t workspace_bytes) { return
 
 size_t gn_conv1d_bf16x3_workspace(int B, int L, int Cin, int Cout, int k) { return conv_bf16x3_workspace_bytes(B, L, Cin, Cout, k); }
 
+size_t gn_conv1d_fwd_stats_workspace(int B, int Lout, int Cout) {
+  const size_t fused = (size_t)B * (size_t)((Lout + 127) / 128) * 2 * (size_t)Cout * sizeof(double);      // per-block partials (smallest tile: 128 rows)
+  const size_t plain = colred_workspace_bytes((size_t)B * Lout, Cout);
+  return (fused > plain ? fused : plain) + 256;
+}
+
+int gn_conv1d_fwd_stats(const float* x, const float* w, const float* bias, float* y, double* sums, void* ws, size_t ws_bytes, int B, int L, int Cin, int Cout, int k,
+                        int stride, int pad_left, int Lout, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GN_REQUIRE(x && w && y && sums && ws, "conv1d_fwd_stats: null pointer");
+  GN_REQUIRE(B > 0 && L > 0 && Cin > 0 && Cout > 0 && Cout % 4 == 0 && k >= 1 && k <= 8 && stride >= 1 && Lout > 0, "conv1d_fwd_stats: bad shape");
+  GN_REQUIRE(pad_left >= 0 && stride * (Lout - 1) + k - pad_left <= L + k, "conv1d_fwd_stats: Lout %d inconsistent with L %d k %d stride %d", Lout, L, k, stride);
+  GN_REQUIRE(ws_bytes >= gn_conv1d_fwd_stats_workspace(B, Lout, Cout), "conv1d_fwd_stats: workspace too small");
+  ConvArgs a = {};
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.B = B; a.Lin = L; a.Cin = Cin; a.Cout = Cout; a.M = Lout; a.Ly = Lout;
+  fwd_taps(&a.t, k, stride, pad_left);
+  a.act = GN_ACT_LINEAR; a.act_param = 0.f;
+  int done = 0;
+  a.stat_part = (double*)ws; a.stat_sums = sums; a.stat_done = &done;
+  int rc = conv_dispatch(a, s);
+  if (rc || done) return rc;
+  ColRedArgs r = {};                                     // the launched kernel had no statistics epilogue: one separate pass over y
+  r.a = y; r.rows = (size_t)B * Lout; r.C = Cout;
+  return colred_run(1, r, ws, ws_bytes, sums, nullptr, s);
+}
+
 int gn_conv1d_fwd_bf16x3(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B, int L, int Cin, int Cout, int k, int stride,
                          int pad_left, int Lout, int act, float act_param, int resplit, void* stream) {
   GN_REQUIRE(x && w && y && ws, "conv1d_fwd_bf16x3: null pointer");

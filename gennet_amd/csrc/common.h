@@ -47,6 +47,12 @@ struct ConvArgs {
   const uint8_t* gmask;
   int gact;
   float gparam, gscale;
+  // optional BatchNorm statistics of the OUTPUT, accumulated in the epilogue (pipelined kernel, linear epilogue): per-block fp64
+  // partials stat_part[(b*m_tiles + m_tile)][2][Cout] = (sum y, sum y^2) over the block's valid rows, reduced in fixed order into
+  // stat_sums[2*Cout]; *stat_done is set when the launched kernel produced them (the caller falls back to a separate pass otherwise)
+  double* stat_part;
+  double* stat_sums;
+  int* stat_done;
 };
 
 struct WgradArgs {
@@ -129,6 +135,7 @@ int fill_uniform(float* out, size_t n, float lo, float hi, uint64_t seed, uint64
 int fill_normal(float* out, size_t n, float mean, float sd, uint64_t seed, uint64_t offset, hipStream_t s);
 size_t colred_workspace_bytes(size_t rows, int C);
 int colred_run(int mode, ColRedArgs a, void* ws, size_t ws_bytes, double* out_f64, float* out_f32, hipStream_t s);
+int colred_finalize(const double* part, double* out_f64, size_t n, int chunks, hipStream_t s);   // out[i] = sum_k part[k*n + i], fixed order
 int bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum, float* mm, float* mv,
                 float* bm, float* bv, float zd_step, float* scale, float* shift, float* smean, float* sinv, int C, hipStream_t s);
 int bn_infer_coeffs(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, float* scale, float* shift, int C, hipStream_t s);

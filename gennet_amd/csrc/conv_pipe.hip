@@ -279,6 +279,43 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_pipe_kern
     else GN_EPI(-1, 3, -1);
   }
 #undef GN_EPI
+
+  // BatchNorm statistics of the output on the way (the conv -> BatchNormalization layers of the generator): every lane sums its 32
+  // values of each column in fp64 (rows past M excluded), the two lane halves and the waves stacked in M combine through a shuffle
+  // and LDS (every wave is past the loop's last barrier, the stages are free), one fp64 partial per block and column
+  if (a.stat_part) {
+    double* red = reinterpret_cast<double*>(smem);
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+      const int n = n_base + nt * 32 + i32;
+      const float bias = a.bias ? a.bias[n] : 0.f;
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_base + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < a.M) {
+            const double v = (double)(acc[mt][nt][r] + bias);
+            s1 += v; s2 += v * v;
+          }
+        }
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) {
+        const int slot = (wm * TN + wn * WN * 32 + nt * 32 + i32) * 2;
+        red[slot] = s1; red[slot + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < TN) {
+      double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) { t1 += red[(w * TN + tid) * 2]; t2 += red[(w * TN + tid) * 2 + 1]; }
+      double* dst = a.stat_part + (size_t)(b * m_tiles + m_tile) * 2 * a.Cout;
+      dst[n0 + tid] = t1;
+      dst[a.Cout + n0 + tid] = t2;
+    }
+  }
 #endif
 }
 
@@ -302,7 +339,10 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t s) {
   prof_begin(s);
   hipLaunchKernelGGL((conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles);
   prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0, 4.0 * ((double)a.B * a.Lin * a.Cin + (double)a.t.ntaps * a.Cin * a.Cout + (double)a.B * a.M * a.Cout));
-  return check_launch("conv_mfma_pipe");
+  int rc = check_launch("conv_mfma_pipe");
+  if (rc || !a.stat_part) return rc;
+  *a.stat_done = 1;
+  return colred_finalize(a.stat_part, a.stat_sums, (size_t)2 * a.Cout, a.B * m_tiles, s);
 }
 
 
@@ -320,6 +360,11 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
   if (no_pipe || nt < 2 || nt > 5 || maxoff - minoff + 1 > nt || (size_t)a.Ly * a.Cout * 4 >= 0x40000000ull) return GN_OK;
   if (a.t.in_stride != 1 && !(a.t.in_stride == 2 && nt == 5)) return GN_OK;
   *launched = true;
+  if (a.stat_part && (a.act != GN_ACT_LINEAR || a.mask || a.gy || a.t.out_stride != 1)) {   // statistics are defined for the plain linear forward only
+    ConvArgs a2 = a;
+    a2.stat_part = nullptr;
+    return conv_pipe_try(a2, tall, s, launched);
+  }
 #define GN_PIPE(NT_, IS_) return tall ? launch_conv_pipe<4, 1, NT_, IS_>(a, s) : launch_conv_pipe<2, 2, NT_, IS_>(a, s)
   if (a.t.in_stride == 2) { GN_PIPE(5, 2); }
   switch (nt) {

@@ -448,6 +448,11 @@ int colred_run(int mode, ColRedArgs a, void* ws, size_t ws_bytes, double* out_f6
   return check_launch("colred_final");
 }
 
+int colred_finalize(const double* part, double* out_f64, size_t n, int chunks, hipStream_t s) {
+  hipLaunchKernelGGL(colred_final_kernel<double>, dim3(cdiv(n, 32)), dim3(256), 0, s, part, out_f64, n, chunks);
+  return check_launch("colred_final");
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm finalize / apply / backward-apply
 // ---------------------------------------------------------------------------------------------

@@ -194,6 +194,7 @@ class RunContext(object):
         self.epi = {}                      # node index -> (y, act, act_param, mask, rate): epilogue a consumer's dgrad can differentiate
         self.pre_applied = set()           # producers whose activation gradient has already been applied to their dy
         self.skip = set()                  # inference phase: BatchNormalization nodes already folded into the producing conv
+        self.bn_sums = {}                  # training phase: BN node index -> fp64 (sum x, sum x^2) produced by the conv epilogue
 
     def wants_grad(self, layer):
         if self.train_ids is None:

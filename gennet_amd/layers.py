@@ -13,6 +13,7 @@ from .engine import Layer, Model, device, device_rng, glorot_uniform
 
 import os as _os
 _NO_DROPGEN = bool(_os.environ.get('GN_NO_DROPGEN'))      # A/B switch: separate dropout-mask kernel instead of drawing it inside bn_apply
+_NO_CONVSTATS = bool(_os.environ.get('GN_NO_CONVSTATS'))  # A/B switch: separate BatchNorm statistics pass instead of the conv epilogue
 
 _ACT_NAMES = {'relu': ('relu', 0.0), 'tanh': ('tanh', 0.0), 'sigmoid': ('sigmoid', 0.0), 'linear': ('linear', 0.0), None: ('linear', 0.0)}
 
@@ -146,6 +147,13 @@ class Conv1D(Layer):
         fused_drop = node.fused_drop is not None and self.filters > 4
         if node.fused_drop is not None and not fused_drop:
             raise NotImplementedError('Dropout directly after a Conv1D with <= 4 filters')
+        if ctx.training and bn_node is not None and x.shape[2] > 4 and not _NO_CONVSTATS:
+            # training phase, linear conv whose only consumer is a BatchNormalization: its batch statistics come out of the conv kernel's
+            # epilogue (no separate pass over the output); the BN node picks them up from ctx.bn_sums
+            y, sums = ops.conv1d_fwd_stats(x, self.kernel.data, self.bias.data, self.stride, pl, Lout)
+            ctx.bn_sums[bn_node.index] = sums
+            ctx.tape[node.index] = (x, y, a, pl, None, 0.0)
+            return y
         y, mask, rate = _conv_fwd(node, ctx, x, self.kernel.data, self.bias.data, self.stride, pl, Lout, a, (x.shape[0], Lout, self.filters))
         ctx.tape[node.index] = (x, y, a, pl, mask, rate)
         if ctx.training and (a[0] != 'linear' or mask is not None):
@@ -281,7 +289,9 @@ class BatchNormalization(Layer):
         if not ctx.training:
             scale, shift = ops.bn_infer_coeffs(self.gamma.data, self.beta.data, self.moving_mean.data, self.moving_variance.data, self.epsilon)
             return ops.bn_apply(x2, scale, shift, None, act[0], act[1]).reshape(x.shape)
-        sums = ops.bn_stats(x2)
+        sums = ctx.bn_sums.pop(node.index, None)          # handed over by the producing convolution's epilogue, if it had one
+        if sums is None:
+            sums = ops.bn_stats(x2)
         count = x2.shape[0]
         if ctx.dp is not None:
             ctx.dp.all_reduce_sum(sums)

@@ -65,6 +65,20 @@ def conv1d_fwd(x, w, b, stride, pad_left, Lout, act='linear', act_param=0.0):
     return y
 
 
+def conv1d_fwd_stats(x, w, b, stride, pad_left, Lout):
+    """Linear conv forward + the BatchNorm statistics of its output: (y, sums fp64 (2*Cout,) = [sum y | sum y^2]); the sums come out of
+    the conv kernel's epilogue where the pipelined kernel runs, from a separate pass otherwise (same values either way)."""
+    _chk(x, w, b)
+    B, L, Cin = x.shape
+    k, _, Cout = w.shape
+    y = torch.empty((B, Lout, Cout), dtype=torch.float32, device=x.device)
+    sums = torch.empty((2 * Cout,), dtype=torch.float64, device=x.device)
+    nb = _lib.size('gn_conv1d_fwd_stats_workspace', B, Lout, Cout)
+    ws = workspace(nb, x.device)
+    _lib.call('gn_conv1d_fwd_stats', _p(x), _p(w), _p(b), _p(y), _p(sums), _p(ws), ws.numel(), B, L, Cin, Cout, k, stride, pad_left, Lout, _stream())
+    return y, sums
+
+
 _BF16X3_WS = {}
 
 

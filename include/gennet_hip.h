@@ -64,6 +64,13 @@ int gn_set_conv_math(int mode, void* workspace, size_t workspace_bytes);
 int gn_conv1d_fwd_dropout(const float* x, const float* w, const float* bias, const uint8_t* mask, float* y,
                           int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout,
                           int act, float act_param, float rate, void* stream);
+/* Linear Conv1D forward that also returns the BatchNorm statistics of its output, sums[0:Cout] = sum y, sums[Cout:2*Cout] = sum y^2
+ * (fp64) -- the Conv1D -> BatchNormalization pairs of the generator (bbhMahoGANy.py:250-251, ..., :283-284).  On the pipelined MFMA
+ * kernel the sums are accumulated in the epilogue (per-block fp64 partials, fixed-order final reduction): the separate statistics
+ * pass over the output tensor disappears; other shapes run the convolution and then gn_bn_stats' pass, with the same result. */
+size_t gn_conv1d_fwd_stats_workspace(int B, int Lout, int Cout);
+int gn_conv1d_fwd_stats(const float* x, const float* w, const float* bias, float* y, double* sums, void* ws, size_t ws_bytes,
+                        int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout, void* stream);
 
 /* wt[k, co, ci] = w[k, ci, co]  (operand layout the dgrad GEMM consumes) */
 int gn_conv1d_transpose_w(const float* w, float* wt, int k, int Cin, int Cout, void* stream);

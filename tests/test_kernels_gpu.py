@@ -76,6 +76,29 @@ def test_conv1d_fwd_dgrad_wgrad(B, L, Cin, Cout, k, s, padding):
     close(db, db_ref, 5e-5)
 
 
+@pytest.mark.parametrize("B,L,Cin,Cout,s,padding", [(3, 300, 64, 128, 1, 'same'),      # pipelined kernel, square tile, ragged last M tile
+                                                    (2, 700, 32, 64, 1, 'same'),       # tall tile (256 rows), 700 = 2*256 + 188
+                                                    (2, 512, 64, 64, 2, 'same'),       # stride 2 (de-interleaved slab)
+                                                    (2, 90, 20, 72, 1, 'valid'),       # ragged channels: plain kernel + separate statistics pass
+                                                    (2, 64, 2, 16, 1, 'same')])        # small-Cin kernel + separate pass
+def test_conv1d_fwd_with_batchnorm_statistics(B, L, Cin, Cout, s, padding):
+    """gn_conv1d_fwd_stats: y as gn_conv1d_fwd, sums = (sum y, sum y^2) over (B, Lout) in fp64 -- from the conv epilogue on the pipelined
+    kernel (rows of the ragged last tile excluded), from a separate pass elsewhere."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(L + Cin)
+    x = f32(rng.randn(B, L, Cin)); w = f32(rng.randn(5, Cin, Cout) / np.sqrt(5 * Cin)); b = f32(rng.randn(Cout) * 0.3 + 0.5)
+    Lout, pl = ops.conv_geometry(L, 5, s, padding)
+    y_ref = K.conv1d_fwd(x, w, b, s, padding)
+    y, sums = ops.conv1d_fwd_stats(g(x), g(w), g(b), s, pl, Lout)
+    close(y, y_ref)
+    assert torch.equal(y, ops.conv1d_fwd(g(x), g(w), g(b), s, pl, Lout))
+    yd = y.double().reshape(-1, Cout)
+    ref = torch.cat([yd.sum(0), (yd * yd).sum(0)]).cpu().numpy()
+    got = sums.cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()                       # fp64 sums of the same fp32 values: order only
+    close(ops.bn_stats(y.reshape(-1, Cout)), got, 1e-12)
+
+
 def test_conv1d_mfma_exact_integers():
     """A = small integers, B asymmetric integers: fp32 MFMA must be bit-exact (catches row/col swaps, tap mix-ups)."""
     from gennet_amd import ops
