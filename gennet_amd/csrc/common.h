@@ -136,6 +136,7 @@ int fill_normal(float* out, size_t n, float mean, float sd, uint64_t seed, uint6
 size_t colred_workspace_bytes(size_t rows, int C);
 int colred_run(int mode, ColRedArgs a, void* ws, size_t ws_bytes, double* out_f64, float* out_f32, hipStream_t s);
 int colred_finalize(const double* part, double* out_f64, size_t n, int chunks, hipStream_t s);   // out[i] = sum_k part[k*n + i], fixed order
+int colred_finalize_f32(const double* part, float* out_f32, size_t n, int chunks, hipStream_t s);
 int bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum, float* mm, float* mv,
                 float* bm, float* bv, float zd_step, float* scale, float* shift, float* smean, float* sinv, int C, hipStream_t s);
 int bn_infer_coeffs(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, float* scale, float* shift, int C, hipStream_t s);

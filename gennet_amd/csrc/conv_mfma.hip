@@ -712,14 +712,6 @@ size_t wgrad_workspace_bytes(int B, int Cin, int Cout, int ntaps) {
   return (size_t)s * ntaps * Cin * Cout * sizeof(float) + (size_t)s * Cout * sizeof(double);      // dw slabs + per-split bias partials
 }
 
-// db[n] = sum_s part[s][n] in fp64, fixed order
-__global__ void bias_reduce_kernel(const double* __restrict__ part, float* __restrict__ db, int C, int splits) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= C) return;
-  double s = 0.0;
-  for (int k = 0; k < splits; ++k) s += part[(size_t)k * C + n];
-  db[n] = (float)s;
-}
 
 template <int WAVES_C, int WAVES_N, int WNT, int NTAPS>
 static int launch_wgrad(WgradArgs& a, float* dw, hipStream_t s) {
@@ -754,7 +746,8 @@ static int launch_wgrad(WgradArgs& a, float* dw, hipStream_t s) {
   const size_t n = (size_t)NTAPS * a.Cin * a.Cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a.part, dw, n / 4, splits, n / 4);
   if (piped && a.db_part) {
-    hipLaunchKernelGGL(bias_reduce_kernel, dim3(cdiv(a.Cout, 256)), dim3(256), 0, s, a.db_part, a.db, a.Cout, splits);
+    int rc2 = colred_finalize_f32(a.db_part, a.db, (size_t)a.Cout, splits, s);      // db[n] = sum over splits, fp64, fixed order
+    if (rc2) return rc2;
     a.db_done = 1;
   }
   return check_launch("wgrad_reduce");

@@ -452,6 +452,10 @@ int colred_finalize(const double* part, double* out_f64, size_t n, int chunks, h
   hipLaunchKernelGGL(colred_final_kernel<double>, dim3(cdiv(n, 32)), dim3(256), 0, s, part, out_f64, n, chunks);
   return check_launch("colred_final");
 }
+int colred_finalize_f32(const double* part, float* out_f32, size_t n, int chunks, hipStream_t s) {
+  hipLaunchKernelGGL(colred_final_kernel<float>, dim3(cdiv(n, 32)), dim3(256), 0, s, part, out_f32, n, chunks);
+  return check_launch("colred_final");
+}
 
 // ---------------------------------------------------------------------------------------------
 // BatchNorm finalize / apply / backward-apply
