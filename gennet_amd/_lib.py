@@ -25,6 +25,8 @@ _SIGS = {
     'gn_conv1d_wgrad': [vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'gn_conv2d_w2_fold': [vp, vp, vp, vp, i32, i32, i32, vp],
     'gn_conv2d_w2_unfold_grad': [vp, vp, vp, vp, i32, i32, i32, vp],
+    'gn_conv1d_up2_fold': [vp, vp, vp, vp, i32, i32, i32, vp],
+    'gn_conv1d_up2_unfold_grad': [vp, vp, vp, vp, i32, i32, i32, vp],
     'gn_dense_fwd': [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     'gn_dense_bwd': [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp],
     'gn_act_fwd': [vp, vp, sz, i32, f32, vp],

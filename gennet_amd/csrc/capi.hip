@@ -360,6 +360,14 @@ int gn_conv2d_w2_unfold_grad(const float* dwf, const float* dbf, float* dw, floa
   GN_REQUIRE(dwf && dw && kh >= 1 && Cin > 0 && Cout > 0, "conv2d_w2_unfold_grad: bad arguments");
   return conv2d_w2_unfold(dwf, dbf, dw, db, kh, Cin, Cout, (hipStream_t)stream);
 }
+int gn_conv1d_up2_fold(const float* w, const float* bias, float* wf, float* biasf, int Cin, int Cout, int stride, void* stream) {
+  GN_REQUIRE(w && wf && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2), "conv1d_up2_fold: bad arguments (5-tap 'same' conv, stride 1 or 2)");
+  return up2_fold(w, bias, wf, biasf, Cin, Cout, stride, (hipStream_t)stream);
+}
+int gn_conv1d_up2_unfold_grad(const float* dwf, const float* dbf, float* dw, float* db, int Cin, int Cout, int stride, void* stream) {
+  GN_REQUIRE(dwf && dw && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2) && (!db || dbf), "conv1d_up2_unfold_grad: bad arguments");
+  return up2_unfold(dwf, dbf, dw, db, Cin, Cout, stride, (hipStream_t)stream);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 int gn_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int in, int out, int act, float act_param, void* stream) {

@@ -149,6 +149,8 @@ int adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t
 int transpose_w(const float* w, float* wt, int k, int Cin, int Cout, hipStream_t s);
 int conv2d_w2_fold(const float* w, const float* bias, float* wf, float* bf, int kh, int Cin, int Cout, hipStream_t s);
 int conv2d_w2_unfold(const float* dwf, const float* dbf, float* dw, float* db, int kh, int Cin, int Cout, hipStream_t s);
+int up2_fold(const float* w, const float* bias, float* wf, float* bf, int Cin, int Cout, int stride, hipStream_t s);
+int up2_unfold(const float* dwf, const float* dbf, float* dw, float* db, int Cin, int Cout, int stride, hipStream_t s);
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 

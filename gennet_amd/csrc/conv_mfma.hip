@@ -772,8 +772,12 @@ int wgrad_mfma_dispatch(WgradArgs& a, float* dw, size_t ws_bytes, hipStream_t s)
     // and measured 115 vs 128 TFLOP/s on MI355X
     case 1: return narrow ? launch_wgrad<2, 2, 1, 1>(a, dw, s) : launch_wgrad<1, 4, 1, 1>(a, dw, s);
     case 5: return narrow ? launch_wgrad<2, 2, 1, 5>(a, dw, s) : launch_wgrad<1, 4, 1, 5>(a, dw, s);
+    // 2..4 taps (the 3-tap folded UpSampling1D -> Conv1D layers, user graphs): the register-staged kernel
+    case 2: return narrow ? launch_wgrad<2, 2, 1, 2>(a, dw, s) : launch_wgrad<1, 4, 1, 2>(a, dw, s);
+    case 3: return narrow ? launch_wgrad<2, 2, 1, 3>(a, dw, s) : launch_wgrad<1, 4, 1, 3>(a, dw, s);
+    case 4: return narrow ? launch_wgrad<2, 2, 1, 4>(a, dw, s) : launch_wgrad<1, 4, 1, 4>(a, dw, s);
     default:
-      set_error("wgrad_mfma: ntaps %d unsupported (1 or 5)", a.ntaps);
+      set_error("wgrad_mfma: ntaps %d unsupported (1..5)", a.ntaps);
       return GN_EINVAL;
   }
 }

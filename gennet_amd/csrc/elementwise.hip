@@ -761,4 +761,50 @@ int conv2d_w2_unfold(const float* dwf, const float* dbf, float* dw, float* db, i
   return check_launch("conv2d_w2_unfold");
 }
 
+// UpSampling1D(2) -> Conv1D(k=5, 'same') folded into a 3-tap stride-1 conv on the un-upsampled input:
+//   stride 2:  y[t]    = W0 x[t-1] + (W1+W2) x[t] + (W3+W4) x[t+1]                                   wf (3, Cin, Cout)
+//   stride 1:  y[2s]   = (W0+W1) x[s-1] + (W2+W3) x[s] + W4 x[s+1]   (columns [0, Cout) of wf)         wf (3, Cin, 2*Cout)
+//              y[2s+1] = W0 x[s-1] + (W1+W2) x[s] + (W3+W4) x[s+1]   (columns [Cout, 2*Cout))
+// the (Lin, 2*Cout) output of the stride-1 form IS the (2*Lin, Cout) tensor in memory.  tap k of W lands on folded tap UP2_TAB[phase][k].
+__device__ __constant__ int UP2_TAB[2][5] = {{0, 0, 1, 1, 2}, {0, 1, 1, 2, 2}};
+__global__ void up2_fold_kernel(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ wf, float* __restrict__ bf, int Cin, int Cout, int stride) {
+  const int phases = stride == 1 ? 2 : 1, Cf = phases * Cout;
+  const size_t total = (size_t)3 * Cin * Cf, step = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+    const int o = (int)(i % Cf);
+    const int c = (int)((i / Cf) % Cin);
+    const int j = (int)(i / ((size_t)Cin * Cf));
+    const int ph = stride == 1 ? o / Cout : 1, n = o % Cout;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+      if (UP2_TAB[ph][k] == j) v += w[((size_t)k * Cin + c) * Cout + n];
+    wf[i] = v;
+  }
+  if (bias && blockIdx.x == 0)
+    for (int o = threadIdx.x; o < Cf; o += blockDim.x) bf[o] = bias[o % Cout];
+}
+__global__ void up2_unfold_kernel(const float* __restrict__ dwf, const float* __restrict__ dbf, float* __restrict__ dw, float* __restrict__ db, int Cin, int Cout, int stride) {
+  const int Cf = (stride == 1 ? 2 : 1) * Cout;
+  const size_t total = (size_t)5 * Cin * Cout, step = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+    const int n = (int)(i % Cout);
+    const int c = (int)((i / Cout) % Cin);
+    const int k = (int)(i / ((size_t)Cin * Cout));
+    float v = dwf[((size_t)UP2_TAB[1][k] * Cin + c) * Cf + (stride == 1 ? Cout : 0) + n];
+    if (stride == 1) v = dwf[((size_t)UP2_TAB[0][k] * Cin + c) * Cf + n] + v;
+    dw[i] = v;
+  }
+  if (db && blockIdx.x == 0)
+    for (int o = threadIdx.x; o < Cout; o += blockDim.x) db[o] = stride == 1 ? dbf[o] + dbf[Cout + o] : dbf[o];
+}
+int up2_fold(const float* w, const float* bias, float* wf, float* bf, int Cin, int Cout, int stride, hipStream_t s) {
+  hipLaunchKernelGGL(up2_fold_kernel, dim3(stream_grid((size_t)6 * Cin * Cout)), dim3(256), 0, s, w, bias, wf, bf, Cin, Cout, stride);
+  return check_launch("up2_fold");
+}
+int up2_unfold(const float* dwf, const float* dbf, float* dw, float* db, int Cin, int Cout, int stride, hipStream_t s) {
+  hipLaunchKernelGGL(up2_unfold_kernel, dim3(stream_grid((size_t)5 * Cin * Cout)), dim3(256), 0, s, dwf, dbf, dw, db, Cin, Cout, stride);
+  return check_launch("up2_unfold");
+}
+
 }  // namespace gn

@@ -341,7 +341,7 @@ class Layer(object):
 
 
 class Node(object):
-    __slots__ = ('layer', 'inbound', 'fused_act', 'fused_drop', 'absorbed', 'index', 'out_shape', 'owners', 'fuse_prev', 'infer_bn')
+    __slots__ = ('layer', 'inbound', 'fused_act', 'fused_drop', 'absorbed', 'index', 'out_shape', 'owners', 'fuse_prev', 'infer_bn', 'fold_up')
 
     def __init__(self, layer, inbound, out_shape, owners=()):
         self.layer = layer
@@ -569,6 +569,17 @@ class Model(Layer):
                 if c is not None and c.layer.drop_rate is not None:
                     n.fused_drop = (c.layer.drop_rate, c.layer)
                     c.absorbed = True
+        # UpSampling1D(2) whose only consumer is a 5-tap 'same' Conv1D: the pair runs as a 3-tap conv on the un-upsampled tensor with
+        # folded weights (layers.Conv1D._geometry); the upsample node passes its input through and nothing is materialised
+        for n in self.nodes:
+            n.fold_up = None
+        for n in self.nodes:
+            if n.absorbed or not getattr(n.layer, 'is_upsample2', False) or len(n.inbound) != 1 or n.inbound[0] < 0:
+                continue
+            c = sole_consumer(n.index)
+            if c is not None and not c.absorbed and hasattr(c.layer, 'can_fold_upsample') and c.layer.can_fold_upsample():
+                c.fold_up = n
+                n.absorbed = True
         # inference-phase fusion: a BatchNormalization that is the sole consumer of a linear conv folds into that conv's weights
         # (predict only: the training phase normalises with batch statistics)
         for n in self.nodes:

@@ -13,6 +13,7 @@ from .engine import Layer, Model, device, device_rng, glorot_uniform
 
 import os as _os
 _NO_DROPGEN = bool(_os.environ.get('GN_NO_DROPGEN'))      # A/B switch: separate dropout-mask kernel instead of drawing it inside bn_apply
+_NO_UPFOLD = bool(_os.environ.get('GN_NO_UPFOLD'))        # A/B switch: materialise UpSampling1D instead of folding it into the conv
 _NO_CONVSTATS = bool(_os.environ.get('GN_NO_CONVSTATS'))  # A/B switch: separate BatchNorm statistics pass instead of the conv epilogue
 
 _ACT_NAMES = {'relu': ('relu', 0.0), 'tanh': ('tanh', 0.0), 'sigmoid': ('sigmoid', 0.0), 'linear': ('linear', 0.0), None: ('linear', 0.0)}
@@ -131,9 +132,24 @@ class Conv1D(Layer):
     def can_fold_bn(self):
         return self.activation[0] == 'linear' and self.filters % 4 == 0 and self.filters > 4
 
+    def can_fold_upsample(self):
+        """UpSampling1D(2) in front folds into the weights (ops.conv1d_up2_fold): the engine's planner asks."""
+        return self.k == 5 and self.padding == 'same' and self.stride in (1, 2) and not _NO_UPFOLD
+
+    def _geometry(self, node, x, w, b):
+        """(w, b, k, stride, pad_left, Lout, Cout) of the conv that actually runs on x: the layer's own, or -- with the upsample in front
+        folded (node.fold_up) -- the 3-tap stride-1 conv on the un-upsampled input; for stride 1 its (L, 2*filters) output is the layer's
+        (2L, filters) output in memory."""
+        if getattr(node, 'fold_up', None) is None:
+            Lout, pl = ops.conv_geometry(x.shape[1], self.k, self.stride, self.padding)
+            return w, b, self.k, self.stride, pl, Lout, self.filters
+        wf, bf = ops.conv1d_up2_fold(w, b, self.stride)
+        return wf, bf, 3, 1, 1, x.shape[1], wf.shape[2]
+
     def forward(self, ctx, node, x):
         a = node.fused_act or self.activation
-        Lout, pl = ops.conv_geometry(x.shape[1], self.k, self.stride, self.padding)
+        fold = getattr(node, 'fold_up', None) is not None
+        B = x.shape[0]
         bn_node = getattr(node, 'infer_bn', None)
         if not ctx.training and bn_node is not None and x.shape[2] > 4:
             # inference phase: the following BatchNormalization (moving statistics) folds into the weights, its activation into the
@@ -141,36 +157,46 @@ class Conv1D(Layer):
             bn = bn_node.layer
             scale, shift = ops.bn_infer_coeffs(bn.gamma.data, bn.beta.data, bn.moving_mean.data, bn.moving_variance.data, bn.epsilon)
             w2, b2 = ops.conv_fold_bn(self.kernel.data, self.bias.data, scale, shift)
+            w2, b2, _, stride, pl, Lout, _ = self._geometry(node, x, w2, b2)
             act = bn_node.fused_act or ('linear', 0.0)
             ctx.skip.add(bn_node.index)
-            return ops.conv1d_fwd(x, w2, b2, self.stride, pl, Lout, act[0], act[1])
+            return ops.conv1d_fwd(x, w2, b2, stride, pl, Lout, act[0], act[1]).view(B, -1, self.filters)
+        w, b, k, stride, pl, Lout, Ce = self._geometry(node, x, self.kernel.data, self.bias.data)
         fused_drop = node.fused_drop is not None and self.filters > 4
         if node.fused_drop is not None and not fused_drop:
             raise NotImplementedError('Dropout directly after a Conv1D with <= 4 filters')
-        if ctx.training and bn_node is not None and x.shape[2] > 4 and not _NO_CONVSTATS:
+        if ctx.training and bn_node is not None and x.shape[2] > 4 and Ce == self.filters and not _NO_CONVSTATS:
             # training phase, linear conv whose only consumer is a BatchNormalization: its batch statistics come out of the conv kernel's
-            # epilogue (no separate pass over the output); the BN node picks them up from ctx.bn_sums
-            y, sums = ops.conv1d_fwd_stats(x, self.kernel.data, self.bias.data, self.stride, pl, Lout)
+            # epilogue (no separate pass over the output); the BN node picks them up from ctx.bn_sums.  (Not for the two-phase folded
+            # form, whose columns are (phase, channel): that BN layer runs its own statistics pass.)
+            y, sums = ops.conv1d_fwd_stats(x, w, b, stride, pl, Lout)
             ctx.bn_sums[bn_node.index] = sums
-            ctx.tape[node.index] = (x, y, a, pl, None, 0.0)
+            ctx.tape[node.index] = (x, y, a, pl, None, 0.0, w if fold else None)
             return y
-        y, mask, rate = _conv_fwd(node, ctx, x, self.kernel.data, self.bias.data, self.stride, pl, Lout, a, (x.shape[0], Lout, self.filters))
-        ctx.tape[node.index] = (x, y, a, pl, mask, rate)
+        y, mask, rate = _conv_fwd(node, ctx, x, w, b, stride, pl, Lout, a, (B, Lout, Ce))
+        ctx.tape[node.index] = (x, y, a, pl, mask, rate, w if fold else None)       # y, mask in the shape of the conv that ran
+        y = y.view(B, -1, self.filters)
         if ctx.training and (a[0] != 'linear' or mask is not None):
-            ctx.epi[node.index] = (y, a[0], a[1], mask, rate)
+            ctx.epi[node.index] = (y, a[0], a[1], None if mask is None else mask.view(y.shape), rate)
         return y
 
     def backward(self, ctx, node, dy, need_dx, need_dw, prev=None):
-        x, y, a, pl, mask, rate = ctx.tape.pop(node.index)
-        dy = _conv_bwd_epilogue(dy.contiguous(), y, a, mask, rate, ctx, node)
+        x, y, a, pl, mask, rate, wf = ctx.tape.pop(node.index)
+        dy = _conv_bwd_epilogue(dy.contiguous().view(y.shape), y, a, mask, rate, ctx, node)
         if need_dw:
-            ops.conv1d_wgrad(x, dy, self.k, self.stride, pl, self.kernel.grad, self.bias.grad)
+            if wf is None:
+                ops.conv1d_wgrad(x, dy, self.k, self.stride, pl, self.kernel.grad, self.bias.grad)
+            else:
+                dwf, dbf = ops.conv1d_wgrad(x, dy, 3, 1, pl)
+                ops.conv1d_up2_unfold_grad(dwf, dbf, self.filters, self.stride, self.kernel.grad, self.bias.grad)
         if need_dx:
-            if prev is not None and ops.can_fuse_dgrad(x.shape[2], self.filters):
+            if prev is not None and ops.can_fuse_dgrad(x.shape[2], y.shape[2]):
                 ctx.pre_applied.add(node.fuse_prev)
             else:
                 prev = None
-            return ops.conv1d_dgrad(dy, ops.conv1d_transpose_w(self.kernel.data), x.shape[1], self.stride, pl, prev)
+            if wf is None:
+                return ops.conv1d_dgrad(dy, ops.conv1d_transpose_w(self.kernel.data), x.shape[1], self.stride, pl, prev)
+            return ops.conv1d_dgrad(dy, ops.conv1d_transpose_w(wf), x.shape[1], 1, pl, prev)
         return None
 
 
@@ -475,7 +501,9 @@ class Flatten(Layer):
 
 
 class UpSampling1D(Layer):
-    """bbhMahoGANy.py:249,:258."""
+    """bbhMahoGANy.py:249,:258.  In front of a 5-tap 'same' Conv1D (both uses in the generator) the planner folds it into that conv's
+    weights and this layer never runs; the kernels below serve every other placement."""
+    is_upsample2 = True
 
     def __init__(self, size=2, **kw):
         Layer.__init__(self, **kw)

@@ -181,6 +181,30 @@ def conv2d_w2_unfold_grad(dwf, dbf, Cin, Cout, dw=None, db=None):
     return dw, db
 
 
+def conv1d_up2_fold(w, b, stride):
+    """UpSampling1D(2) -> Conv1D(5, 'same', stride) as a 3-tap stride-1 conv on the un-upsampled input (gn_conv1d_up2_fold)."""
+    _chk(w, b)
+    k, Cin, Cout = w.shape
+    assert k == 5 and stride in (1, 2)
+    Cf = Cout * (2 if stride == 1 else 1)
+    wf = torch.empty((3, Cin, Cf), dtype=torch.float32, device=w.device)
+    bf = torch.empty((Cf,), dtype=torch.float32, device=w.device)
+    _lib.call('gn_conv1d_up2_fold', _p(w), _p(b), _p(wf), _p(bf), Cin, Cout, stride, _stream())
+    return wf, bf
+
+
+def conv1d_up2_unfold_grad(dwf, dbf, Cout, stride, dw=None, db=None):
+    _chk(dwf, dbf, dw, db)
+    Cin = dwf.shape[1]
+    assert dwf.shape[0] == 3 and dwf.shape[2] == Cout * (2 if stride == 1 else 1)
+    if dw is None:
+        dw = torch.empty((5, Cin, Cout), dtype=torch.float32, device=dwf.device)
+    if db is None:
+        db = torch.empty((Cout,), dtype=torch.float32, device=dwf.device)
+    _lib.call('gn_conv1d_up2_unfold_grad', _p(dwf), _p(dbf), _p(dw), _p(db), Cin, Cout, stride, _stream())
+    return dw, db
+
+
 def dense_fwd(x, w, b, act='linear', act_param=0.0):
     _chk(x, w, b)
     B, n_in = x.shape

@@ -100,6 +100,18 @@ int gn_conv1d_wgrad(const float* x, const float* dy, float* dw, float* db, void*
 int gn_conv2d_w2_fold(const float* w, const float* bias, float* wf, float* biasf, int kh, int Cin, int Cout, void* stream);
 int gn_conv2d_w2_unfold_grad(const float* dwf, const float* dbf, float* dw, float* db, int kh, int Cin, int Cout, void* stream);
 
+/* ---- UpSampling1D(2) -> Conv1D(C, 5, strides=s, padding='same') fold (bbhMahoGANy.py:249-250 s=2, :258-259 s=1) ----
+ * The pair equals a 3-tap stride-1 'same' conv (pad_left 1) on the UN-upsampled input x (B, L, Cin), so the upsampled tensor is
+ * never written and 2 of 5 taps' multiplies go away:
+ *   s=2:  y[t]    = W0 x[t-1] + (W1+W2) x[t] + (W3+W4) x[t+1]                     wf (3, Cin, Cout),   biasf = bias
+ *   s=1:  y[2u]   = (W0+W1) x[u-1] + (W2+W3) x[u] + W4 x[u+1]     columns [0,Cout)
+ *         y[2u+1] = W0 x[u-1] + (W1+W2) x[u] + (W3+W4) x[u+1]     columns [Cout,2Cout)  wf (3, Cin, 2*Cout), biasf = [bias, bias];
+ *         the folded conv's (B, L, 2*Cout) output is the layer's (B, 2L, Cout) output in memory.
+ * unfold_grad maps the folded conv's weight / bias gradient (gn_conv1d_wgrad on x and the same dy memory) back onto the 5 taps:
+ * dW[k] = sum of the folded taps W[k] went into; db = dbf (s=2) or dbf[:Cout] + dbf[Cout:] (s=1). */
+int gn_conv1d_up2_fold(const float* w, const float* bias, float* wf, float* biasf, int Cin, int Cout, int stride, void* stream);
+int gn_conv1d_up2_unfold_grad(const float* dwf, const float* dbf, float* dw, float* db, int Cin, int Cout, int stride, void* stream);
+
 /* ---- Dense (bbhMahoGANy.py:234 generator 100 -> 256*n_pix/2; :377,:399,:494 flatten -> 1 heads) -------------
  * y[b,o] = act(bias[o] + sum_i x[b,i] * w[i,o]).  Large `out` goes through the MFMA GEMM, out <= 4 through
  * the streaming dot-product kernel. */

@@ -56,7 +56,11 @@ def test_graphs_fusion_plan_and_param_counts():
     G_._plan()
     bn = [n for n in G_.nodes if n.layer.__class__.__name__ == 'BatchNormalization']
     assert len(bn) == 6 and all(n.fused_act == ('tanh', 0.0) and n.fused_drop[0] == 0.2 for n in bn)
-    assert sum(n.absorbed for n in G_.nodes) == 13                     # 6 x (Activation + Dropout) + the final linear Activation
+    assert sum(n.absorbed for n in G_.nodes) == 15                     # 6 x (Activation + Dropout) + the final linear Activation + 2 UpSampling1D
+    ups = [n for n in G_.nodes if n.layer.__class__.__name__ == 'UpSampling1D']
+    folded = [n for n in G_.nodes if n.fold_up is not None]
+    assert len(ups) == 2 and all(u.absorbed for u in ups) and [n.fold_up for n in folded] == ups      # never materialised
+    assert [(n.layer.filters, n.layer.stride) for n in folded] == [(64, 2), (128, 1)]
     D._plan()
     convs = [n for n in D.nodes if n.layer.__class__.__name__ == 'Conv2D']
     assert all(n.fused_act == ('leaky', 0.2) for n in convs)

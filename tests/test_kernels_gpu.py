@@ -51,6 +51,9 @@ CONV_CASES = [
     (2, 64, 128, 2, 5, 2, 'same'),
     (3, 70, 512, 1, 5, 1, 'valid'),       # Cout = 1 row-run kernel, ragged run, two channel passes
     (2, 61, 128, 3, 5, 1, 'same'),        # small-Cout weight gradient looped over input rows
+    (2, 50, 16, 64, 3, 1, 'same'),        # 3 taps (the folded UpSampling1D -> Conv1D layers), matrix-core weight gradient
+    (2, 45, 64, 128, 2, 1, 'valid'),      # 2 taps
+    (3, 66, 32, 64, 4, 2, 'same'),        # 4 taps, stride 2
 ]
 
 
@@ -137,6 +140,30 @@ def test_conv2d_width2_fold_matches_conv2d():
     close(dw, dw_ref, 5e-5); close(db, db_ref, 5e-5)
     dx = ops.conv1d_dgrad(dyf, ops.conv1d_transpose_w(wf), H, 2, pl)
     close(dx.reshape(B, H, 2, Cin), dx_ref)
+
+
+@pytest.mark.parametrize("B,L,Cin,Cout,s", [(2, 48, 16, 64, 2), (2, 48, 16, 64, 1), (3, 37, 64, 128, 1), (3, 37, 256, 64, 2), (2, 9, 8, 8, 1)])
+def test_upsample_conv_fold_matches_upsample_then_conv(B, L, Cin, Cout, s):
+    """UpSampling1D(2) -> Conv1D(5, 'same', s) == a 3-tap stride-1 conv on the un-upsampled input with folded weights
+    (bbhMahoGANy.py:249-250 s=2, :258-259 s=1): forward, data gradient, weight / bias gradient against the materialised definition."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(L + Cin + s)
+    x = f32(rng.randn(B, L, Cin)); w = f32(rng.randn(5, Cin, Cout) * 0.1); b = f32(rng.randn(Cout))
+    u = K.upsample1d_fwd(x)
+    y_ref = K.conv1d_fwd(u, w, b, s, 'same')
+    wf, bf = ops.conv1d_up2_fold(g(w), g(b), s)
+    assert tuple(wf.shape) == (3, Cin, Cout * (2 if s == 1 else 1))
+    y = ops.conv1d_fwd(g(x), wf, bf, 1, 1, L)
+    close(y.reshape(y_ref.shape), y_ref)
+    dy = f32(rng.randn(*y_ref.shape))
+    du_ref, dw_ref, db_ref = K.conv1d_bwd(u, w, dy, s, 'same')
+    dx_ref = K.upsample1d_bwd(du_ref)
+    dyf = g(dy).reshape(y.shape)
+    dwf, dbf = ops.conv1d_wgrad(g(x), dyf, 3, 1, 1)
+    dw, db = ops.conv1d_up2_unfold_grad(dwf, dbf, Cout, s)
+    close(dw, dw_ref, 5e-5); close(db, db_ref, 5e-5)
+    dx = ops.conv1d_dgrad(dyf, ops.conv1d_transpose_w(wf), L, 1, 1)
+    close(dx, dx_ref, 5e-5)
 
 
 @pytest.mark.parametrize("B,n_in,n_out", [(5, 100, 512), (130, 100, 1024), (4, 64, 260)])

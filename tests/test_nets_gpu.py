@@ -249,6 +249,48 @@ def test_unfused_layers_match_fused_epilogues():
     assert np.isfinite(out).all()
 
 
+@pytest.mark.parametrize("stride", [1, 2])
+def test_folded_upsample_trains_like_the_materialised_one(stride, monkeypatch):
+    """The planner's UpSampling1D -> Conv1D fold (weights folded per step, gradient unfolded) against the same graph with the upsampled
+    tensor materialised: predict, losses and the weights after two Adam steps, with the fused tanh + dropout epilogue on the folded conv
+    and an UpSampling1D that cannot fold (3-tap 'valid' consumer) in the same graph."""
+    from gennet_amd import engine, layers
+    from gennet_amd.engine import Adam, Sequential
+    from gennet_amd.layers import Activation, Conv1D, Dense, Dropout, Flatten, UpSampling1D
+    rng = np.random.RandomState(5 + stride)
+    B, L = 4, 20
+    x = f32(rng.randn(B, L, 4)); y = f32(rng.randn(B))
+    Lc = 2 * L // stride
+    mask = (rng.rand(B, Lc, 16) >= 0.2).astype(np.uint8)
+
+    def run(fold):
+        monkeypatch.setattr(layers, '_NO_UPFOLD', not fold)
+        engine.set_init_seed(9)
+        m = Sequential()
+        m.add(Conv1D(8, 5, padding='same', input_shape=(L, 4)))
+        m.add(UpSampling1D(size=2))
+        m.add(Conv1D(16, 5, strides=stride, padding='same'))
+        m.add(Activation('tanh'))
+        m.add(Dropout(0.2, name='drop_fold'))
+        m.add(UpSampling1D(size=2))
+        m.add(Conv1D(8, 3, padding='valid'))
+        m.add(Flatten())
+        m.add(Dense(1))
+        m.compile(loss='mean_squared_error', optimizer=Adam(lr=1e-2))
+        m._plan()
+        assert [n.fold_up is not None for n in m.nodes if isinstance(n.layer, Conv1D)] == [False, fold, False]
+        p0 = m.predict(x)
+        losses = [m.train_on_batch(x, y, dropout_masks={'drop_fold': mask}) for _ in range(2)]
+        return p0, losses, m.get_weights()
+
+    pa, la, wa = run(True)
+    pb, lb, wb = run(False)
+    assert rel(pa, pb) < 2e-5
+    assert np.allclose(la, lb, rtol=1e-4)
+    for a, b in zip(wa, wb):
+        assert rel(a, b) < 1e-4
+
+
 def test_save_load_roundtrip(tmp_path):
     from gennet_amd import bbh
     from gennet_amd.engine import Adam, load_model
