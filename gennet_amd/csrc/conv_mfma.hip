@@ -734,6 +734,11 @@ static int launch_wgrad(WgradArgs& a, float* dw, hipStream_t s) {
         (size_t)a.M * a.Cout * 4 < 0x40000000ull) {
       // the bias gradient rides along: the blocks of Cin-tile 0 sum the columns of the dy tiles they stage anyway (no separate pass over dy)
       a.db_part = a.db ? reinterpret_cast<double*>(reinterpret_cast<char*>(a.part) + (size_t)splits * NTAPS * a.Cin * a.Cout * sizeof(float)) : nullptr;
+      // whole K-splits per XCD (wgrad_pipe_kernel): FETCH_SIZE -33 % but 1 % SLOWER on G 512 -> 1024 (143.8 against 145.5 TFLOP/s in
+      // the step): in grid order the 8 XCDs read the same dy tiles at about the same time and the Infinity Cache serves 7 of the 8;
+      // with private splits every XCD streams its own batch range from HBM.  Off unless GN_WGRAD_XCD is set.
+      static const bool xcd = getenv("GN_WGRAD_XCD") != nullptr;
+      a.xcd_order = xcd && splits % 8 == 0;
       wgrad_pipe_launch(a, grid, WAVES_C == 2, s);                       // wgrad_pipe.hip
       piped = true;
     }

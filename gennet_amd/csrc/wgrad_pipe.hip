@@ -101,7 +101,21 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(W
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave / WAVES_N, wn = wave % WAVES_N;
   const int i32 = lane & 31, h = lane >> 5;
-  const int c0 = blockIdx.x * TC, n0 = blockIdx.y * TN, split = blockIdx.z;
+  // block -> (Cin tile, Cout tile, K-split).  In grid order (x fastest) block i runs on XCD i mod 8: with 8 Cin tiles every XCD owns one
+  // of them and reads ALL of dy -- dy crosses the fabric 8 times.  xcd_order gives XCD k the K-splits k, k + 8, ... with all their
+  // tiles (consecutive blocks of an XCD walk the tiles of one split), so each x slab and dy tile of a split is fetched by one XCD only
+  // and its L2 serves the Cin-tile x Cout-tile reuse.
+  int ct = blockIdx.x, nt_ = blockIdx.y, split = blockIdx.z;
+  if (a.xcd_order) {
+    const int tiles = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int q = lin >> 3, tile = q % tiles;
+    split = (q / tiles) * 8 + (lin & 7);
+    ct = tile % (int)gridDim.x;
+    nt_ = tile / (int)gridDim.x;
+  }
+  ct = __builtin_amdgcn_readfirstlane(ct); nt_ = __builtin_amdgcn_readfirstlane(nt_); split = __builtin_amdgcn_readfirstlane(split);
+  const int c0 = ct * TC, n0 = nt_ * TN;
 
   int minoff = a.off[0];
 #pragma unroll
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(W
 
   // bias gradient on the way (blocks of Cin-tile 0 only): thread (column tid % TN, row group tid / TN) adds its rows of every staged
   // dy tile in fp64 (rows >= M were staged as zeros); 8 LDS reads per chunk against the 96 of the MFMA operands
-  const bool do_bias = a.db_part != nullptr && blockIdx.x == 0;
+  const bool do_bias = a.db_part != nullptr && ct == 0;
   constexpr int RG = NT / TN, RPG = KT / RG;
   double bsum = 0.0;
   auto bias_chunk = [&](const float* stage) {
