@@ -398,21 +398,29 @@ __global__ __launch_bounds__(256) void colred_kernel(ColRedArgs a) {
 
 // sum the chunk partials: block = 32 columns x 8 chunk lanes; lane l adds chunks l, l+8, ... then the 8 lane sums are added in
 // lane order (fixed order -> bitwise reproducible)
-template <typename OUT>
+template <typename OUT, int COLS>
 __global__ __launch_bounds__(256) void colred_final_kernel(const double* __restrict__ part, OUT* __restrict__ out, size_t n, int chunks) {
-  const int col = threadIdx.x & 31, lane = threadIdx.x >> 5;
-  const size_t i = (size_t)blockIdx.x * 32 + col;
+  constexpr int LANES = 256 / COLS;
+  const int col = threadIdx.x % COLS, lane = threadIdx.x / COLS;
+  const size_t i = (size_t)blockIdx.x * COLS + col;
   double s = 0.0;
   if (i < n)
-    for (int k = lane; k < chunks; k += 8) s += part[(size_t)k * n + i];
-  __shared__ double red[8][33];
+    for (int k = lane; k < chunks; k += LANES) s += part[(size_t)k * n + i];
+  __shared__ double red[LANES][COLS + 1];
   red[lane][col] = s;
   __syncthreads();
   if (lane == 0 && i < n) {
     double t = red[0][col];
-    for (int l = 1; l < 8; ++l) t += red[l][col];
+    for (int l = 1; l < LANES; ++l) t += red[l][col];
     out[i] = (OUT)t;
   }
+}
+// 32 columns x 8 lanes per block; with many partial rows and few columns (the per-block partials of the conv epilogue: 4096 rows x 2048
+// columns ran on 64 blocks) 8 columns x 32 lanes, four times the blocks and a quarter of the serial adds per thread
+template <typename OUT>
+static void colred_final_launch(const double* part, OUT* out, size_t n, int chunks, hipStream_t s) {
+  if (chunks >= 256 && n <= 16384) hipLaunchKernelGGL((colred_final_kernel<OUT, 8>), dim3(cdiv(n, 8)), dim3(256), 0, s, part, out, n, chunks);
+  else hipLaunchKernelGGL((colred_final_kernel<OUT, 32>), dim3(cdiv(n, 32)), dim3(256), 0, s, part, out, n, chunks);
 }
 
 static int colred_chunks(size_t rows, int C) {
@@ -443,17 +451,17 @@ int colred_run(int mode, ColRedArgs a, void* ws, size_t ws_bytes, double* out_f6
   int rc = check_launch("colred");
   if (rc) return rc;
   const size_t n = (size_t)NV * a.C;
-  if (out_f32) hipLaunchKernelGGL(colred_final_kernel<float>, dim3(cdiv(n, 32)), dim3(256), 0, s, (const double*)ws, out_f32, n, chunks);
-  else hipLaunchKernelGGL(colred_final_kernel<double>, dim3(cdiv(n, 32)), dim3(256), 0, s, (const double*)ws, out_f64, n, chunks);
+  if (out_f32) colred_final_launch((const double*)ws, out_f32, n, chunks, s);
+  else colred_final_launch((const double*)ws, out_f64, n, chunks, s);
   return check_launch("colred_final");
 }
 
 int colred_finalize(const double* part, double* out_f64, size_t n, int chunks, hipStream_t s) {
-  hipLaunchKernelGGL(colred_final_kernel<double>, dim3(cdiv(n, 32)), dim3(256), 0, s, part, out_f64, n, chunks);
+  colred_final_launch(part, out_f64, n, chunks, s);
   return check_launch("colred_final");
 }
 int colred_finalize_f32(const double* part, float* out_f32, size_t n, int chunks, hipStream_t s) {
-  hipLaunchKernelGGL(colred_final_kernel<float>, dim3(cdiv(n, 32)), dim3(256), 0, s, part, out_f32, n, chunks);
+  colred_final_launch(part, out_f32, n, chunks, s);
   return check_launch("colred_final");
 }
 

@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256) void dense_small_bwd_kernel(const float* __res
     }
   // U rows of x (and their masks) are loaded before any of them is used: with one load per iteration and 2 blocks per CU the
   // loop ran at the latency of a single 16-byte load per wave (1.7-2.5 TB/s); the sums stay in b order
-  constexpr int U = 4;
+  constexpr int U = 8;
   for (int b0 = 0; b0 < B; b0 += U) {
     float4 xq[U];
     uchar4 mq[U];

@@ -54,6 +54,8 @@ CONV_CASES = [
     (2, 50, 16, 64, 3, 1, 'same'),        # 3 taps (the folded UpSampling1D -> Conv1D layers), matrix-core weight gradient
     (2, 45, 64, 128, 2, 1, 'valid'),      # 2 taps
     (3, 66, 32, 64, 4, 2, 'same'),        # 4 taps, stride 2
+    (9, 2100, 16, 512, 5, 1, 'same'),     # 648 blocks of the tall tile: 512 in XCD patch order (8 slabs x 8 column tiles) + a plain-order tail
+    (20, 1100, 16, 512, 3, 1, 'same'),    # 720 blocks of the square tile, 4 column tiles: 16 x 4 patches + tail
 ]
 
 
