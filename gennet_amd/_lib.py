@@ -57,6 +57,8 @@ _SIGS = {
     'gn_bn_apply': [vp, vp, vp, vp, vp, sz, i32, i32, f32, f32, vp],
     'gn_bn_bwd_stats': [vp, vp, vp, vp, vp, vp, vp, vp, sz, sz, i32, i32, f32, f32, vp, vp, vp],
     'gn_bn_bwd_apply': [vp, vp, vp, vp, vp, vp, vp, vp, f64, vp, vp, vp, vp, sz, i32, i32, f32, f32, vp, vp, vp],
+    'gn_bn_bwd_stats_conv1': [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, sz, i32, i32, f32, f32, vp, vp, vp],
+    'gn_bn_bwd_apply_conv1': [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, f64, vp, vp, vp, vp, sz, i32, i32, f32, f32, vp, vp, vp],
     'gn_bce_loss': [vp, vp, vp, vp, i32, i32, vp],
     'gn_mse_loss': [vp, vp, vp, vp, i32, i32, vp],
     'gn_adam_step': [vp, vp, vp, vp, sz, f32, f32, f32, f32, vp],

@@ -547,6 +547,36 @@ int gn_bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8
                       shift, (hipStream_t)stream);
 }
 
+static int lazy_dy_check(const char* who, const float* g, const float* w, int L, int Lout, int k, int pad_left, size_t rows, int C, const float* scale,
+                         const float* shift, LazyDy* z) {
+  GN_REQUIRE(g && w && L > 0 && Lout > 0 && k >= 1 && k <= 8 && pad_left >= 0, "%s: bad conv description (1 filter, 1..8 taps, stride 1)", who);
+  GN_REQUIRE(C % 4 == 0 && scale && shift, "%s: needs C %% 4 == 0 and the forward pass' scale / shift", who);
+  GN_REQUIRE(rows % (size_t)L == 0 && rows / (size_t)L < 0x7fffffffull, "%s: rows %zu is not a whole number of length-%d segments", who, rows, L);
+  z->g = g; z->w = w; z->L = L; z->Lout = Lout; z->k = k; z->pad_left = pad_left;
+  return GN_OK;
+}
+int gn_bn_bwd_stats_conv1(const float* g, const float* w, int L, int Lout, int k, int pad_left, const float* x, const uint8_t* mask, const float* save_mean,
+                          const float* save_invstd, double* dsums, void* ws, size_t ws_bytes, size_t rows, int C, int act, float p, float rate,
+                          const float* scale, const float* shift, void* stream) {
+  GN_REQUIRE(x && save_mean && save_invstd && dsums && ws && rows > 0 && C > 0, "bn_bwd_stats_conv1: bad arguments");
+  ColRedArgs r = {};
+  int rc = lazy_dy_check("bn_bwd_stats_conv1", g, w, L, Lout, k, pad_left, rows, C, scale, shift, &r.lz);
+  if (rc) return rc;
+  r.a = nullptr; r.y = nullptr; r.xpre = x; r.mask = mask; r.mean = save_mean; r.invstd = save_invstd; r.scale = scale; r.shift = shift;
+  r.rows = rows; r.C = C; r.act = act; r.act_param = p; r.keep_scale = 1.0f / (1.0f - (mask ? rate : 0.f));
+  return colred_run(2, r, ws, ws_bytes, dsums, nullptr, (hipStream_t)stream);
+}
+int gn_bn_bwd_apply_conv1(const float* g, const float* w, int L, int Lout, int k, int pad_left, const float* x, const uint8_t* mask, const float* gamma,
+                          const float* save_mean, const float* save_invstd, const double* dsums_global, double count, const double* dsums_local, float* dx,
+                          float* dgamma, float* dbeta, size_t rows, int C, int act, float p, float rate, const float* scale, const float* shift, void* stream) {
+  GN_REQUIRE(x && gamma && save_mean && save_invstd && dsums_global && dsums_local && dx && dgamma && dbeta && C > 0, "bn_bwd_apply_conv1: bad arguments");
+  LazyDy z = {};
+  int rc = lazy_dy_check("bn_bwd_apply_conv1", g, w, L, Lout, k, pad_left, rows, C, scale, shift, &z);
+  if (rc) return rc;
+  return bn_bwd_apply(nullptr, nullptr, x, mask, gamma, save_mean, save_invstd, dsums_global, count, dsums_local, dx, dgamma, dbeta, rows, C, act, p,
+                      mask ? rate : 0.f, scale, shift, (hipStream_t)stream, &z);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 int gn_bce_loss(const float* p, const float* y, float* dp, float* out, int B, int Bglobal, void* stream) {
   GN_REQUIRE(p && y && dp && out, "bce_loss: null pointer");

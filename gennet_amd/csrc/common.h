@@ -79,6 +79,14 @@ struct WgradSmallArgs {
   int rows_per_chunk;
 };
 
+// The gradient arriving at a BatchNormalization output when the layer feeds ONLY a Conv1D(1 filter, k <= 8 taps, stride 1): that conv's
+// data gradient dz[b,t,c] = sum_j g[b, t - j + pad_left] * w[j,c], computed where it is consumed instead of written and re-read.
+struct LazyDy {
+  const float* g;   // (B, Lout): the conv's output gradient (after its own activation backward); NULL = not lazy
+  const float* w;   // (k, C): the conv's kernel
+  int L, Lout, k, pad_left;
+};
+
 struct ColRedArgs {
   const float* a;        // x (MODE 0/1) or dy (MODE 2)
   const float* y;        // MODE 2: layer output (post act, post dropout)
@@ -95,6 +103,7 @@ struct ColRedArgs {
   int act;
   float act_param;
   float keep_scale;      // 1/(1-rate)
+  LazyDy lz;             // MODE 2: lz.g != NULL -> a is not read
 };
 
 // conv_mfma.hip
@@ -144,7 +153,7 @@ int bn_infer_coeffs(const float* gamma, const float* beta, const float* mm, cons
 int bn_apply(const float* x, const float* scale, const float* shift, const uint8_t* mask, float* y, size_t rows, int C, int act, float p, float rate, hipStream_t s);
 int bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8_t* mask, const float* gamma, const float* mean, const float* invstd,
                  const double* dsums_global, double count, const double* dsums_local, float* dx, float* dgamma, float* dbeta, size_t rows, int C,
-                 int act, float p, float rate, const float* scale, const float* shift, hipStream_t s);
+                 int act, float p, float rate, const float* scale, const float* shift, hipStream_t s, const LazyDy* lz = nullptr);
 int loss_run(int kind, const float* p, const float* y, float* dp, float* out, int B, int Bglobal, hipStream_t s);
 int adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s);
 int transpose_w(const float* w, float* wt, int k, int Cin, int Cout, hipStream_t s);

@@ -310,6 +310,32 @@ __device__ __forceinline__ float bn_bwd_g_act(float dy, float yact, uint8_t keep
   return dy * keep_scale * act_grad_from_y(yact, act, p);
 }
 
+// LazyDy (common.h): the 4 channels 4q..4q+3 of row r of the data gradient of a 1-filter stride-1 conv, from its output gradient
+// and kernel; wq holds the thread's kernel columns (taps past k are zero)
+__device__ __forceinline__ void lazy_dy_taps(const LazyDy& z, int C, int q, float wq[8][4]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < z.k) w4 = *reinterpret_cast<const float4*>(z.w + (size_t)j * C + 4 * q);
+    wq[j][0] = w4.x; wq[j][1] = w4.y; wq[j][2] = w4.z; wq[j][3] = w4.w;
+  }
+}
+__device__ __forceinline__ void lazy_dy4(const LazyDy& z, size_t r, const float wq[8][4], float v[4]) {
+  const unsigned b = (unsigned)(r / (unsigned)z.L);
+  const int t = (int)(r - (size_t)b * z.L);
+  const float* gb = z.g + (size_t)b * z.Lout;
+  v[0] = v[1] = v[2] = v[3] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < z.k) {
+      const int u = t - j + z.pad_left;
+      const float gv = (u >= 0 && u < z.Lout) ? gb[u] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(gv, wq[j][e], v[e]);
+    }
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void colred_kernel(ColRedArgs a) {
   constexpr int NV = MODE == 0 ? 1 : 2;
@@ -337,10 +363,18 @@ __global__ __launch_bounds__(256) void colred_kernel(ColRedArgs a) {
         sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
       }
     }
+    float wq[8][4];
+    const bool lazy = MODE == 2 && a.lz.g != nullptr;
+    if (lazy) lazy_dy_taps(a.lz, a.C, q, wq);
     for (size_t r = r_lo + rl; r < r_hi; r += RL) {
       const size_t o = r * a.C + 4 * q;
-      const float4 v4 = *reinterpret_cast<const float4*>(a.a + o);
-      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+      float v[4];
+      if (lazy) {
+        lazy_dy4(a.lz, r, wq, v);
+      } else {
+        const float4 v4 = *reinterpret_cast<const float4*>(a.a + o);
+        v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
+      }
       if (MODE == 0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[0][e] += (double)v[e];
@@ -572,7 +606,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
                                                               const uint8_t* __restrict__ mask, const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, const double* __restrict__ dsums, double count,
                                                               const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ dx,
-                                                              size_t rows, int C, int rows_per_chunk, int act, float p, float keep_scale) {
+                                                              size_t rows, int C, int rows_per_chunk, int act, float p, float keep_scale, LazyDy lz) {
   const int NQ = C >> 2;
   const int NQc = NQ < 256 ? NQ : 256;
   const int RL = 256 / NQc;
@@ -590,10 +624,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
     mg[e] = (float)(dsums[c] / count); mgx[e] = (float)(dsums[C + c] / count);
     if (scale) { sc[e] = scale[c]; sh[e] = shift[c]; }
   }
+  float wq[8][4];
+  if (lz.g) lazy_dy_taps(lz, C, q, wq);
   for (size_t r = r_lo + rl; r < r_hi; r += RL) {
     const size_t o = r * C + 4 * q;
-    const float4 d4 = *reinterpret_cast<const float4*>(dy + o), x4 = *reinterpret_cast<const float4*>(x + o);
-    const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+    const float4 x4 = *reinterpret_cast<const float4*>(x + o);
+    const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+    float dv[4];
+    if (lz.g) {
+      lazy_dy4(lz, r, wq, dv);
+    } else {
+      const float4 d4 = *reinterpret_cast<const float4*>(dy + o);
+      dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
+    }
     float yv[4] = {0, 0, 0, 0};
     if (!scale) {
       const float4 y4 = *reinterpret_cast<const float4*>(y + o);
@@ -623,9 +666,12 @@ __global__ void bn_param_grads_kernel(const double* __restrict__ dsums_local, fl
 }
 int bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8_t* mask, const float* gamma, const float* mean, const float* invstd,
                  const double* dsums_global, double count, const double* dsums_local, float* dx, float* dgamma, float* dbeta, size_t rows, int C,
-                 int act, float p, float rate, const float* scale, const float* shift, hipStream_t s) {
+                 int act, float p, float rate, const float* scale, const float* shift, hipStream_t s, const LazyDy* lz) {
   const size_t n = rows * C;
   if (!n) return GN_OK;
+  LazyDy z = {};
+  if (lz) z = *lz;
+  if (z.g && (C % 4 || !scale)) { set_error("bn_bwd_apply: the on-the-fly conv gradient needs C %% 4 == 0 and scale / shift"); return GN_EINVAL; }
   if (C % 4 == 0) {
     const int NQ = C / 4, NQc = NQ < 256 ? NQ : 256, RL = 256 / NQc, qblocks = cdiv(NQ, NQc);
     size_t chunks = 8192 / qblocks;                       // ~8k blocks: 32 per CU
@@ -635,7 +681,7 @@ int bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8_t*
     if (rpc < (size_t)RL) rpc = RL;
     chunks = (rows + rpc - 1) / rpc;
     hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3((unsigned)(chunks * qblocks)), dim3(256), 0, s, dy, y, x, mask, gamma, mean, invstd, dsums_global, count, scale,
-                       shift, dx, rows, C, (int)rpc, act, p, 1.0f / (1.0f - rate));
+                       shift, dx, rows, C, (int)rpc, act, p, 1.0f / (1.0f - rate), z);
   } else {
     if (!y) { set_error("bn_bwd_apply: C %d %% 4 != 0 needs the stored layer output y", C); return GN_EINVAL; }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n)), dim3(256), 0, s, dy, y, x, mask, gamma, mean, invstd, dsums_global, count, dx, n, C, act, p,

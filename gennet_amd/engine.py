@@ -341,7 +341,7 @@ class Layer(object):
 
 
 class Node(object):
-    __slots__ = ('layer', 'inbound', 'fused_act', 'fused_drop', 'absorbed', 'index', 'out_shape', 'owners', 'fuse_prev', 'infer_bn', 'fold_up')
+    __slots__ = ('layer', 'inbound', 'fused_act', 'fused_drop', 'absorbed', 'index', 'out_shape', 'owners', 'fuse_prev', 'infer_bn', 'fold_up', 'lazy_bn')
 
     def __init__(self, layer, inbound, out_shape, owners=()):
         self.layer = layer
@@ -603,6 +603,20 @@ class Model(Layer):
                 cur = self.nodes[cur].inbound[0]
             if ok and cur >= 0 and len(consumers[cur]) == 1 and cur not in outs and getattr(self.nodes[cur].layer, 'offers_act_bwd', False):
                 n.fuse_prev = cur
+        # a 1-filter stride-1 Conv1D whose input comes from a BatchNormalization through absorbed nodes only (the generator's output
+        # conv): its data gradient is not materialised, the BatchNormalization's backward passes form it on the fly (ops.ConvGrad1)
+        for n in self.nodes:
+            n.lazy_bn = -1
+            if n.absorbed or len(n.inbound) != 1 or n.fold_up is not None or not hasattr(n.layer, 'can_defer_dgrad'):
+                continue
+            cur = n.inbound[0]
+            while cur >= 0 and self.nodes[cur].absorbed and len(consumers[cur]) == 1 and cur not in outs:
+                cur = self.nodes[cur].inbound[0]
+            if cur < 0 or len(consumers[cur]) != 1 or cur in outs or not getattr(self.nodes[cur].layer, 'is_batchnorm', False) or self.nodes[cur].absorbed:
+                continue
+            shp = self.nodes[cur].out_shape
+            if len(shp) == 2 and n.layer.can_defer_dgrad(shp[1]):
+                n.lazy_bn = cur
         self._planned = True
 
     # -- execution

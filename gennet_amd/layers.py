@@ -13,6 +13,7 @@ from .engine import Layer, Model, device, device_rng, glorot_uniform
 
 import os as _os
 _NO_DROPGEN = bool(_os.environ.get('GN_NO_DROPGEN'))      # A/B switch: separate dropout-mask kernel instead of drawing it inside bn_apply
+_NO_LAZYGRAD = bool(_os.environ.get('GN_NO_LAZYGRAD'))    # A/B switch: materialise the 1-filter conv's data gradient in front of a BatchNormalization
 _NO_UPFOLD = bool(_os.environ.get('GN_NO_UPFOLD'))        # A/B switch: materialise UpSampling1D instead of folding it into the conv
 _NO_CONVSTATS = bool(_os.environ.get('GN_NO_CONVSTATS'))  # A/B switch: separate BatchNorm statistics pass instead of the conv epilogue
 
@@ -132,6 +133,10 @@ class Conv1D(Layer):
     def can_fold_bn(self):
         return self.activation[0] == 'linear' and self.filters % 4 == 0 and self.filters > 4
 
+    def can_defer_dgrad(self, Cin):
+        """1 filter, stride 1: a BatchNormalization producer can form this layer's data gradient inside its own backward passes."""
+        return self.filters == 1 and self.stride == 1 and self.k <= 8 and Cin % 4 == 0 and not _NO_LAZYGRAD
+
     def can_fold_upsample(self):
         """UpSampling1D(2) in front folds into the weights (ops.conv1d_up2_fold): the engine's planner asks."""
         return self.k == 5 and self.padding == 'same' and self.stride in (1, 2) and not _NO_UPFOLD
@@ -194,6 +199,10 @@ class Conv1D(Layer):
                 ctx.pre_applied.add(node.fuse_prev)
             else:
                 prev = None
+            if getattr(node, 'lazy_bn', -1) >= 0:
+                # 1 filter, stride 1, and the input comes straight from a BatchNormalization: that layer's backward passes form this
+                # data gradient on the fly (ops.ConvGrad1); the (B, L, Cin) tensor is neither written here nor read there
+                return ops.ConvGrad1(dy, self.kernel.data, x.shape[1], pl)
             if wf is None:
                 return ops.conv1d_dgrad(dy, ops.conv1d_transpose_w(self.kernel.data), x.shape[1], self.stride, pl, prev)
             return ops.conv1d_dgrad(dy, ops.conv1d_transpose_w(wf), x.shape[1], 1, pl, prev)
@@ -350,8 +359,12 @@ class BatchNormalization(Layer):
         y = None
         if x2.shape[1] % 4:            # the scalar fallback kernels read the stored output; not reached by the BBH nets
             raise NotImplementedError('BatchNormalization backward over %d channels (not a multiple of 4)' % x2.shape[1])
-        dy2 = dy.contiguous().reshape(x2.shape)
-        local = ops.bn_bwd_stats(dy2, y, x2, mask, smean, sinv, act[0], act[1], rate, scale, shift)
+        lazy = isinstance(dy, ops.ConvGrad1)
+        if lazy:
+            local = ops.bn_bwd_stats_conv1(dy, x2, mask, smean, sinv, act[0], act[1], rate, scale, shift)
+        else:
+            dy2 = dy.contiguous().reshape(x2.shape)
+            local = ops.bn_bwd_stats(dy2, y, x2, mask, smean, sinv, act[0], act[1], rate, scale, shift)
         glob = local
         if ctx.dp is not None:
             glob = local.clone()
@@ -360,7 +373,10 @@ class BatchNormalization(Layer):
             dgamma, dbeta = self.gamma.grad, self.beta.grad
         else:
             dgamma = torch.empty_like(self.gamma.data); dbeta = torch.empty_like(self.beta.data)
-        dx = ops.bn_bwd_apply(dy2, y, x2, mask, self.gamma.data, smean, sinv, glob, count, local, dgamma, dbeta, act[0], act[1], rate, scale, shift)
+        if lazy:
+            dx = ops.bn_bwd_apply_conv1(dy, x2, mask, self.gamma.data, smean, sinv, glob, count, local, dgamma, dbeta, act[0], act[1], rate, scale, shift)
+        else:
+            dx = ops.bn_bwd_apply(dy2, y, x2, mask, self.gamma.data, smean, sinv, glob, count, local, dgamma, dbeta, act[0], act[1], rate, scale, shift)
         return dx.reshape(dy.shape)
 
 

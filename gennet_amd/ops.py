@@ -470,6 +470,38 @@ def bn_bwd_apply(dy2d, y2d, x2d, mask, gamma, smean, sinv, dsums_global, count, 
     return dx
 
 
+class ConvGrad1(object):
+    """The data gradient of a Conv1D(1 filter, k taps, stride 1), NOT materialised: g (B, Lout, 1) the conv's output gradient, w (k, C, 1)
+    its kernel, L the conv's input length.  Consumed by bn_bwd_stats_conv1 / bn_bwd_apply_conv1 (gn_bn_bwd_*_conv1)."""
+
+    def __init__(self, g, w, L, pad_left):
+        _chk(g, w)
+        self.g, self.w, self.L, self.pad_left = g, w, int(L), int(pad_left)
+        self.B, self.Lout = int(g.shape[0]), int(g.shape[1])
+        self.k, self.C = int(w.shape[0]), int(w.shape[1])
+        self.shape = (self.B, self.L, self.C)
+
+
+def bn_bwd_stats_conv1(cg, x2d, mask, smean, sinv, act, act_param, rate, scale, shift):
+    _chk(x2d, mask)
+    rows, Cc = x2d.shape
+    assert rows == cg.B * cg.L and Cc == cg.C
+    dsums = torch.empty((2 * Cc,), dtype=torch.float64, device=x2d.device)
+    ws = workspace(_lib.size('gn_bn_stats_workspace', rows, Cc), x2d.device)
+    _lib.call('gn_bn_bwd_stats_conv1', _p(cg.g), _p(cg.w), cg.L, cg.Lout, cg.k, cg.pad_left, _p(x2d), _p(mask), _p(smean), _p(sinv), _p(dsums), _p(ws),
+              ws.numel(), rows, Cc, ACT[act], float(act_param), float(rate), _p(scale), _p(shift), _stream())
+    return dsums
+
+
+def bn_bwd_apply_conv1(cg, x2d, mask, gamma, smean, sinv, dsums_global, count, dsums_local, dgamma, dbeta, act, act_param, rate, scale, shift):
+    rows, Cc = x2d.shape
+    dx = torch.empty_like(x2d)
+    _lib.call('gn_bn_bwd_apply_conv1', _p(cg.g), _p(cg.w), cg.L, cg.Lout, cg.k, cg.pad_left, _p(x2d), _p(mask), _p(gamma), _p(smean), _p(sinv),
+              _p(dsums_global), float(count), _p(dsums_local), _p(dx), _p(dgamma), _p(dbeta), rows, Cc, ACT[act], float(act_param), float(rate),
+              _p(scale), _p(shift), _stream())
+    return dx
+
+
 # ---------------------------------------------------------------------------------------------- loss / optimizer
 def loss(kind, p, y, Bglobal=None):
     """kind 'binary_crossentropy' | 'mean_squared_error'. p, y (B,1). Returns (dp, out[2] = [loss share, hit count])."""

@@ -214,6 +214,22 @@ int gn_bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8
                     const double* dsums_global, double count, const double* dsums_local, float* dx, float* dgamma, float* dbeta,
                     size_t rows, int C, int act, float act_param, float rate, const float* scale, const float* shift, void* stream);
 
+/* BatchNormalization backward when the layer's output feeds ONLY a Conv1D(1 filter, k <= 8 taps, stride 1) -- the generator's last
+ * BatchNormalization -> tanh -> Dropout -> Conv1D(1, 5, padding='same') (bbhMahoGANy.py:284-292).  The gradient arriving at the BN
+ * output is then that conv's data gradient  dz[b,t,c] = sum_j g[b, t - j + pad_left] * w[j,c]  (g (B, Lout): the conv's output
+ * gradient, w (k, C): its kernel; terms with t - j + pad_left outside [0, Lout) are zero), rank-k in (t, c).  These two calls take
+ * (g, w, L, Lout, k, pad_left) in place of dy and form dz where it is consumed, so gn_conv1d_dgrad never writes the (B, L, C) tensor
+ * and the two passes never read it (12 bytes per element less: 4.3 GB x 3 per generator step at the BASELINE size).  rows = B * L.
+ * Same results as gn_bn_bwd_stats / gn_bn_bwd_apply on the materialised dz up to the rounding of the k-term sum.
+ * Needs C % 4 == 0 and scale / shift (the activation output is recomputed from x). */
+int gn_bn_bwd_stats_conv1(const float* g, const float* w, int L, int Lout, int k, int pad_left, const float* x, const uint8_t* mask,
+                          const float* save_mean, const float* save_invstd, double* dsums, void* ws, size_t ws_bytes, size_t rows, int C,
+                          int act, float act_param, float rate, const float* scale, const float* shift, void* stream);
+int gn_bn_bwd_apply_conv1(const float* g, const float* w, int L, int Lout, int k, int pad_left, const float* x, const uint8_t* mask,
+                          const float* gamma, const float* save_mean, const float* save_invstd, const double* dsums_global, double count,
+                          const double* dsums_local, float* dx, float* dgamma, float* dbeta, size_t rows, int C, int act, float act_param,
+                          float rate, const float* scale, const float* shift, void* stream);
+
 /* ---- losses + metric (compile(loss='binary_crossentropy'|'mean_squared_error', metrics=['accuracy']),
  *      bbhMahoGANy.py:1101-1119) ---------------------------------------------------------------------------
  * p, y: (B, 1).  out[0] = loss (mean over the local B rows scaled by B/Bglobal), out[1] = #rows with round(p)==y;

@@ -281,6 +281,46 @@ def test_batchnorm_train_fwd_bwd(shape, with_drop):
     close(dx2, dx_ref.reshape(rows, Cc), 1e-4)
 
 
+@pytest.mark.parametrize("B,L,Cc,k,padding", [(3, 40, 64, 5, 'same'), (2, 33, 1024, 5, 'same'), (4, 21, 16, 3, 'valid'), (2, 7, 8, 5, 'same')])
+def test_batchnorm_backward_with_the_1_filter_conv_gradient_formed_on_the_fly(B, L, Cc, k, padding):
+    """gn_bn_bwd_stats_conv1 / gn_bn_bwd_apply_conv1: BatchNormalization -> tanh -> Dropout -> Conv1D(1, k) (bbhMahoGANy.py:284-292) with the
+    conv's data gradient formed inside the BN backward passes, against the oracle chain on the materialised gradient."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(L + Cc)
+    x = f32(rng.randn(B, L, Cc) * 1.5 + 0.3); gamma = f32(rng.rand(Cc) + 0.5); beta = f32(rng.randn(Cc) * 0.1)
+    rate = 0.2
+    mask = (rng.rand(B, L, Cc) >= rate).astype(np.uint8)
+    w = f32(rng.randn(k, Cc, 1) * 0.2)
+    y_bn, cache, mean, var = K.bn_train_fwd(x, gamma, beta)
+    y_act = np.tanh(y_bn)
+    y = K.dropout_fwd(y_act, mask, rate)
+    z = K.conv1d_fwd(y, w, np.zeros(1), 1, padding)
+    gz = f32(rng.randn(*z.shape))
+    dz_ref, _, _ = K.conv1d_bwd(y, w, gz, 1, padding)
+    d_bn = K.act_bwd(dz_ref * mask / (1 - rate), y_act, 'tanh')
+    dx_ref, dg_ref, db_ref = K.bn_train_bwd(d_bn, cache, gamma)
+
+    rows = B * L
+    x2 = g(x).reshape(rows, Cc)
+    sums = ops.bn_stats(x2)
+    mm, mv = g(np.zeros(Cc)), g(np.ones(Cc))
+    scale, shift, smean, sinv = ops.bn_finalize(sums, rows, g(gamma), g(beta), K.BN_EPS, 0.99, mm, mv)
+    mt = torch.tensor(mask.reshape(rows, Cc), device=dev())
+    Lout, pl = ops.conv_geometry(L, k, 1, padding)
+    cg = ops.ConvGrad1(g(gz), g(w), L, pl)
+    assert cg.shape == (B, L, Cc) and cg.Lout == Lout
+    dsums = ops.bn_bwd_stats_conv1(cg, x2, mt, smean, sinv, 'tanh', 0.0, rate, scale, shift)
+    dgamma = torch.empty(Cc, device=dev()); dbeta = torch.empty(Cc, device=dev())
+    dx = ops.bn_bwd_apply_conv1(cg, x2, mt, g(gamma), smean, sinv, dsums, rows, dsums, dgamma, dbeta, 'tanh', 0.0, rate, scale, shift)
+    close(dgamma, dg_ref, 1e-4); close(dbeta, db_ref, 1e-4)
+    close(dx, dx_ref.reshape(rows, Cc), 1e-4)
+    # and against the same kernels fed the materialised gradient
+    dz = ops.conv1d_dgrad(g(gz), ops.conv1d_transpose_w(g(w)), L, 1, pl).reshape(rows, Cc)
+    close(dz, dz_ref.reshape(rows, Cc), 5e-5)
+    dsums_m = ops.bn_bwd_stats(dz, None, x2, mt, smean, sinv, 'tanh', 0.0, rate, scale, shift)
+    close(dsums, dsums_m.cpu().numpy(), 1e-5, 1e-6)
+
+
 def test_batchnorm_infer():
     from gennet_amd import ops
     rng = np.random.RandomState(9)

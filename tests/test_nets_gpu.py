@@ -291,6 +291,42 @@ def test_folded_upsample_trains_like_the_materialised_one(stride, monkeypatch):
         assert rel(a, b) < 1e-4
 
 
+def test_deferred_output_conv_gradient_trains_like_the_materialised_one(monkeypatch):
+    """The planner's deferral of the 1-filter output conv's data gradient into the BatchNormalization backward (ops.ConvGrad1) against
+    the same graph with the gradient tensor written and read: losses and weights after two Adam steps."""
+    from gennet_amd import engine, layers
+    from gennet_amd.engine import Adam, Sequential
+    from gennet_amd.layers import Activation, BatchNormalization, Conv1D, Dense, Dropout, Flatten
+    rng = np.random.RandomState(17)
+    B, L = 4, 24
+    x = f32(rng.randn(B, L, 4)); y = f32(rng.randn(B))
+    mask = (rng.rand(B, L, 16) >= 0.2).astype(np.uint8)
+
+    def run(lazy):
+        monkeypatch.setattr(layers, '_NO_LAZYGRAD', not lazy)
+        engine.set_init_seed(4)
+        m = Sequential()
+        m.add(Conv1D(16, 5, padding='same', input_shape=(L, 4)))
+        m.add(BatchNormalization(momentum=0.99))
+        m.add(Activation('tanh'))
+        m.add(Dropout(0.2, name='drop_last'))
+        m.add(Conv1D(1, 5, padding='same'))
+        m.add(Activation('linear'))
+        m.add(Flatten())
+        m.add(Dense(1))
+        m.compile(loss='mean_squared_error', optimizer=Adam(lr=1e-2))
+        m._plan()
+        assert [n.lazy_bn >= 0 for n in m.nodes if isinstance(n.layer, Conv1D)] == [False, lazy]
+        losses = [m.train_on_batch(x, y, dropout_masks={'drop_last': mask}) for _ in range(2)]
+        return losses, m.get_weights()
+
+    la, wa = run(True)
+    lb, wb = run(False)
+    assert np.allclose(la, lb, rtol=1e-5)
+    for a, b in zip(wa, wb):
+        assert rel(a, b) < 1e-4
+
+
 def test_save_load_roundtrip(tmp_path):
     from gennet_amd import bbh
     from gennet_amd.engine import Adam, load_model
