@@ -549,7 +549,7 @@ int gn_bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8
 
 static int lazy_dy_check(const char* who, const float* g, const float* w, int L, int Lout, int k, int pad_left, size_t rows, int C, const float* scale,
                          const float* shift, LazyDy* z) {
-  GN_REQUIRE(g && w && L > 0 && Lout > 0 && k >= 1 && k <= 8 && pad_left >= 0, "%s: bad conv description (1 filter, 1..8 taps, stride 1)", who);
+  GN_REQUIRE(g && w && L > 0 && Lout > 0 && k >= 1 && k <= 5 && pad_left >= 0, "%s: bad conv description (1 filter, 1..5 taps, stride 1)", who);
   GN_REQUIRE(C % 4 == 0 && scale && shift, "%s: needs C %% 4 == 0 and the forward pass' scale / shift", who);
   GN_REQUIRE(rows % (size_t)L == 0 && rows / (size_t)L < 0x7fffffffull, "%s: rows %zu is not a whole number of length-%d segments", who, rows, L);
   z->g = g; z->w = w; z->L = L; z->Lout = Lout; z->k = k; z->pad_left = pad_left;

@@ -79,7 +79,7 @@ struct WgradSmallArgs {
   int rows_per_chunk;
 };
 
-// The gradient arriving at a BatchNormalization output when the layer feeds ONLY a Conv1D(1 filter, k <= 8 taps, stride 1): that conv's
+// The gradient arriving at a BatchNormalization output when the layer feeds ONLY a Conv1D(1 filter, k <= 5 taps, stride 1): that conv's
 // data gradient dz[b,t,c] = sum_j g[b, t - j + pad_left] * w[j,c], computed where it is consumed instead of written and re-read.
 struct LazyDy {
   const float* g;   // (B, Lout): the conv's output gradient (after its own activation backward); NULL = not lazy
@@ -187,12 +187,30 @@ static inline void allow_big_lds(const void* kernel, unsigned long long* done) {
 // ---------------------------------------------------------------------------------------------
 // activation epilogues (fwd on the pre-activation, bwd through the OUTPUT value)
 // ---------------------------------------------------------------------------------------------
+// tanh for every kernel of the library (forward epilogues, BN apply passes, and the backward passes that RECOMPUTE the activation from
+// the pre-BN tensor: all must agree bit for bit, so there is exactly one implementation).  |x| < 0.35: odd Taylor polynomial through
+// x^11 (next term 4e-9); else 1 - 2 / (exp(2|x|) + 1) on v_exp_f32 / v_rcp_f32.  Absolute error <= ~1e-7 (a few ulp at 0.35, less
+// elsewhere), NaN in -> NaN out, +-inf -> +-1.  libdevice's tanhf is ~4x the instructions and made the BN backward passes
+// arithmetic-bound (0.5-1.0 ms of 4.4-5.6 ms on the generator's largest layer).
+__device__ __forceinline__ float gn_tanhf(float x) {
+  const float ax = fabsf(x);
+  const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);          // exp(2|x|); +inf past |x| ~ 44 -> big = 1
+  const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+  const float x2 = ax * ax;
+  float q = fmaf(x2, -1382.f / 155925.f, 62.f / 2835.f);
+  q = fmaf(x2, q, -17.f / 315.f);
+  q = fmaf(x2, q, 2.f / 15.f);
+  q = fmaf(x2, q, -1.f / 3.f);
+  const float small = fmaf(ax * x2, q, ax);
+  return copysignf(ax < 0.35f ? small : big, x);
+}
+
 __device__ __forceinline__ float act_apply(float x, int act, float p) {
   switch (act) {
     case GN_ACT_RELU: return fmaxf(x, 0.f);
     case GN_ACT_RELU_MAX: return fminf(fmaxf(x, 0.f), p);
     case GN_ACT_LEAKY: return x > 0.f ? x : p * x;
-    case GN_ACT_TANH: return tanhf(x);
+    case GN_ACT_TANH: return gn_tanhf(x);
     case GN_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
     default: return x;
   }

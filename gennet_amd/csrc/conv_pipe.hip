@@ -124,7 +124,7 @@ __device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&
         float v = acc[mt][nt][r] + bias;
         if (ACT == GN_ACT_RELU) v = fmaxf(v, 0.f);
         else if (ACT == GN_ACT_LEAKY) v = v > 0.f ? v : a.act_param * v;
-        else if (ACT == GN_ACT_TANH) v = tanhf(v);
+        else if (ACT == GN_ACT_TANH) v = gn_tanhf(v);
         else if (ACT != GN_ACT_LINEAR) v = act_apply(v, a.act, a.act_param);         // rare kinds: runtime switch
         if (MODE == 1) {
           const unsigned k = __builtin_amdgcn_raw_buffer_load_b8(msrd, voff, soff, 0);

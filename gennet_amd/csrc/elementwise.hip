@@ -310,30 +310,65 @@ __device__ __forceinline__ float bn_bwd_g_act(float dy, float yact, uint8_t keep
   return dy * keep_scale * act_grad_from_y(yact, act, p);
 }
 
-// LazyDy (common.h): the 4 channels 4q..4q+3 of row r of the data gradient of a 1-filter stride-1 conv, from its output gradient
-// and kernel; wq holds the thread's kernel columns (taps past k are zero)
-__device__ __forceinline__ void lazy_dy_taps(const LazyDy& z, int C, int q, float wq[8][4]) {
+// LazyDy (common.h): the 4 channels 4q..4q+3 of one row of the data gradient of a 1-filter stride-1 conv with k <= 5 taps, from its
+// output gradient g and kernel; wq holds the thread's kernel columns (taps past k are zero).
+__device__ __forceinline__ void lazy_dy_taps(const LazyDy& z, int C, int q, float wq[5][4]) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < 5; ++j) {
     float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (j < z.k) w4 = *reinterpret_cast<const float4*>(z.w + (size_t)j * C + 4 * q);
     wq[j][0] = w4.x; wq[j][1] = w4.y; wq[j][2] = w4.z; wq[j][3] = w4.w;
   }
 }
-__device__ __forceinline__ void lazy_dy4(const LazyDy& z, size_t r, const float wq[8][4], float v[4]) {
-  const unsigned b = (unsigned)(r / (unsigned)z.L);
-  const int t = (int)(r - (size_t)b * z.L);
-  const float* gb = z.g + (size_t)b * z.Lout;
-  v[0] = v[1] = v[2] = v[3] = 0.f;
+// A wave's window on g: lane l holds g[b, base + l] (0 outside [0, Lout)).  With C / 4 lanes per row a multiple of 64 the row is the same
+// for all lanes of a wave, rows advance along the segment, and one 64-wide load serves ~60 / RL rows; the k values of a row come out
+// of it by v_readlane.  (k vector loads of one address per row cost the address path as much as the 16-byte row loads themselves
+// and doubled the kernels' time; scalar loads are not available next to the kernel's own global stores.)
+struct LazyWin {
+  float win;
+  int base;
+  unsigned b;
+};
+template <bool UNI>
+__device__ __forceinline__ void lazy_dy4(const LazyDy& z, unsigned b, int t, const float wq[5][4], float v[4], LazyWin& w) {
+  float gv[5];
+  if (UNI) {
+    b = __builtin_amdgcn_readfirstlane(b);
+    t = __builtin_amdgcn_readfirstlane(t);
+    const int uhi = t + z.pad_left, ulo = uhi - (z.k - 1);
+    if (b != w.b || ulo < w.base || uhi >= w.base + 64) {              // wave-uniform
+      w.b = b;
+      w.base = ulo;
+      const int idx = ulo + (int)(threadIdx.x & 63);
+      w.win = (idx >= 0 && idx < z.Lout) ? z.g[(size_t)b * z.Lout + idx] : 0.f;
+    }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (j < z.k) {
+    for (int j = 0; j < 5; ++j)
+      gv[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w.win), max(uhi - j - w.base, 0)));      // taps past k: weight 0
+  } else {
+    const float* gb = z.g + (size_t)b * z.Lout;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
       const int u = t - j + z.pad_left;
-      const float gv = (u >= 0 && u < z.Lout) ? gb[u] : 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaf(gv, wq[j][e], v[e]);
+      const int uc = min(max(u, 0), z.Lout - 1);
+      const float g = gb[uc];
+      gv[j] = (u == uc) ? g : 0.f;
     }
   }
+  v[0] = v[1] = v[2] = v[3] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaf(gv[j], wq[j][e], v[e]);
+}
+// (segment, position) of row r; the row loops then step both without dividing
+__device__ __forceinline__ void lazy_dy_pos(const LazyDy& z, size_t r, unsigned* b, int* t) {
+  *b = (unsigned)(r / (unsigned)z.L);
+  *t = (int)(r - (size_t)*b * z.L);
+}
+__device__ __forceinline__ void lazy_dy_step(const LazyDy& z, int step, unsigned* b, int* t) {
+  *t += step;
+  while (*t >= z.L) { *t -= z.L; ++*b; }
 }
 
 template <int MODE>
@@ -363,50 +398,73 @@ __global__ __launch_bounds__(256) void colred_kernel(ColRedArgs a) {
         sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
       }
     }
-    float wq[8][4];
+    float wq[5][4];
+    LazyWin lw = {0.f, 0, 0xffffffffu};
     const bool lazy = MODE == 2 && a.lz.g != nullptr;
-    if (lazy) lazy_dy_taps(a.lz, a.C, q, wq);
-    for (size_t r = r_lo + rl; r < r_hi; r += RL) {
-      const size_t o = r * a.C + 4 * q;
-      float v[4];
-      if (lazy) {
-        lazy_dy4(a.lz, r, wq, v);
-      } else {
-        const float4 v4 = *reinterpret_cast<const float4*>(a.a + o);
-        v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
+    unsigned lb = 0;
+    int lt = 0;
+    if (lazy) {
+      lazy_dy_taps(a.lz, a.C, q, wq);
+      lazy_dy_pos(a.lz, r_lo + rl, &lb, &lt);
+    }
+    // U rows per trip with all their loads issued before the first use.  Measured on the generator's largest BatchNormalization
+    // (1 M rows x 1024 channels): U = 4 is SLOWER than U = 1 (146 VGPRs, 3 waves per SIMD: 6.6 against 6.2 ms for the backward pair) --
+    // the pass is bound by its arithmetic (tanh recomputation, fp64 sums), not by load latency.
+    constexpr int U = 2;
+    for (size_t r = r_lo + rl; r < r_hi; r += (size_t)RL * U) {
+      float4 v4[U], x4[U], y4[U];
+      uchar4 m4[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t ru = r + (size_t)u * RL;
+        ok[u] = ru < r_hi;
+        const size_t o = (ok[u] ? ru : r) * a.C + 4 * q;
+        if (!lazy) v4[u] = *reinterpret_cast<const float4*>(a.a + o);
+        if (MODE == 2) {
+          x4[u] = *reinterpret_cast<const float4*>(a.xpre + o);
+          if (!a.scale) y4[u] = *reinterpret_cast<const float4*>(a.y + o);
+          m4[u] = a.mask ? *reinterpret_cast<const uchar4*>(a.mask + o) : make_uchar4(1, 1, 1, 1);
+        }
       }
-      if (MODE == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[0][e] += (double)v[e];
-      } else if (MODE == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s[0][e] += (double)v[e];
-          s[1][e] += (double)v[e] * (double)v[e];
-        }
-      } else {
-        const float4 x4 = *reinterpret_cast<const float4*>(a.xpre + o);
-        const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
-        float yv[4];
-        if (a.scale) {        // activation output recomputed from the pre-BN tensor: one 4-byte read per element less
-#pragma unroll
-          for (int e = 0; e < 4; ++e) yv[e] = act_apply(fmaf(xv[e], sc[e], sh[e]), a.act, a.act_param);
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) break;
+        float v[4];
+        if (lazy) {
+          if (((NQc | NQ) & 63) == 0) lazy_dy4<true>(a.lz, lb, lt, wq, v, lw);
+          else lazy_dy4<false>(a.lz, lb, lt, wq, v, lw);
+          lazy_dy_step(a.lz, RL, &lb, &lt);
         } else {
-          const float4 y4 = *reinterpret_cast<const float4*>(a.y + o);
-          yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
+          v[0] = v4[u].x; v[1] = v4[u].y; v[2] = v4[u].z; v[3] = v4[u].w;
         }
-        uint8_t k[4] = {1, 1, 1, 1};
-        if (a.mask) {
-          const uchar4 m = *reinterpret_cast<const uchar4*>(a.mask + o);
-          k[0] = m.x; k[1] = m.y; k[2] = m.z; k[3] = m.w;
-        }
+        if (MODE == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float g = a.scale ? bn_bwd_g_act(v[e], yv[e], k[e], a.act, a.act_param, a.keep_scale)
-                                  : bn_bwd_g(v[e], yv[e], k[e], a.act, a.act_param, a.keep_scale);
-          const float xh = (xv[e] - mu[e]) * is[e];
-          s[0][e] += (double)g;
-          s[NV - 1][e] += (double)g * (double)xh;
+          for (int e = 0; e < 4; ++e) s[0][e] += (double)v[e];
+        } else if (MODE == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s[0][e] += (double)v[e];
+            s[1][e] += (double)v[e] * (double)v[e];
+          }
+        } else {
+          const float xv[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};
+          float yv[4];
+          if (a.scale) {        // activation output recomputed from the pre-BN tensor: one 4-byte read per element less
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yv[e] = act_apply(fmaf(xv[e], sc[e], sh[e]), a.act, a.act_param);
+          } else {
+            yv[0] = y4[u].x; yv[1] = y4[u].y; yv[2] = y4[u].z; yv[3] = y4[u].w;
+          }
+          const uint8_t k[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float g = a.scale ? bn_bwd_g_act(v[e], yv[e], k[e], a.act, a.act_param, a.keep_scale)
+                                    : bn_bwd_g(v[e], yv[e], k[e], a.act, a.act_param, a.keep_scale);
+            const float xh = (xv[e] - mu[e]) * is[e];
+            s[0][e] += (double)g;
+            s[NV - 1][e] += (double)g * (double)xh;
+          }
         }
       }
     }
@@ -624,38 +682,56 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
     mg[e] = (float)(dsums[c] / count); mgx[e] = (float)(dsums[C + c] / count);
     if (scale) { sc[e] = scale[c]; sh[e] = shift[c]; }
   }
-  float wq[8][4];
-  if (lz.g) lazy_dy_taps(lz, C, q, wq);
-  for (size_t r = r_lo + rl; r < r_hi; r += RL) {
-    const size_t o = r * C + 4 * q;
-    const float4 x4 = *reinterpret_cast<const float4*>(x + o);
-    const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
-    float dv[4];
-    if (lz.g) {
-      lazy_dy4(lz, r, wq, dv);
-    } else {
-      const float4 d4 = *reinterpret_cast<const float4*>(dy + o);
-      dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
-    }
-    float yv[4] = {0, 0, 0, 0};
-    if (!scale) {
-      const float4 y4 = *reinterpret_cast<const float4*>(y + o);
-      yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
-    }
-    uint8_t k[4] = {1, 1, 1, 1};
-    if (mask) {
-      const uchar4 m = *reinterpret_cast<const uchar4*>(mask + o);
-      k[0] = m.x; k[1] = m.y; k[2] = m.z; k[3] = m.w;
-    }
-    float ov[4];
+  float wq[5][4];
+  LazyWin lw = {0.f, 0, 0xffffffffu};
+  unsigned lb = 0;
+  int lt = 0;
+  if (lz.g) {
+    lazy_dy_taps(lz, C, q, wq);
+    lazy_dy_pos(lz, r_lo + rl, &lb, &lt);
+  }
+  constexpr int U = 2;                                   // rows per trip, loads first (see colred_kernel: more is slower)
+  const bool uni = ((NQc | NQ) & 63) == 0;
+  for (size_t r = r_lo + rl; r < r_hi; r += (size_t)RL * U) {
+    float4 d4[U], x4[U], y4[U];
+    uchar4 m4[U];
+    bool ok[U];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float g = scale ? bn_bwd_g_act(dv[e], act_apply(fmaf(xv[e], sc[e], sh[e]), act, p), k[e], act, p, keep_scale)
-                            : bn_bwd_g(dv[e], yv[e], k[e], act, p, keep_scale);
-      const float xh = (xv[e] - mu[e]) * is[e];
-      ov[e] = gi[e] * (g - mg[e] - xh * mgx[e]);
+    for (int u = 0; u < U; ++u) {
+      const size_t ru = r + (size_t)u * RL;
+      ok[u] = ru < r_hi;
+      const size_t o = (ok[u] ? ru : r) * C + 4 * q;
+      x4[u] = *reinterpret_cast<const float4*>(x + o);
+      if (!lz.g) d4[u] = *reinterpret_cast<const float4*>(dy + o);
+      if (!scale) y4[u] = *reinterpret_cast<const float4*>(y + o);
+      m4[u] = mask ? *reinterpret_cast<const uchar4*>(mask + o) : make_uchar4(1, 1, 1, 1);
     }
-    *reinterpret_cast<float4*>(dx + o) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) break;
+      const size_t o = (r + (size_t)u * RL) * C + 4 * q;
+      const float xv[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};
+      float dv[4];
+      if (lz.g) {
+        if (uni) lazy_dy4<true>(lz, lb, lt, wq, dv, lw);
+        else lazy_dy4<false>(lz, lb, lt, wq, dv, lw);
+        lazy_dy_step(lz, RL, &lb, &lt);
+      } else {
+        dv[0] = d4[u].x; dv[1] = d4[u].y; dv[2] = d4[u].z; dv[3] = d4[u].w;
+      }
+      float yv[4] = {0, 0, 0, 0};
+      if (!scale) { yv[0] = y4[u].x; yv[1] = y4[u].y; yv[2] = y4[u].z; yv[3] = y4[u].w; }
+      const uint8_t k[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w};
+      float ov[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g = scale ? bn_bwd_g_act(dv[e], act_apply(fmaf(xv[e], sc[e], sh[e]), act, p), k[e], act, p, keep_scale)
+                              : bn_bwd_g(dv[e], yv[e], k[e], act, p, keep_scale);
+        const float xh = (xv[e] - mu[e]) * is[e];
+        ov[e] = gi[e] * (g - mg[e] - xh * mgx[e]);
+      }
+      *reinterpret_cast<float4*>(dx + o) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
   }
 }
 __global__ void bn_param_grads_kernel(const double* __restrict__ dsums_local, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {

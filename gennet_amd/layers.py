@@ -135,7 +135,7 @@ class Conv1D(Layer):
 
     def can_defer_dgrad(self, Cin):
         """1 filter, stride 1: a BatchNormalization producer can form this layer's data gradient inside its own backward passes."""
-        return self.filters == 1 and self.stride == 1 and self.k <= 8 and Cin % 4 == 0 and not _NO_LAZYGRAD
+        return self.filters == 1 and self.stride == 1 and self.k <= 5 and Cin % 4 == 0 and not _NO_LAZYGRAD
 
     def can_fold_upsample(self):
         """UpSampling1D(2) in front folds into the weights (ops.conv1d_up2_fold): the engine's planner asks."""

@@ -214,7 +214,7 @@ int gn_bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8
                     const double* dsums_global, double count, const double* dsums_local, float* dx, float* dgamma, float* dbeta,
                     size_t rows, int C, int act, float act_param, float rate, const float* scale, const float* shift, void* stream);
 
-/* BatchNormalization backward when the layer's output feeds ONLY a Conv1D(1 filter, k <= 8 taps, stride 1) -- the generator's last
+/* BatchNormalization backward when the layer's output feeds ONLY a Conv1D(1 filter, k <= 5 taps, stride 1) -- the generator's last
  * BatchNormalization -> tanh -> Dropout -> Conv1D(1, 5, padding='same') (bbhMahoGANy.py:284-292).  The gradient arriving at the BN
  * output is then that conv's data gradient  dz[b,t,c] = sum_j g[b, t - j + pad_left] * w[j,c]  (g (B, Lout): the conv's output
  * gradient, w (k, C): its kernel; terms with t - j + pad_left outside [0, Lout) are zero), rank-k in (t, c).  These two calls take

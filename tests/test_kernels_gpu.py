@@ -208,6 +208,22 @@ def test_activations(act, p):
     close(ops.act_bwd(g(dy), y, act, p), K.act_bwd(dy, y.cpu().numpy().astype(np.float64), act, p), 1e-6)
 
 
+def test_tanh_absolute_error_over_the_whole_range():
+    """The library's one tanh (gn_tanhf, common.h): absolute error <= 2e-7 from 1e-8 to saturation, through the switch point at 0.35,
+    odd symmetry exact, +-inf -> +-1, NaN -> NaN, tiny arguments returned unchanged."""
+    from gennet_amd import ops
+    x = np.concatenate([np.linspace(-12, 12, 200001), np.linspace(0.34, 0.36, 20001), np.logspace(-8, -1, 5001), [0.0, 50.0, 100.0, 1e30]]).astype(np.float32)
+    y = ops.act_fwd(g(x), 'tanh', 0.0).cpu().numpy().astype(np.float64)
+    ref = np.tanh(x.astype(np.float64))
+    assert np.abs(y - ref).max() <= 2e-7
+    small = np.abs(x) < 1e-3
+    assert (np.abs(y[small] - ref[small]) <= 1.2e-7 * np.abs(ref[small])).all()          # relative, where absolute says nothing
+    ym = ops.act_fwd(g(-x), 'tanh', 0.0).cpu().numpy().astype(np.float64)
+    assert np.array_equal(ym, -y)
+    sp = ops.act_fwd(g(np.array([np.inf, -np.inf, np.nan], np.float32)), 'tanh', 0.0).cpu().numpy()
+    assert sp[0] == 1.0 and sp[1] == -1.0 and np.isnan(sp[2])
+
+
 def test_dropout_mask_and_apply():
     from gennet_amd import ops
     n = 1 << 20
