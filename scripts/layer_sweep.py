@@ -17,8 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # (name, B, L, Cin, Cout, k, stride, padding, launches of fwd / dgrad / wgrad per bench step)
 # G runs forward 3x per GAN iteration (predict, and inside the G step; the D step uses the predicted batch), backward once.
 LAYERS = [
-    ('G  conv 256->64 s2 (after Up2)', 512, 2048, 256, 64, 5, 2, 'same', 2, 1, 1),
-    ('G  conv 64->128', 512, 2048, 64, 128, 5, 1, 'same', 2, 1, 1),
+    # the two UpSampling1D -> Conv1D pairs run folded: 3 taps, stride 1, on the un-upsampled tensor (gn_conv1d_up2_fold)
+    ('G  Up2+conv 256->64 s2 (3-tap fold)', 512, 1024, 256, 64, 3, 1, 'same', 2, 1, 1),
+    ('G  Up2+conv 64->128 (3-tap, 2 phases)', 512, 1024, 64, 256, 3, 1, 'same', 2, 1, 1),
     ('G  conv 128->256', 512, 2048, 128, 256, 5, 1, 'same', 2, 1, 1),
     ('G  conv 256->512', 512, 2048, 256, 512, 5, 1, 'same', 2, 1, 1),
     ('G  conv 512->1024', 512, 2048, 512, 1024, 5, 1, 'same', 2, 1, 1),
@@ -64,9 +65,9 @@ def main():
             rows.append((name, what, ms, flop / ms / 1e9, count))
         del x, w, dy, wt
     total = sum(ms * c for _, _, ms, _, c in rows)
-    print('%-36s %-6s %9s %9s %7s %7s' % ('layer', 'pass', 'ms', 'TFLOP/s', 'x/step', 'share'))
+    print('%-40s %-6s %9s %9s %7s %7s' % ('layer', 'pass', 'ms', 'TFLOP/s', 'x/step', 'share'))
     for name, what, ms, tf, c in rows:
-        print('%-36s %-6s %9.3f %9.1f %7d %6.1f%%' % (name, what, ms, tf, c, 100.0 * ms * c / total), flush=True)
+        print('%-40s %-6s %9.3f %9.1f %7d %6.1f%%' % (name, what, ms, tf, c, 100.0 * ms * c / total), flush=True)
     print('sum of MFMA conv time per bench step: %.1f ms' % total)
 
 
