@@ -89,6 +89,7 @@ def masks_by_name(stack, masks, layers):
 
 
 @pytest.mark.parametrize("n_pix,B,steps", [(128, 6, 3), (256, 5, 3),
+                                          (1024, 4, 2),        # the reference script's own default n_pix (bbhMahoGANy.py:84)
                                           (2048, 4, 2),        # BASELINE configs 1-4 size: the 64 000- and 519 168-input Dense heads, 2048-row convs
                                           (4096, 2, 1)])       # BASELINE config 5 size (129 536- and 1 043 456-input heads)
 def test_pe_train_on_batch_matches_oracle(n_pix, B, steps):
@@ -152,6 +153,8 @@ def _build_gan(n_pix, rng):
 
 
 @pytest.mark.parametrize("n_pix,B,iters", [(64, 4, 2),
+                                          (1024, 3, 1),        # the reference script's own default n_pix; odd batch
+                                          (4096, 2, 1),        # BASELINE config 5 size: Dense(100 -> 524 288), 4096-row convs, 1 048 576-input head
                                           (2048, 4, 1)])       # BASELINE size: Dense(100 -> 262 144) + feature-BN over B, the 524 288-input head,
                                                                # channel-BN over 2048*B rows, fused dgrad epilogues, fold_bn predict inside the graph
 def test_gan_iteration_matches_oracle(n_pix, B, iters):
