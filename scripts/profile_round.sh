@@ -13,6 +13,9 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TA
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_pmc_write.log 2>&1
 python scripts/pmc_traffic.py gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write gpurun_out/${TAG}_pmc_traffic.json > gpurun_out/${TAG}_pmc_summary.log 2>&1
 find gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write -name "*counter_collection.csv" -delete
+rocprofv3 --kernel-trace --pmc MfmaUtil GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${TAG}_pmc_mfma -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_pmc_mfma.log 2>&1
+python scripts/pmc_mfma_util.py gpurun_out/${TAG}_pmc_mfma gpurun_out/${TAG}_pmc_mfma_util.json > gpurun_out/${TAG}_pmc_mfma_summary.log 2>&1
+find gpurun_out/${TAG}_pmc_mfma -name "*.csv" -delete
 find gpurun_out/${TAG}_prof -name "*kernel_trace.csv" -delete
 cp gpurun_out/${TAG}_prof/*/*kernel_stats.csv gpurun_out/${TAG}_bench_kernel_stats.csv
 echo profiled
