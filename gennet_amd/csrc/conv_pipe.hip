@@ -151,10 +151,10 @@ __device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&
   }
 }
 
-template <int WAVES_M, int WAVES_N, int NTAPS, int IS>
+template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_pipe_kernel(ConvArgs a, int m_tiles, int n_tiles, int patch) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int WM = 2, WN = 2, KC = 8;
+  constexpr int WM = 2, WN = 2;
   constexpr int TM = WAVES_M * WM * 32;
   constexpr int TN = WAVES_N * WN * 32;
   constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -338,16 +338,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_pipe_kern
 #endif
 }
 
-template <int WAVES_M, int WAVES_N, int NTAPS, int IS>
+template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8>
 static int launch_conv_pipe(const ConvArgs& a, hipStream_t s) {
-  constexpr int KC = 8, TM = WAVES_M * 64, TN = WAVES_N * 64;
+  constexpr int TM = WAVES_M * 64, TN = WAVES_N * 64;
   constexpr int R = IS * (TM - 1) + NTAPS, RPER = (R + IS - 1) / IS;
   constexpr size_t lds = 2 * sizeof(float) * ((size_t)IS * RPER * KC + (size_t)NTAPS * KC * TN);
   static_assert(lds <= 160 * 1024, "stage too large");
   static_assert(lds / 2 + (NTAPS * KC + 8) * TN * 4 < 65536, "ds_read offsets must fit 16 bits");
   if (lds > 64 * 1024) {
     static unsigned long long lds_done = 0;
-    allow_big_lds((const void*)conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS>, &lds_done);
+    allow_big_lds((const void*)conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS, KC>, &lds_done);
   }
   const int m_tiles = (a.M + TM - 1) / TM, n_tiles = a.Cout / TN;
   const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
@@ -363,7 +363,7 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t s) {
     if (!no_patch && pn >= 0 && ng <= 8 && (ng & (ng - 1)) == 0) patch = __builtin_ctz(ng) | (pn << 8);
   }
   prof_begin(s);
-  hipLaunchKernelGGL((conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles,
+  hipLaunchKernelGGL((conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS, KC>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles,
                      patch);
   prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0, 4.0 * ((double)a.B * a.Lin * a.Cin + (double)a.t.ntaps * a.Cin * a.Cout + (double)a.B * a.M * a.Cout));
   int rc = check_launch("conv_mfma_pipe");
@@ -394,6 +394,8 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
   }
 #define GN_PIPE(NT_, IS_) return tall ? launch_conv_pipe<4, 1, NT_, IS_>(a, s) : launch_conv_pipe<2, 2, NT_, IS_>(a, s)
   if (a.t.in_stride == 2) { GN_PIPE(5, 2); }
+  // (16-channel chunks for the 2- / 3-tap square tile -- twice the MFMAs per barrier, 49 / 66 KiB of LDS -- were measured on the
+  // stride-2 data gradient: 140.7 -> 139.3 / 136.9 TFLOP/s; the lost block per CU costs more than the barriers. KC stays 8.)
   switch (nt) {
     case 2: GN_PIPE(2, 1);
     case 3: GN_PIPE(3, 1);
