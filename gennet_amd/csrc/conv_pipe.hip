@@ -393,6 +393,8 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
     return conv_pipe_try(a2, tall, s, launched);
   }
 #define GN_PIPE(NT_, IS_) return tall ? launch_conv_pipe<4, 1, NT_, IS_>(a, s) : launch_conv_pipe<2, 2, NT_, IS_>(a, s)
+  // (4-channel chunks for the stride-2 forward -- 27 instead of 53 KiB of LDS, a fourth block per CU, but a barrier per 40 MFMAs -- were
+  // measured: 140.3 -> 135.5 TFLOP/s.  Eight channels per chunk is the optimum in both directions.)
   if (a.t.in_stride == 2) { GN_PIPE(5, 2); }
   // (16-channel chunks for the 2- / 3-tap square tile -- twice the MFMAs per barrier, 49 / 66 KiB of LDS -- were measured on the
   // stride-2 data gradient: 140.7 -> 139.3 / 136.9 TFLOP/s; the lost block per CU costs more than the barriers. KC stays 8.)
