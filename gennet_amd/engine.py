@@ -843,12 +843,14 @@ class Model(Layer):
         (print_fn or print)(s)
 
     # -- persistence: Keras' HDF5 layout through gennet_amd/keras_io.py + h5lite.py (bbhMahoGANy.py:1135-1142, :1171-1173, :1372-1375)
-    def save_weights(self, filepath, overwrite=True):
+    def save_weights(self, filepath, overwrite=True, writer=None):
+        """`writer` (a hostio.BackgroundWriter, not a keras argument): the weights are copied to the host now, the file is written by the
+        writer's thread."""
         import os
         from . import keras_io
         if os.path.exists(filepath) and not overwrite:
             raise IOError('%s exists' % filepath)
-        keras_io.save_weights(self, filepath)
+        keras_io.save_weights(self, filepath, writer)
 
     def load_weights(self, filepath, by_name=False):
         from . import keras_io
@@ -856,12 +858,12 @@ class Model(Layer):
             raise NotImplementedError('load_weights(by_name=True)')
         keras_io.load_weights(self, filepath)      # raises h5lite.H5Error on anything that is not an HDF5 file (never unpickles)
 
-    def save(self, filepath, overwrite=True, include_optimizer=True):
+    def save(self, filepath, overwrite=True, include_optimizer=True, writer=None):
         import os
         from . import keras_io
         if os.path.exists(filepath) and not overwrite:
             raise IOError('%s exists' % filepath)
-        keras_io.save_model(self, filepath, include_optimizer)
+        keras_io.save_model(self, filepath, include_optimizer, writer)
 
     def get_config(self):
         from . import keras_io

@@ -382,11 +382,19 @@ def load_private_state(f, model):
             l.zero_debias[site] = [to_device(sg['biased_mean'].value), to_device(sg['biased_var'].value), int(np.asarray(sg['local_step'].value).reshape(-1)[0])]
 
 
-def save_weights(model, path):
+def _write(w, path, writer):
+    """The tree `w` holds host copies only: with a hostio.BackgroundWriter the serialisation + file write leaves the caller's thread."""
+    if writer is None:
+        w.save(path)
+    else:
+        writer.submit(w.save, path)
+
+
+def save_weights(model, path, writer=None):
     w = h5lite.Writer()
     save_weights_to_group(w.root, top_layers(model))
     save_private_state(w.root, model)
-    w.save(path)
+    _write(w, path, writer)
 
 
 def load_weights(model, path):
@@ -402,7 +410,7 @@ def _loss_json(loss):
     return loss if isinstance(loss, str) else getattr(loss, '__name__', str(loss))
 
 
-def save_model(model, path, include_optimizer=True):
+def save_model(model, path, include_optimizer=True, writer=None):
     w = h5lite.Writer()
     w.root.attrs['keras_version'] = KERAS_VERSION.encode('utf-8')
     w.root.attrs['backend'] = BACKEND.encode('utf-8')
@@ -428,7 +436,7 @@ def save_model(model, path, include_optimizer=True):
                     k += 1
             og.attrs['weight_names'] = np.array([n.encode('utf-8') for n in names], dtype='S')
     save_private_state(w.root, model)
-    w.save(path)
+    _write(w, path, writer)
 
 
 def load_model(path, custom_objects=None, compile=True):

@@ -36,7 +36,7 @@ def main():
     ap.add_argument('--out', default='.')
     args = ap.parse_args()
 
-    from gennet_amd import bbh, dist, engine, templates as T
+    from gennet_amd import bbh, dist, engine, hostio, templates as T
     dp = dist.init()
     rank, world = (dp.rank, dp.world_size) if dp else (0, 1)
     engine.set_init_seed(1)
@@ -58,10 +58,11 @@ def main():
     os.makedirs(os.path.join(args.out, 'best_models'), exist_ok=True)
     os.makedirs(os.path.join(args.out, 'GAN_posterior_samples'), exist_ok=True)
 
+    bg = hostio.BackgroundWriter()             # serialisation + file writes of the cadence blocks leave the loop's thread
     for i in range(args.pe_iter):                                                     # :1153-1173
         pe_loss = bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch_size, rank=rank, world=world)
         if i % 5000 == 0 and i > 0 and rank == 0:
-            nets.signal_pe.save(os.path.join(args.out, 'best_models/signal_pe.h5'), True)
+            nets.signal_pe.save(os.path.join(args.out, 'best_models/signal_pe.h5'), True, writer=bg)
         if i % 1000 == 0 and rank == 0:
             print('%d: [PE loss: %f, acc: %f]' % (i, pe_loss[0], pe_loss[1]), flush=True)
     print('Completed CNN PE')
@@ -71,15 +72,13 @@ def main():
         if i % args.cadence == 0 and i > 0 and rank == 0:
             print('%d: [sD loss: %f, acc: %f]  [sG loss: %f, acc: %f]' % (i, l[2], l[3], l[0], l[1]), flush=True)
             pe_samples, waves = bbh.posterior_samples(nets, 4000)                     # :1330-1343
-            with open(os.path.join(args.out, 'gan_pe_samples.sav'), 'wb') as f:
-                pickle.dump(pe_samples, f, protocol=2)
-            with open(os.path.join(args.out, 'gan_pe_waveforms.sav'), 'wb') as f:
-                pickle.dump(waves, f, protocol=2)
-            nets.generator.save_weights(os.path.join(args.out, 'generator.h5'), True)
-            nets.signal_discriminator.save_weights(os.path.join(args.out, 'discriminator.h5'), True)
-            nets.signal_discriminator_on_generator.save_weights(os.path.join(args.out, 'signal_dis_on_gen.h5'), True)
-            with open(os.path.join(args.out, 'GAN_posterior_samples/posterior_samples_%05d.sav' % i), 'wb') as f:
-                pickle.dump(pe_samples, f)
+            bg.pickle(pe_samples, os.path.join(args.out, 'gan_pe_samples.sav'), protocol=2)
+            bg.pickle(waves, os.path.join(args.out, 'gan_pe_waveforms.sav'), protocol=2)
+            nets.generator.save_weights(os.path.join(args.out, 'generator.h5'), True, writer=bg)
+            nets.signal_discriminator.save_weights(os.path.join(args.out, 'discriminator.h5'), True, writer=bg)
+            nets.signal_discriminator_on_generator.save_weights(os.path.join(args.out, 'signal_dis_on_gen.h5'), True, writer=bg)
+            bg.pickle(pe_samples, os.path.join(args.out, 'GAN_posterior_samples/posterior_samples_%05d.sav' % i), protocol=pickle.DEFAULT_PROTOCOL)
+    bg.close()                                 # every file is on disk (or its error raised) before the script ends
 
 
 if __name__ == '__main__':

@@ -217,3 +217,48 @@ def test_ts_pars_file_layout_roundtrip(tmp_path):
     assert images.shape == (4, 64) and labels.shape == (4, 2) and np.array_equal(ev, ts[0][-1, 0])
     assert np.allclose(labels[:, 1], [27.0 / (33.0 + i) for i in range(4)])
     assert T.bbhparams.__module__ == 'gennet_amd.templates'
+
+
+def test_background_writer_orders_jobs_and_reports_errors(tmp_path):
+    """hostio.BackgroundWriter: jobs run in submission order on one thread, flush() waits, a failing job's exception
+    surfaces in the caller's thread at the next call, close() is idempotent and refuses later submissions."""
+    import pickle
+    import threading
+    import time
+    from gennet_amd import hostio
+    seen = []
+    gate = threading.Event()
+    with hostio.BackgroundWriter() as bg:
+        bg.submit(lambda: (gate.wait(5), seen.append('a')))
+        bg.submit(seen.append, 'b')
+        p = str(tmp_path / 'x.sav')
+        bg.pickle({'k': [1, 2, 3]}, p)
+        bg.pickle({'k': 'later'}, p)
+        assert seen == []                        # the caller is not blocked by the first job
+        gate.set()
+        bg.flush()
+        assert seen == ['a', 'b']
+        with open(p, 'rb') as f:
+            assert pickle.load(f) == {'k': 'later'}
+    with pytest.raises(RuntimeError):
+        bg.submit(seen.append, 'c')
+    bg.close()
+
+    bg = hostio.BackgroundWriter()
+    bg.pickle(1, str(tmp_path / 'no_such_dir' / 'y.sav'))
+    t0 = time.time()
+    with pytest.raises(IOError):
+        while time.time() - t0 < 5:
+            bg.submit(seen.append, 'd')
+            time.sleep(0.01)
+    bg.close()                                   # the error was reported once; close() is clean
+
+
+def test_save_weights_through_the_background_writer_equals_the_inline_write(tmp_path):
+    from gennet_amd import bbh, hostio
+    m = bbh.signal_discriminator_model(64)
+    a, b = str(tmp_path / 'a.h5'), str(tmp_path / 'b.h5')
+    m.save_weights(a, True)
+    with hostio.BackgroundWriter() as bg:
+        m.save_weights(b, True, writer=bg)
+    assert open(a, 'rb').read() == open(b, 'rb').read()
