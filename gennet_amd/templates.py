@@ -415,11 +415,29 @@ def training_arrays(ts, pars):
 
 # --------------------------------------------------------------------------------------------------- posterior-driven mode
 def m1m2_from_mc_q(mc, q):
-    """Closed form of what data/get_lalinf_pars.py:41-91 solves symbolically: q = m2/m1 <= 1, mc = (m1 m2)^(3/5)/(m1+m2)^(1/5)
-    -> m1 = mc (1+q)^(1/5) / q^(3/5), m2 = q m1."""
+    """Component masses of a posterior row, heavier first: q = m2/m1 <= 1, mc = (m1 m2)^(3/5)/(m1+m2)^(1/5)
+    -> m1 = mc (1+q)^(1/5) / q^(3/5), m2 = q m1.  This is the pair lalinf_post_waveform_maker.py:385 forms (m12 = [column 1, column 0] of
+    the m1_m2 file); the file itself holds them the other way round, see lalinf_pars."""
     mc = np.asarray(mc, np.float64); q = np.asarray(q, np.float64)
     m1 = mc * (1.0 + q) ** 0.2 / q ** 0.6
     return m1, q * m1
+
+
+def lalinf_pars(post_mc, post_q):
+    """data/get_lalinf_pars.py:52-91 in closed form (the reference solves the two equations per row with sympy): the three arrays it
+    pickles from the lalinference posterior columns mc and q.
+      'm1_m2': [post_m1, post_m2] with post_m1 = mc (1 + 1/q)^(1/5) q^(3/5)  (root of :58, which sets m2 = m1/q)
+                                       post_m2 = mc (1 + q)^(1/5) / q^(3/5)   (root of :62, which sets m1 = q m2)
+               -- for q <= 1 the FIRST row is the lighter mass, as in the reference's file
+      'mc_M' : [mc, post_m1 + post_m2]     (:69-84)
+      'mc_q' : [mc, q]                     (:88-91)
+    Pinned by tests/golden/lalinf_pars_golden.npz (the reference's loops executed on supplied columns)."""
+    mc = np.asarray(post_mc, np.float64).reshape(-1); q = np.asarray(post_q, np.float64).reshape(-1)
+    if mc.shape != q.shape or (q <= 0).any() or (mc <= 0).any():
+        raise ValueError('lalinf_pars: mc and q must be positive columns of equal length')
+    m1 = mc * (1.0 + 1.0 / q) ** 0.2 * q ** 0.6
+    m2 = mc * (1.0 + q) ** 0.2 / q ** 0.6
+    return {'m1_m2': np.array([m1, m2]), 'mc_M': np.array([mc, m1 + m2]), 'mc_q': np.array([mc, q])}
 
 
 def sim_data_posterior(fs, T_obs, psds, post_m1, post_m2, post_mc=None, dets=['H1'], size=None, beta=[0.45, 0.55], batch_size=3907,

@@ -23,6 +23,9 @@ indexing_golden.npz (sample indexing: north_star's "bit-exact for sample indexin
                    the python slice [ref_idx - par.idx - 11:], zero fill, window -- is the reference's own text.
   sim_data         gw_template_maker.py:632-740   executed as written (Nnoise = 0) on top of the functions above: the crop :695, the trim
                    quirk :718-722, the permutation :725-727, the event-like template appended last :730-739
+lalinf_pars_golden.npz (data/get_lalinf_pars.py, the posterior-column conversion in front of the posterior-driven synthesiser, row n3):
+  the do_m1m2 and do_mc_M loops (:52-65, :69-84, located by their first / last statement) executed as written with sympy on supplied
+  post_mc / post_q columns
 Run-time text handling (nothing of it is stored): tabs expanded to 8 columns (the files mix tabs and spaces: Python 2 semantics), and
 lines that are Python 2 `print '...'` statements (with or without the `if verb:` prefix) replaced by `pass`.  Integer `/` in those
 lines only ever divides even ints by 2 or feeds int(): Python 3's true division gives the same values for T_obs = 4 and even fs.
@@ -95,6 +98,7 @@ def main():
     print('wrote', OUT, {k: np.asarray(v).shape for k, v in out.items()})
     posterior_golden()
     indexing_golden()
+    lalinf_pars_golden()
 
 
 _PY2_PRINT = re.compile(r"^(\s*)(if verb:\s*)?print\s+'")
@@ -240,6 +244,37 @@ def posterior_golden():
     path = os.path.join(os.path.dirname(OUT), 'posterior_golden.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, 'beta =', beta)
+
+
+def lalinf_pars_golden():
+    """data/get_lalinf_pars.py: the two conversion loops (`if do_m1m2:` ... `lalinf_pars = np.array([post_m1,post_m2])` and
+    `if do_mc_M:` ... `lalinf_pars = np.array([post_mc,post_M])`) executed as written -- sympy's solve on the reference's own equations --
+    on SUPPLIED posterior columns post_mc / post_q (the script reads them from a lalinference HDF5 file that is not in the repository);
+    the pickle.dump lines that follow each block are not executed.  Line ranges are located by their first / last statement at run
+    time.  Stores inputs and the two (2, n) arrays."""
+    from sympy import Eq, Symbol, solve
+    path = '/root/reference/BBH_version/data/get_lalinf_pars.py'
+    lines = open(path).read().splitlines(True)
+
+    def block(first, last):
+        a = next(i for i, ln in enumerate(lines) if ln.startswith(first))
+        b = next(i for i, ln in enumerate(lines) if i > a and ln.strip().startswith(last))
+        return ''.join(lines[a:b + 1]), a + 1, b + 1
+
+    rng = np.random.RandomState(12)
+    post_mc = np.concatenate([rng.uniform(24.0, 34.0, 5), [30.0]])
+    post_q = np.concatenate([rng.uniform(0.5, 1.0, 5), [1.0]])
+    out = {'post_mc': post_mc, 'post_q': post_q}
+    for flag, first, last, key in (('do_m1m2', 'if do_m1m2:', 'lalinf_pars = np.array([post_m1,post_m2])', 'm1_m2'),
+                                   ('do_mc_M', 'if do_mc_M:', 'lalinf_pars = np.array([post_mc,post_M])', 'mc_M')):
+        text, a, b = block(first, last)
+        ns = {'np': np, 'Eq': Eq, 'Symbol': Symbol, 'solve': solve, 'post_mc': post_mc, 'post_q': post_q, flag: True, 'print': lambda *x: None}
+        exec(compile(text, 'get_lalinf_pars.py:%d-%d' % (a, b), 'exec'), ns)
+        out[key] = np.asarray(ns['lalinf_pars'], np.float64)
+        out[key + '_lines'] = np.array([a, b])
+    dst = os.path.join(os.path.dirname(OUT), 'lalinf_pars_golden.npz')
+    np.savez_compressed(dst, **out)
+    print('wrote', dst, out['m1_m2'][:, :2], out['m1_m2_lines'], out['mc_M_lines'])
 
 
 if __name__ == '__main__':

@@ -262,3 +262,32 @@ def test_save_weights_through_the_background_writer_equals_the_inline_write(tmp_
     with hostio.BackgroundWriter() as bg:
         m.save_weights(b, True, writer=bg)
     assert open(a, 'rb').read() == open(b, 'rb').read()
+
+
+def test_lalinf_posterior_conversion_matches_the_reference_executed_fixture(tmp_path):
+    """data/get_lalinf_pars.py (in front of row n3): templates.lalinf_pars' closed forms against the reference's own sympy loops executed
+    on supplied columns (tests/golden/lalinf_pars_golden.npz), and scripts/get_lalinf_pars.py writing the reference's three files."""
+    import pickle
+    import subprocess
+    from gennet_amd import templates as T
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'lalinf_pars_golden.npz'))
+    pars = T.lalinf_pars(g['post_mc'], g['post_q'])
+    assert np.abs(pars['m1_m2'] - g['m1_m2']).max() <= 1e-11 * np.abs(g['m1_m2']).max()
+    assert np.abs(pars['mc_M'] - g['mc_M']).max() <= 1e-11 * np.abs(g['mc_M']).max()
+    assert np.array_equal(pars['mc_q'], np.array([g['post_mc'], g['post_q']]))
+    # the pair the posterior-driven maker forms from the file (lalinf_post_waveform_maker.py:385: [column 1, column 0]) is (heavier, lighter)
+    m1, m2 = T.m1m2_from_mc_q(g['post_mc'], g['post_q'])
+    assert np.allclose(m1, g['m1_m2'][1], rtol=1e-11) and np.allclose(m2, g['m1_m2'][0], rtol=1e-11)
+    with pytest.raises(ValueError):
+        T.lalinf_pars([30.0], [0.0])
+    post = str(tmp_path / 'post.npz')
+    np.savez(post, mc=g['post_mc'], q=g['post_q'])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts/get_lalinf_pars.py'), '--posterior', post, '--tag', 'srate-2048', '--mc-M', '1',
+                        '--out', str(tmp_path / 'data')], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for stem, key in (('gw150914_m1_m2_lainf_post_srate-2048.sav', 'm1_m2'), ('gw150914_mc_M_lainf_post_srate-2048.sav', 'mc_M'),
+                      ('gw150914_mc_q_lalinf_post_srate-2048.sav', 'mc_q')):
+        with open(str(tmp_path / 'data' / stem), 'rb') as f:
+            a = pickle.load(f)
+        assert a.shape == (2, 6) and np.array_equal(a, pars[key])
