@@ -18,8 +18,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def parser():
-    p = argparse.ArgumentParser(prog='make_templates.py', description='generates GW template banks on MI355X (gennet_amd)')
+def parser(prog='make_templates.py', extra=None):
+    p = argparse.ArgumentParser(prog=prog, description='generates GW template banks on MI355X (gennet_amd)')
     p.add_argument('-N', '--Nsamp', type=int, default=50000, help='the number of samples')
     p.add_argument('-Nn', '--Nnoise', type=int, default=0, help='the number of noise realisations per signal, if 0 then signal only')
     p.add_argument('-Nb', '--Nblock', type=int, default=50000, help='the number of training samples per output file')
@@ -34,12 +34,15 @@ def parser():
     p.add_argument('--psd-file', default=None)
     p.add_argument('--peak-offset', type=int, default=11, help='the alignment constant of gw_template_maker.py:554')
     p.add_argument('--tag', default=None)
+    if extra:
+        extra(p)
     return p.parse_args()
 
 
-def main():
-    from gennet_amd import templates as T
-    args = parser()
+def prepare_event(args, T):
+    """gw_template_maker.py:753-791 (and, line for line the same, lalinf_post_waveform_maker.py:759-791): the event in noise and the noise-free
+    event whitened in the frequency domain, gw_norm_constant = 1/std of the whitened noisy event, their central 1-s crops, the PSD.
+    Returns (psd, wht_wvf, h_t, gw_norm_constant, fs, safeTobs, tag)."""
     if args.seed > 0:
         np.random.seed(args.seed)
     fs = args.fsample
@@ -47,7 +50,6 @@ def main():
     N = fs * safeTobs
     Nf = N // 2 + 1
     tag = args.tag if args.tag is not None else '_srate-%dhz_oversamp' % fs
-    event_name = 'gw150914'
 
     if args.freq_data and args.freq_data_inj and args.psd_file:
         noise_f = np.loadtxt(args.freq_data)[:, 1:]
@@ -73,7 +75,14 @@ def main():
     h_t = np.fft.irfft(T.whiten_data(h_f, safeTobs, fs, psd, 'fd'), N)
     gw_norm_constant = 1.0 / np.std(wht_wvf)
     c0, c1 = int((safeTobs / 2) * fs - fs / 2.0), int((safeTobs / 2) * fs + fs / 2.0)
-    wht_wvf, h_t = wht_wvf[c0:c1], h_t[c0:c1]
+    return psd, wht_wvf[c0:c1], h_t[c0:c1], gw_norm_constant, fs, safeTobs, tag
+
+
+def main():
+    from gennet_amd import templates as T
+    args = parser()
+    psd, wht_wvf, h_t, gw_norm_constant, fs, safeTobs, tag = prepare_event(args, T)
+    event_name = 'gw150914'
 
     os.makedirs(os.path.dirname(args.basename) or '.', exist_ok=True)
     os.makedirs('data', exist_ok=True)

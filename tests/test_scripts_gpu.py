@@ -53,3 +53,18 @@ def test_template_maker_then_trainer_leave_the_reference_files(tmp_path):
     g = bbh.generator_model(fs)
     g.load_weights(str(tmp_path / 'run' / 'generator.h5'))
     assert all(np.isfinite(w).all() for w in g.get_weights())
+
+
+@pytest.mark.gpu
+def test_posterior_columns_to_sanity_check_set(tmp_path):
+    """data/get_lalinf_pars.py -> lalinf_post_waveform_maker.main(): posterior columns -> m1_m2 / mc_q pickles -> the CNN sanity-check set."""
+    fs, n = 256, 12
+    rng = np.random.RandomState(3)
+    np.savez(str(tmp_path / 'post.npz'), mc=rng.uniform(26, 32, n), q=rng.uniform(0.6, 1.0, n))
+    run([os.path.join(ROOT, 'scripts/get_lalinf_pars.py'), '--posterior', 'post.npz', '--tag', 'srate-%d' % fs, '--out', 'data'], str(tmp_path))
+    out = run([os.path.join(ROOT, 'scripts/make_posterior_templates.py'), '--posterior', 'data/gw150914_m1_m2_lainf_post_srate-%d.sav' % fs,
+               '--mc-q-file', 'data/gw150914_mc_q_lalinf_post_srate-%d.sav' % fs, '-f', str(fs), '-T', '1', '-N', '9', '-Nb', '9', '-z', '1'], str(tmp_path))
+    assert 'success' in out
+    with open(str(tmp_path / 'data' / ('gw150914_cnn_sanity_check_ts_mass-time-vary_srate-%dhz_oversamp.sav' % fs)), 'rb') as f:
+        ts = pickle.load(f)
+    assert ts.shape == (9, fs) and ts.dtype == np.float64 and np.isfinite(ts).all() and np.abs(ts).max() > 0         # 8 posterior rows + the event-like template
