@@ -264,3 +264,14 @@ def posterior_samples(nets, n_samples=4000, predict_batch=32):
     wave = nets.generator.predict_device(z, batch_size=predict_batch)
     pe = nets.signal_pe.predict_device(wave, batch_size=predict_batch)
     return [p.cpu().numpy() for p in pe], wave.cpu().numpy()
+
+
+def posterior_overlap(pe_samples, lalinf_pars):
+    """bbhMahoGANy.py:1345-1356 without the plot: the overlap of the GAN posterior [mc (n,1), q (n,1)] with the lalinference posterior
+    (2, m) -- (ks_score, ad_score, beta_score) of overlap_tests (:811-873) -- or None while either read-out is still constant ("if results
+    aren't terrible", :1352: both variances non-zero)."""
+    from . import posterior
+    if np.var(pe_samples[0]) == 0 or np.var(pe_samples[1]) == 0:
+        return None
+    return posterior.overlap_tests(pe_samples, np.asarray(lalinf_pars, np.float64))
+

@@ -34,6 +34,8 @@ def main():
     ap.add_argument('--lr', type=float, default=9e-5)
     ap.add_argument('--event-scale', type=float, default=817.98, help='bbhMahoGANy.py:1028-1029 scales the event by this literal')
     ap.add_argument('--out', default='.')
+    ap.add_argument('--lalinf-posterior', default=None,
+                    help='mc_q pickle of scripts/get_lalinf_pars.py: the overlap of the GAN posterior with it is scored at every cadence (:1345-1356)')
     args = ap.parse_args()
 
     from gennet_amd import bbh, dist, engine, hostio, templates as T
@@ -58,6 +60,10 @@ def main():
     os.makedirs(os.path.join(args.out, 'best_models'), exist_ok=True)
     os.makedirs(os.path.join(args.out, 'GAN_posterior_samples'), exist_ok=True)
 
+    lalinf_pars, beta_score_hist = None, []
+    if args.lalinf_posterior:                                                         # :1016-1020 (lalinf_pars)
+        with open(args.lalinf_posterior, 'rb') as f:
+            lalinf_pars = np.asarray(pickle.load(f, encoding='latin1'), np.float64)
     bg = hostio.BackgroundWriter()             # serialisation + file writes of the cadence blocks leave the loop's thread
     for i in range(args.pe_iter):                                                     # :1153-1173
         pe_loss = bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch_size, rank=rank, world=world)
@@ -72,6 +78,12 @@ def main():
         if i % args.cadence == 0 and i > 0 and rank == 0:
             print('%d: [sD loss: %f, acc: %f]  [sG loss: %f, acc: %f]' % (i, l[2], l[3], l[0], l[1]), flush=True)
             pe_samples, waves = bbh.posterior_samples(nets, 4000)                     # :1330-1343
+            score = bbh.posterior_overlap(pe_samples, lalinf_pars) if lalinf_pars is not None else None          # :1345-1356 (the plot is not produced)
+            if score is not None:
+                ks, ad, beta = score
+                beta_score_hist.append(float(beta))
+                print('%d: [posterior overlap beta: %f, KS p (mc, q): %g, %g]' % (i, beta, ks[0][1], ks[1][1]), flush=True)
+                bg.pickle(list(beta_score_hist), os.path.join(args.out, 'beta_score_hist.sav'), protocol=2)
             bg.pickle(pe_samples, os.path.join(args.out, 'gan_pe_samples.sav'), protocol=2)
             bg.pickle(waves, os.path.join(args.out, 'gan_pe_waveforms.sav'), protocol=2)
             nets.generator.save_weights(os.path.join(args.out, 'generator.h5'), True, writer=bg)

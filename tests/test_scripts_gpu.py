@@ -37,10 +37,17 @@ def test_template_maker_then_trainer_leave_the_reference_files(tmp_path):
         ev = pickle.load(f, encoding='latin1')
     assert np.asarray(ev).shape == (fs,)
 
+    rng = np.random.RandomState(2)
+    with open(str(tmp_path / 'lalinf_mc_q.sav'), 'wb') as f:                                       # stand-in for the lalinference posterior (mc, q)
+        pickle.dump(np.array([rng.normal(30.0, 1.0, 500), rng.normal(0.8, 0.05, 500)]), f, protocol=2)
     out = run([os.path.join(ROOT, 'scripts/bbh_train.py'), '--templates', 'templates/', '--training-num', str(n), '--tag', tag, '--n-pix', str(fs),
-               '--batch-size', '4', '--pe-batch-size', '8', '--pe-iter', '40', '--max-iter', '7', '--cadence', '3', '--event-scale', '1.0', '--out', 'run'],
-              str(tmp_path))
+               '--batch-size', '4', '--pe-batch-size', '8', '--pe-iter', '400', '--lr', '1e-3', '--max-iter', '7', '--cadence', '3', '--event-scale', '1.0', '--out', 'run',
+               '--lalinf-posterior', 'lalinf_mc_q.sav'], str(tmp_path))
     assert 'Completed CNN PE' in out and '[sD loss:' in out
+    if 'posterior overlap beta' in out:             # scored only once both read-outs vary (bbhMahoGANy.py:1352); a few hundred steps may not get there
+        with open(str(tmp_path / 'run' / 'beta_score_hist.sav'), 'rb') as f:
+            hist = pickle.load(f)
+        assert 1 <= len(hist) <= 2 and all(0.0 <= b <= 1.0 for b in hist)
     for name in ('generator.h5', 'discriminator.h5', 'signal_dis_on_gen.h5', 'gan_pe_samples.sav', 'gan_pe_waveforms.sav',
                  'GAN_posterior_samples/posterior_samples_00006.sav'):
         assert (tmp_path / 'run' / name).exists(), name
@@ -68,3 +75,19 @@ def test_posterior_columns_to_sanity_check_set(tmp_path):
     with open(str(tmp_path / 'data' / ('gw150914_cnn_sanity_check_ts_mass-time-vary_srate-%dhz_oversamp.sav' % fs)), 'rb') as f:
         ts = pickle.load(f)
     assert ts.shape == (9, fs) and ts.dtype == np.float64 and np.isfinite(ts).all() and np.abs(ts).max() > 0         # 8 posterior rows + the event-like template
+
+
+@pytest.mark.gpu
+def test_cadence_overlap_score_of_the_trainer():
+    """bbh.posterior_overlap (bbhMahoGANy.py:1345-1356): None while a read-out is constant, else overlap_tests' triple with beta in [0, 1]
+    and beta = 1 for identical sample sets."""
+    sys.path.insert(0, ROOT)
+    from gennet_amd import bbh
+    rng = np.random.RandomState(4)
+    lal = np.array([rng.normal(30.0, 1.0, 600), rng.normal(0.8, 0.05, 600)])
+    pe = [rng.normal(30.2, 1.1, (500, 1)).astype(np.float32), rng.normal(0.79, 0.05, (500, 1)).astype(np.float32)]
+    assert bbh.posterior_overlap([np.zeros((500, 1), np.float32), pe[1]], lal) is None
+    ks, ad, beta = bbh.posterior_overlap(pe, lal)
+    assert 0.5 < beta <= 1.0 and 0.0 <= ks[0][1] <= 1.0
+    same = bbh.posterior_overlap([lal[0].reshape(-1, 1), lal[1].reshape(-1, 1)], lal)
+    assert abs(same[2] - 1.0) < 1e-9
