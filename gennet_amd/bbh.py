@@ -275,3 +275,18 @@ def posterior_overlap(pe_samples, lalinf_pars):
         return None
     return posterior.overlap_tests(pe_samples, np.asarray(lalinf_pars, np.float64))
 
+
+def pe_accuracy(signal_pe, bank, n_eval=4000, rng=_pyrandom, predict_batch=32):
+    """The CNN loop's progress read-out, bbhMahoGANy.py:1184-1196 / :1208-1222: predict on `n_eval` randomly chosen training templates
+    (random.sample from the host stream) and return (rms, pe_std) -- per parameter the mean squared and the mean absolute difference
+    between the training labels [mc, q] and the two read-outs.  (The reference's `rms` line indexes the label ROWS k = 0, 1 instead of the
+    parameter columns, :1189; this is the per-parameter quantity its message announces.)"""
+    n = min(int(n_eval), bank.n)
+    it = torch.tensor(rng.sample(range(bank.n), n), dtype=torch.int64, device=device())
+    x = ops.gather_rows(bank.images, it).reshape(n, bank.n_pix, 1)
+    y = ops.gather_rows(bank.pars, it).cpu().numpy().astype(np.float64)
+    pe = [p.cpu().numpy().astype(np.float64).reshape(-1) for p in signal_pe.predict_device(x, batch_size=predict_batch)]
+    rms = [float(np.mean((y[:, k] - pe[k]) ** 2)) for k in range(2)]
+    pe_std = [float(np.mean(np.abs(y[:, k] - pe[k]))) for k in range(2)]
+    return rms, pe_std
+

@@ -34,6 +34,11 @@ def main():
     ap.add_argument('--lr', type=float, default=9e-5)
     ap.add_argument('--event-scale', type=float, default=817.98, help='bbhMahoGANy.py:1028-1029 scales the event by this literal')
     ap.add_argument('--out', default='.')
+    ap.add_argument('--pe-cadence', type=int, default=1000, help='CNN progress read-out every so many iterations (:1176, :1200)')
+    ap.add_argument('--old-model', action='store_true', help='do_old_model (:1133-1138): start all four networks from the files of an earlier run in --out')
+    ap.add_argument('--only-old-pe-model', action='store_true', help='do_only_old_pe_model (:1141-1142): load best_models/signal_pe.h5 and skip the CNN loop')
+    ap.add_argument('--sanity-check', default=None,
+                    help='the (n, n_pix) pickle of scripts/make_posterior_templates.py: with --lalinf-posterior the CNN read-out of it is scored (:1224-1229)')
     ap.add_argument('--lalinf-posterior', default=None,
                     help='mc_q pickle of scripts/get_lalinf_pars.py: the overlap of the GAN posterior with it is scored at every cadence (:1345-1356)')
     args = ap.parse_args()
@@ -64,13 +69,36 @@ def main():
     if args.lalinf_posterior:                                                         # :1016-1020 (lalinf_pars)
         with open(args.lalinf_posterior, 'rb') as f:
             lalinf_pars = np.asarray(pickle.load(f, encoding='latin1'), np.float64)
+    sanity = None
+    if args.sanity_check:                                                             # :1225-1226
+        with open(args.sanity_check, 'rb') as f:
+            sanity = engine.to_device(np.asarray(pickle.load(f, encoding='latin1'), np.float32).reshape(-1, args.n_pix, 1))
+    if args.old_model:                                                                # :1133-1138
+        nets.signal_pe.load_weights(os.path.join(args.out, 'best_models/signal_pe.h5'))
+        nets.signal_discriminator.load_weights(os.path.join(args.out, 'discriminator.h5'))
+        nets.signal_discriminator_on_generator.load_weights(os.path.join(args.out, 'signal_dis_on_gen.h5'))
+        nets.generator.load_weights(os.path.join(args.out, 'generator.h5'))
+    if args.only_old_pe_model:                                                        # :1141-1142
+        nets.signal_pe.load_weights(os.path.join(args.out, 'best_models/signal_pe.h5'))
     bg = hostio.BackgroundWriter()             # serialisation + file writes of the cadence blocks leave the loop's thread
-    for i in range(args.pe_iter):                                                     # :1153-1173
+    for i in range(0 if args.only_old_pe_model else args.pe_iter):                    # :1145, :1153-1173
         pe_loss = bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch_size, rank=rank, world=world)
         if i % 5000 == 0 and i > 0 and rank == 0:
             nets.signal_pe.save(os.path.join(args.out, 'best_models/signal_pe.h5'), True, writer=bg)
-        if i % 1000 == 0 and rank == 0:
-            print('%d: [PE loss: %f, acc: %f]' % (i, pe_loss[0], pe_loss[1]), flush=True)
+        if i % args.pe_cadence == 0 and i > 0:
+            rms, pe_std = bbh.pe_accuracy(nets.signal_pe, bank)                       # every rank: it draws from the shared host index stream
+        if i % args.pe_cadence == 0 and rank == 0:
+            if i > 0:                                                                 # :1200-1229
+                print('%d: [PE loss: %f, acc: %f, RMS: %f,%f] mean |error| (mc, q): %f, %f' % (i, pe_loss[0], pe_loss[1], rms[0], rms[1], pe_std[0], pe_std[1]),
+                      flush=True)
+                if sanity is not None and lalinf_pars is not None:
+                    score = bbh.posterior_overlap([p.cpu().numpy() for p in nets.signal_pe.predict_device(sanity)], lalinf_pars)
+                    if score is not None:
+                        print('%d: [CNN sanity check vs lalinference: overlap beta %f]' % (i, score[2]), flush=True)
+            else:
+                print('%d: [PE loss: %f, acc: %f]' % (i, pe_loss[0], pe_loss[1]), flush=True)
+    if not args.only_old_pe_model and args.pe_iter > 0 and rank == 0:
+        nets.signal_pe.save(os.path.join(args.out, 'best_models/signal_pe.h5'), True, writer=bg)     # so that --old-model finds the trained CNN
     print('Completed CNN PE')
 
     for i in range(args.max_iter):                                                    # :1241-1382

@@ -41,9 +41,14 @@ def test_template_maker_then_trainer_leave_the_reference_files(tmp_path):
     with open(str(tmp_path / 'lalinf_mc_q.sav'), 'wb') as f:                                       # stand-in for the lalinference posterior (mc, q)
         pickle.dump(np.array([rng.normal(30.0, 1.0, 500), rng.normal(0.8, 0.05, 500)]), f, protocol=2)
     out = run([os.path.join(ROOT, 'scripts/bbh_train.py'), '--templates', 'templates/', '--training-num', str(n), '--tag', tag, '--n-pix', str(fs),
-               '--batch-size', '4', '--pe-batch-size', '8', '--pe-iter', '400', '--lr', '1e-3', '--max-iter', '7', '--cadence', '3', '--event-scale', '1.0', '--out', 'run',
+               '--batch-size', '4', '--pe-batch-size', '8', '--pe-iter', '400', '--pe-cadence', '200', '--lr', '1e-3', '--max-iter', '7', '--cadence', '3', '--event-scale', '1.0', '--out', 'run',
                '--lalinf-posterior', 'lalinf_mc_q.sav'], str(tmp_path))
-    assert 'Completed CNN PE' in out and '[sD loss:' in out
+    assert 'Completed CNN PE' in out and '[sD loss:' in out and 'RMS:' in out and 'mean |error| (mc, q):' in out
+    # do_old_model / do_only_old_pe_model (bbhMahoGANy.py:1133-1142): a second run starts from the files of the first and skips the CNN loop
+    out2 = run([os.path.join(ROOT, 'scripts/bbh_train.py'), '--templates', 'templates/', '--training-num', str(n), '--tag', tag, '--n-pix', str(fs),
+                '--batch-size', '4', '--max-iter', '2', '--cadence', '1', '--event-scale', '1.0', '--out', 'run', '--old-model', '--only-old-pe-model'],
+               str(tmp_path))
+    assert 'Completed CNN PE' in out2 and 'PE loss' not in out2 and '[sD loss:' in out2
     if 'posterior overlap beta' in out:             # scored only once both read-outs vary (bbhMahoGANy.py:1352); a few hundred steps may not get there
         with open(str(tmp_path / 'run' / 'beta_score_hist.sav'), 'rb') as f:
             hist = pickle.load(f)
