@@ -238,11 +238,16 @@ def gan_train_step_online(nets, online_bank, event, batch, predict_batch=32):
     return gan_train_step(nets, None, event, batch, predict_batch=predict_batch, real=real)
 
 
-def gan_train_step(nets, bank, event, batch, rng=_pyrandom, rank=0, world=1, predict_batch=32, real=None):
-    """One iteration of the GAN loop, bbhMahoGANy.py:1243-1299.  Returns [sg_loss, sg_acc, sd_loss, sd_acc] (:1299)."""
+def gan_train_step(nets, bank, event, batch, rng=_pyrandom, rank=0, world=1, predict_batch=32, real=None, n_noise_real=1):
+    """One iteration of the GAN loop, bbhMahoGANy.py:1243-1299.  Returns [sg_loss, sg_acc, sd_loss, sd_acc] (:1299).
+    n_noise_real (:107, default 1): noise realisations per sampled template -- the `batch` sampled templates are stacked n_noise_real times
+    (:1280-1283) and every other batch of the iteration (latents, fakes, noise, labels) has batch * n_noise_real rows."""
     if real is None:
         it = bank.sample(batch, rng, rank, world)
         real = ops.gather_rows(bank.images, it)
+    if n_noise_real > 1:
+        real = real.repeat(int(n_noise_real), 1)                      # whole copies one after another, as np.concatenate builds them
+        batch = batch * int(n_noise_real)
     n = real.shape[1]
     seed, off = device_rng().take(batch * 100)
     z = ops.fill_uniform((batch, 100), -1.0, 1.0, seed, off, device())

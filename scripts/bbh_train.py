@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--lr', type=float, default=9e-5)
     ap.add_argument('--event-scale', type=float, default=817.98, help='bbhMahoGANy.py:1028-1029 scales the event by this literal')
     ap.add_argument('--out', default='.')
+    ap.add_argument('--n-noise-real', type=int, default=1, help='noise realisations per sampled template in the GAN loop (:107)')
     ap.add_argument('--pe-cadence', type=int, default=1000, help='CNN progress read-out every so many iterations (:1176, :1200)')
     ap.add_argument('--old-model', action='store_true', help='do_old_model (:1133-1138): start all four networks from the files of an earlier run in --out')
     ap.add_argument('--only-old-pe-model', action='store_true', help='do_only_old_pe_model (:1141-1142): load best_models/signal_pe.h5 and skip the CNN loop')
@@ -102,7 +103,7 @@ def main():
     print('Completed CNN PE')
 
     for i in range(args.max_iter):                                                    # :1241-1382
-        l = bbh.gan_train_step(nets, bank, event, args.batch_size, rank=rank, world=world)
+        l = bbh.gan_train_step(nets, bank, event, args.batch_size, rank=rank, world=world, n_noise_real=args.n_noise_real)
         if i % args.cadence == 0 and i > 0 and rank == 0:
             print('%d: [sD loss: %f, acc: %f]  [sG loss: %f, acc: %f]' % (i, l[2], l[3], l[0], l[1]), flush=True)
             pe_samples, waves = bbh.posterior_samples(nets, 4000)                     # :1330-1343

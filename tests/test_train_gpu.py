@@ -115,3 +115,28 @@ def test_config5_both_loops_at_n_pix_4096_with_synthesis_in_the_loop():
             assert not torch.equal(l.moving_variance.data, torch.ones_like(l.moving_variance.data))
     fake = G.predict_device(z, batch_size=4)
     assert fake.shape == (4, fs, 1) and torch.isfinite(fake).all()
+
+
+def test_gan_step_with_several_noise_realisations_per_template():
+    """n_noise_real > 1 (bbhMahoGANy.py:107, :1277-1296): the sampled templates are stacked n_noise_real times and every batch of the
+    iteration grows with them; the discriminator then sees 2 * batch * n_noise_real rows."""
+    import torch
+    from gennet_amd import bbh, engine
+    engine.set_init_seed(2); engine.set_device_seed(5)
+    n_pix, B = 64, 4
+    rng = np.random.RandomState(0)
+    event = rng.randn(n_pix, 1).astype(np.float32)
+    nets = bbh.build_and_compile(event, n_pix)
+    bank = bbh.DeviceBank(rng.randn(32, n_pix).astype(np.float32), rng.uniform(0.5, 1, (32, 2)).astype(np.float32))
+    seen = {}
+    orig = nets.signal_discriminator.train_on_batch
+
+    def spy(x, y, **kw):
+        seen['rows'] = (tuple(x.shape), len(y))
+        seen['x'] = x
+        return orig(x, y, **kw)
+    nets.signal_discriminator.train_on_batch = spy
+    out = bbh.gan_train_step(nets, bank, engine.to_device(event.reshape(-1)), B, n_noise_real=3)
+    assert seen['rows'] == ((2 * B * 3, n_pix, 2, 1), 2 * B * 3) and np.isfinite(out).all()
+    real = seen['x'][:B * 3, :, 0, 0]
+    assert torch.equal(real[:B], real[B:2 * B]) and torch.equal(real[:B], real[2 * B:])          # the same B templates, three times over
