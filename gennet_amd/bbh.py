@@ -147,9 +147,20 @@ class Nets(object):
     pass
 
 
-def build_and_compile(noise_signal, n_pix, lr=9e-5, do_pe=True, data_parallel=None):
+def chisquare_loss(n_sig=1.0):
+    """chisquare_Loss of bbhMahoGANy.py:146-162 for a noise standard deviation n_sig (:85), written with the backend facade exactly as the
+    script writes it; Model.compile traces it once and lowers it to the squared-error kernel with the scale 1 / n_sig^2."""
+    from .keras import backend as K
+
+    def chisquare_Loss(yTrue, yPred):
+        return K.sum(K.square(yTrue - yPred) / (n_sig ** 2), axis=-1)
+    return chisquare_Loss
+
+
+def build_and_compile(noise_signal, n_pix, lr=9e-5, do_pe=True, data_parallel=None, chi_loss=False, n_sig=1.0):
     """bbhMahoGANy.py:1089-1119, in the reference's order (the order fixes which weights each compiled model trains):
-    the combined model is compiled while the discriminator is frozen, the discriminator after it is unfrozen."""
+    the combined model is compiled while the discriminator is frozen, the discriminator after it is unfrozen.
+    chi_loss (:97, :1106-1109): the combined model trains on chisquare_Loss instead of binary cross-entropy."""
     nets = Nets()
     nets.generator = generator_model(n_pix)
     nets.signal_discriminator = signal_discriminator_model(n_pix)
@@ -160,7 +171,8 @@ def build_and_compile(noise_signal, n_pix, lr=9e-5, do_pe=True, data_parallel=No
     nets.data_subtraction_on_generator.compile(loss='binary_crossentropy', optimizer=Adam(lr=lr, beta_1=0.5), metrics=['accuracy'], data_parallel=dp)
     nets.signal_discriminator_on_generator = generator_containing_signal_discriminator(nets.data_subtraction_on_generator, nets.signal_discriminator)
     set_trainable(nets.signal_discriminator, False)
-    nets.signal_discriminator_on_generator.compile(loss='binary_crossentropy', optimizer=Adam(lr=lr, beta_1=0.5), metrics=['accuracy'], data_parallel=dp)
+    nets.signal_discriminator_on_generator.compile(loss=chisquare_loss(n_sig) if chi_loss else 'binary_crossentropy', optimizer=Adam(lr=lr, beta_1=0.5),
+                                                   metrics=['accuracy'], data_parallel=dp)
     set_trainable(nets.signal_discriminator, True)
     nets.signal_discriminator.compile(loss='binary_crossentropy', optimizer=Adam(lr=lr, beta_1=0.5), metrics=['accuracy'], data_parallel=dp)
     if do_pe:

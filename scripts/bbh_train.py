@@ -34,6 +34,10 @@ def main():
     ap.add_argument('--lr', type=float, default=9e-5)
     ap.add_argument('--event-scale', type=float, default=817.98, help='bbhMahoGANy.py:1028-1029 scales the event by this literal')
     ap.add_argument('--out', default='.')
+    ap.add_argument('--chi-loss', action='store_true', help='chi_loss (:97): the generator trains on chisquare_Loss (:146-162) instead of binary cross-entropy')
+    ap.add_argument('--n-sig', type=float, default=1.0, help='n_sig (:85), the noise standard deviation in chisquare_Loss')
+    ap.add_argument('--cnn-noise-frac', type=float, default=1.0 / 8.0, help='cnn_noise_frac (:113): fraction of each CNN batch that gets noise added')
+    ap.add_argument('--retrain-pe-mod', action='store_true', help='retrain_pe_mod (:104, :1145): load best_models/signal_pe.h5 and keep training it')
     ap.add_argument('--n-noise-real', type=int, default=1, help='noise realisations per sampled template in the GAN loop (:107)')
     ap.add_argument('--pe-cadence', type=int, default=1000, help='CNN progress read-out every so many iterations (:1176, :1200)')
     ap.add_argument('--old-model', action='store_true', help='do_old_model (:1133-1138): start all four networks from the files of an earlier run in --out')
@@ -57,7 +61,7 @@ def main():
     with open('data/%s0%s.sav' % (args.event_name, args.tag), 'rb') as f:            # :1027-1028
         noise_signal = np.reshape(pickle.load(f, encoding='latin1') * args.event_scale, (args.n_pix, 1))
 
-    nets = bbh.build_and_compile(noise_signal, args.n_pix, lr=args.lr, data_parallel=dp)
+    nets = bbh.build_and_compile(noise_signal, args.n_pix, lr=args.lr, data_parallel=dp, chi_loss=args.chi_loss, n_sig=args.n_sig)
     if dp:
         for m in (nets.generator, nets.signal_discriminator, nets.signal_pe):
             dp.sync_model(m)
@@ -79,11 +83,12 @@ def main():
         nets.signal_discriminator.load_weights(os.path.join(args.out, 'discriminator.h5'))
         nets.signal_discriminator_on_generator.load_weights(os.path.join(args.out, 'signal_dis_on_gen.h5'))
         nets.generator.load_weights(os.path.join(args.out, 'generator.h5'))
-    if args.only_old_pe_model:                                                        # :1141-1142
+    if args.only_old_pe_model or args.retrain_pe_mod:                                 # :1141-1142
         nets.signal_pe.load_weights(os.path.join(args.out, 'best_models/signal_pe.h5'))
     bg = hostio.BackgroundWriter()             # serialisation + file writes of the cadence blocks leave the loop's thread
-    for i in range(0 if args.only_old_pe_model else args.pe_iter):                    # :1145, :1153-1173
-        pe_loss = bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch_size, rank=rank, world=world)
+    skip_pe = args.only_old_pe_model and not args.retrain_pe_mod                      # :1145
+    for i in range(0 if skip_pe else args.pe_iter):                                   # :1153-1173
+        pe_loss = bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch_size, cnn_noise_frac=args.cnn_noise_frac, rank=rank, world=world)
         if i % 5000 == 0 and i > 0 and rank == 0:
             nets.signal_pe.save(os.path.join(args.out, 'best_models/signal_pe.h5'), True, writer=bg)
         if i % args.pe_cadence == 0 and i > 0:
@@ -98,7 +103,7 @@ def main():
                         print('%d: [CNN sanity check vs lalinference: overlap beta %f]' % (i, score[2]), flush=True)
             else:
                 print('%d: [PE loss: %f, acc: %f]' % (i, pe_loss[0], pe_loss[1]), flush=True)
-    if not args.only_old_pe_model and args.pe_iter > 0 and rank == 0:
+    if not skip_pe and args.pe_iter > 0 and rank == 0:
         nets.signal_pe.save(os.path.join(args.out, 'best_models/signal_pe.h5'), True, writer=bg)     # so that --old-model finds the trained CNN
     print('Completed CNN PE')
 

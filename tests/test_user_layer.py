@@ -138,3 +138,23 @@ def test_callable_chisquare_loss_equals_scaled_mse():
         outs.append(pe.train_on_batch(x, y))
     for a, b in zip(outs[0][:3], outs[1][:3]):
         assert abs(b - 0.25 * a) <= 1e-6 * abs(a)
+
+
+@pytest.mark.gpu
+def test_build_and_compile_with_chi_loss_trains_the_generator_on_the_scripts_own_loss():
+    """chi_loss = True (bbhMahoGANy.py:97, :1106-1109): the combined model is compiled with chisquare_Loss; its reported loss is then the
+    scaled squared error of D(G(z)) against the labels, and only the generator's weights move."""
+    from gennet_amd import bbh, engine
+    n_pix, B = 64, 4
+    rng = np.random.RandomState(6)
+    event = rng.randn(n_pix, 1).astype(np.float32)
+    z = rng.uniform(-1, 1, (B, 100)).astype(np.float32)
+    engine.set_init_seed(8); engine.set_device_seed(1)
+    nets = bbh.build_and_compile(event, n_pix, chi_loss=True, n_sig=2.0)
+    assert nets.signal_discriminator_on_generator._loss_scales == [0.25]
+    d_before = [w.copy() for w in nets.signal_discriminator.get_weights()]
+    g_before = [w.copy() for w in nets.generator.get_weights()]
+    out = nets.signal_discriminator_on_generator.train_on_batch(z, np.ones(B, np.float32))
+    assert np.isfinite(out).all() and 0.0 <= out[0] <= 0.25 + 1e-6                 # (1 - p)^2 / 4 with p in [0, 1]
+    assert all(np.array_equal(a, b) for a, b in zip(d_before, nets.signal_discriminator.get_weights()))
+    assert any(not np.array_equal(a, b) for a, b in zip(g_before, nets.generator.get_weights()))
