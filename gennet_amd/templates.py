@@ -183,19 +183,44 @@ def gen_noise_device(fs, T_obs, psd, nb, seed, offset=0):
 
 
 def gen_masses(m_min=5.0, M_max=100.0, mdist='astro'):
-    """gw_template_maker.py:289-339 ('astro' and 'hunt_constrain'; 'gh' / 'metric' are not on the hot path)."""
-    log_m_max = np.log(M_max - m_min)
-    while True:
-        m12 = np.exp(np.log(m_min) + np.random.uniform(0, 1, 2) * (log_m_max - np.log(m_min)))
-        eta = m12[0] * m12[1] / (m12[0] + m12[1]) ** 2
-        mc = np.sum(m12) * eta ** (3.0 / 5.0)
-        flag = (np.sum(m12) < M_max) and np.all(m12 > m_min) and (m12[0] >= m12[1])
-        if mdist == 'hunt_constrain':
-            flag = flag and (m12[1] / m12[0] >= 0.5) and (mc >= 20.0) and (mc <= 35.0)
-        elif mdist != 'astro':
-            raise NotImplementedError('mass distribution %r' % (mdist,))
-        if flag:
-            return m12, mc, eta
+    """gw_template_maker.py:289-370, all four distributions, same draws from the numpy legacy stream per rejection trial:
+    'astro' / 'hunt_constrain' (:312-339: two log-uniform component masses per trial; the latter adds q >= 0.5, 20 <= mc <= 35),
+    'gh' (:341-351: q ~ U(1, 10), m2 ~ U(5, 75), m1 = q m2, both below 75), 'metric' (:353-367: total mass and eta from the
+    template-bank-metric densities).  Returns (m12, mc, eta) with mc, eta as floats (the reference's 'metric' branch returns them as
+    1-element arrays).  Pinned by tests/golden/masses_golden.npz (the reference's function executed on seeded streams)."""
+    if mdist in ('astro', 'hunt_constrain'):
+        log_m_max = np.log(M_max - m_min)
+        while True:
+            m12 = np.exp(np.log(m_min) + np.random.uniform(0, 1, 2) * (log_m_max - np.log(m_min)))
+            eta = m12[0] * m12[1] / (m12[0] + m12[1]) ** 2
+            mc = np.sum(m12) * eta ** (3.0 / 5.0)
+            flag = (np.sum(m12) < M_max) and np.all(m12 > m_min) and (m12[0] >= m12[1])
+            if mdist == 'hunt_constrain':
+                flag = flag and (m12[1] / m12[0] >= 0.5) and (mc >= 20.0) and (mc <= 35.0)
+            if flag:
+                return m12, mc, eta
+    if mdist == 'gh':
+        m12 = np.zeros(2)
+        while True:
+            q = np.random.uniform(1.0, 10.0, 1)
+            m12[1] = np.random.uniform(5.0, 75.0, 1)[0]
+            m12[0] = m12[1] * q[0]
+            if np.all(m12 < 75.0) and np.all(m12 > 5.0) and (m12[0] >= m12[1]):
+                eta = m12[0] * m12[1] / (m12[0] + m12[1]) ** 2
+                return m12, np.sum(m12) * eta ** (3.0 / 5.0), eta
+    if mdist == 'metric':
+        M_min = 2.0 * m_min
+        eta_min = m_min * (M_max - m_min) / M_max ** 2
+        while True:
+            # 1-element arrays as in the reference: numpy's array power and its scalar power differ in the last bit
+            M = (M_min ** (-7.0 / 3.0) - np.random.uniform(0, 1, 1) * (M_min ** (-7.0 / 3.0) - M_max ** (-7.0 / 3.0))) ** (-3.0 / 7.0)
+            eta = (eta_min ** (-2.0) - np.random.uniform(0, 1, 1) * (eta_min ** (-2.0) - 16.0)) ** (-1.0 / 2.0)
+            m12 = np.zeros(2)
+            m12[0] = (0.5 * M + M * np.sqrt(0.25 - eta))[0]
+            m12[1] = (M - m12[0])[0]
+            if (np.sum(m12) < M_max) and np.all(m12 > m_min) and (m12[0] >= m12[1]):
+                return m12, float((np.sum(m12) * eta ** (3.0 / 5.0))[0]), float(eta[0])
+    raise ValueError('unknown mass distribution %r (astro, hunt_constrain, gh, metric; gw_template_maker.py:368-370 prints and exits)' % (mdist,))
 
 
 def gen_par(fs, T_obs, mdist='astro', beta=[0.75, 0.95], gw_tmp=False):

@@ -23,6 +23,7 @@ indexing_golden.npz (sample indexing: north_star's "bit-exact for sample indexin
                    the python slice [ref_idx - par.idx - 11:], zero fill, window -- is the reference's own text.
   sim_data         gw_template_maker.py:632-740   executed as written (Nnoise = 0) on top of the functions above: the crop :695, the trim
                    quirk :718-722, the permutation :725-727, the event-like template appended last :730-739
+masses_golden.npz: gen_masses :289-370 for 'astro', 'hunt_constrain', 'gh', 'metric' on seeded streams (values and stream position)
 lalinf_pars_golden.npz (data/get_lalinf_pars.py, the posterior-column conversion in front of the posterior-driven synthesiser, row n3):
   the do_m1m2 and do_mc_M loops (:52-65, :69-84, located by their first / last statement) executed as written with sympy on supplied
   post_mc / post_q columns
@@ -99,6 +100,7 @@ def main():
     posterior_golden()
     indexing_golden()
     lalinf_pars_golden()
+    masses_golden()
 
 
 _PY2_PRINT = re.compile(r"^(\s*)(if verb:\s*)?print\s+'")
@@ -244,6 +246,24 @@ def posterior_golden():
     path = os.path.join(os.path.dirname(OUT), 'posterior_golden.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, 'beta =', beta)
+
+
+def masses_golden():
+    """gen_masses (gw_template_maker.py:289-370) executed as written for all four distributions on seeded legacy streams: 25 draws each,
+    and the next uniform afterwards (stream position)."""
+    ns = reference_namespace()
+    out = {}
+    for k, mdist in enumerate(('astro', 'hunt_constrain', 'gh', 'metric')):
+        np.random.seed(40 + k)
+        rows = []
+        for _ in range(25):
+            m12, mc, eta = ns['gen_masses'](5.0, 100.0, mdist)
+            rows.append([float(np.asarray(m12)[0]), float(np.asarray(m12)[1]), float(np.asarray(mc).reshape(-1)[0]), float(np.asarray(eta).reshape(-1)[0])])
+        out[mdist] = np.array(rows)
+        out[mdist + '_next'] = np.random.uniform(0, 1, 2)
+    dst = os.path.join(os.path.dirname(OUT), 'masses_golden.npz')
+    np.savez_compressed(dst, **out)
+    print('wrote', dst, {k: v.shape for k, v in out.items()})
 
 
 def lalinf_pars_golden():

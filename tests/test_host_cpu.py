@@ -291,3 +291,19 @@ def test_lalinf_posterior_conversion_matches_the_reference_executed_fixture(tmp_
         with open(str(tmp_path / 'data' / stem), 'rb') as f:
             a = pickle.load(f)
         assert a.shape == (2, 6) and np.array_equal(a, pars[key])
+
+
+def test_gen_masses_all_four_distributions_match_the_reference_executed_fixture():
+    """gw_template_maker.py:289-370 ('astro', 'hunt_constrain', 'gh', 'metric'): values bit for bit and the same stream position afterwards."""
+    from gennet_amd import templates as T
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'masses_golden.npz'))
+    for k, mdist in enumerate(('astro', 'hunt_constrain', 'gh', 'metric')):
+        np.random.seed(40 + k)
+        rows = []
+        for _ in range(25):
+            m12, mc, eta = T.gen_masses(5.0, 100.0, mdist)
+            rows.append([m12[0], m12[1], mc, eta])
+        assert np.array_equal(np.array(rows, np.float64), g[mdist]), mdist
+        assert np.array_equal(np.random.uniform(0, 1, 2), g[mdist + '_next']), mdist
+    with pytest.raises(ValueError):
+        T.gen_masses(5.0, 100.0, 'flat')
