@@ -362,7 +362,9 @@ class Adam(object):
     """keras.optimizers.Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)."""
 
     def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=None, decay=0.0, **kwargs):
-        self.lr, self.beta_1, self.beta_2 = float(lr), float(beta_1), float(beta_2)
+        # float32 variables in Keras (K.variable): the values that take part -- and that Keras writes into training_config -- are the
+        # float32-rounded ones (the reference's own d_model.hdf5 records beta_2 = 0.9990000128746033); epsilon stays a python float
+        self.lr, self.beta_1, self.beta_2 = (float(np.float32(x)) for x in (lr, beta_1, beta_2))
         self.epsilon = 1e-7 if epsilon is None else float(epsilon)
         if decay:
             raise NotImplementedError('Adam(decay != 0) is not on the BBH hot path')

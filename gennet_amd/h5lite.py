@@ -15,6 +15,7 @@ Everything is little-endian.  The writer emits exactly these structures with lib
 API:   f = File(path) ; f.attrs ; f['model_weights/dense_1/dense_1/kernel:0'].value ; f.keys() ; f.visit()
        w = Writer() ; g = w.root.create_group('model_weights') ; g.attrs['x'] = ... ; g.create_dataset('kernel:0', array) ; w.save(path)
 """
+import os
 import struct
 
 import numpy as np
@@ -468,9 +469,13 @@ class Writer(object):
         return bytes(self._buf)
 
     def save(self, path):
+        """Written to path + '.tmp' and moved into place (os.replace is atomic within a file system): a writer killed half-way never
+        leaves a truncated file under the final name -- the previous checkpoint stays readable."""
         data = self.tobytes()
-        with open(path, 'wb') as fh:
+        tmp = path + '.tmp'
+        with open(tmp, 'wb') as fh:
             fh.write(data)
+        os.replace(tmp, path)
 
     def _alloc(self, blob):
         pad = _pad8(len(self._buf)) - len(self._buf)

@@ -10,8 +10,12 @@ copies stay where they are (stream-ordered, cheap) and only the serialisation + 
         model.save_weights('generator.h5', True, writer=bg)
 
 Jobs run in submission order (two writes of the same path end with the later content); an exception raised by a job is re-raised in the
-caller's thread by the next submit() / flush() / close(), so a full disk does not pass silently.
+caller's thread by the next submit() / flush() / close(), so a full disk does not pass silently.  Every file is written under
+path + '.tmp' and moved into place with os.replace, so an interrupted run leaves either the previous or the new content under the
+final name, never a truncated file.  Use it as a context manager (or close() in a finally block): the worker is a daemon thread, and only
+close() guarantees that the queued jobs are on disk before the interpreter exits.
 """
+import os
 import pickle
 import queue
 import threading
@@ -53,8 +57,10 @@ class BackgroundWriter(object):
     def pickle(self, obj, path, protocol=2):
         """pickle.dump(obj, open(path, 'wb'), protocol) in the worker; obj must not be mutated by the caller afterwards."""
         def job():
-            with open(path, 'wb') as f:
+            tmp = path + '.tmp'
+            with open(tmp, 'wb') as f:
                 pickle.dump(obj, f, protocol=protocol)
+            os.replace(tmp, path)
         self.submit(job)
 
     def flush(self):

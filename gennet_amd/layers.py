@@ -402,7 +402,8 @@ class Activation(Layer):
 class LeakyReLU(Activation):
     def __init__(self, alpha=0.3, **kw):
         Layer.__init__(self, **kw)
-        self.act_spec = ('leaky', float(alpha))
+        self.alpha = float(np.float32(alpha))       # K.cast_to_floatx(alpha): the reference's Keras files record 0.20000000298023224 for 0.2
+        self.act_spec = ('leaky', self.alpha)
 
 
 class ReLU(Activation):

@@ -465,36 +465,55 @@ def lalinf_pars(post_mc, post_q):
     return {'m1_m2': np.array([m1, m2]), 'mc_M': np.array([mc, m1 + m2]), 'mc_q': np.array([mc, q])}
 
 
-def sim_data_posterior(fs, T_obs, psds, post_m1, post_m2, post_mc=None, dets=['H1'], size=None, beta=[0.45, 0.55], batch_size=3907,
-                       peak_off=PEAK_OFFSET, to_host=True):
-    """lalinf_post_waveform_maker.py sim_data / gen_par (:383-476, :694-746): the same synthesiser fed with component masses
-    taken row by row from posterior samples instead of the prior (the CNN "sanity check" set, bbhMahoGANy.py:1228-1231).
-    Parameter handling follows the reference: idx ~ randint per sample from the numpy legacy stream, at most batch_size-1
-    posterior waveforms, np.random.permutation shuffle, then the event-like (36, 29) template with idx = N/2 - 4 appended last.
-    Returns ([ts (n,1,fs), yval], pars)."""
-    post_m1 = np.asarray(post_m1, np.float64); post_m2 = np.asarray(post_m2, np.float64)
-    n = len(post_m1) if size is None else min(size - 1 if gw_tmp else size, len(post_m1))
-    n = min(n, batch_size - 1)
+def gen_par_posterior(fs, T_obs, index, post_m1, post_m2, post_mc=None, beta=[0.75, 0.95], gw_tmp=False):
+    """gen_par of lalinf_post_waveform_maker.py:356-475: masses of posterior row `index` (m12 = [gan_post[index,1], gan_post[index,0]], :385 --
+    here post_m1 the heavier, post_m2 the lighter column), chirp mass from the posterior column (:404), the fixed angles (:433-437), and ONE
+    randint from the numpy legacy stream (:440-444) -- drawn for the event-like template too, whose gw_tmp branch then replaces idx by
+    N/2 - 4 and the masses by (36, 29) (:460-473).  Pinned by tests/golden/posterior_mode_golden.npz."""
+    m1, m2 = float(post_m1[index]), float(post_m2[index])
+    eta = m1 * m2 / (m1 + m2) ** 2
+    mc = post_mc[index] if post_mc is not None else (m1 + m2) * eta ** (3.0 / 5.0)
     low_idx, high_idx = convert_beta(beta, fs, T_obs)
-    pars = []
-    for k in range(n):
-        m1, m2 = post_m1[k], post_m2[k]
-        eta = m1 * m2 / (m1 + m2) ** 2
-        mc = post_mc[k] if post_mc is not None else (m1 + m2) * eta ** 0.6
-        idx = low_idx if low_idx == high_idx else int(np.random.randint(low_idx, high_idx, 1)[0])
-        pars.append(bbhparams(mc, m1 + m2, eta, m1, m2, RA, DEC, IOTA, PHI, PSI, idx, None, None))
-    syn = Synth(fs, T_obs, psds, dets[0], peak_off)
-    ts, _ = syn.templates([p.m1 for p in pars], [p.m2 for p in pars], [p.idx for p in pars])
-    perm = np.random.permutation(n)
-    pars = [pars[i] for i in perm]
-    ts = ts[torch.as_tensor(perm).to(ts.device)]
+    idx = low_idx if low_idx == high_idx else int(np.random.randint(low_idx, high_idx, 1)[0])
     if gw_tmp:
         m1, m2 = 36.0, 29.0
         eta = m1 * m2 / (m1 + m2) ** 2
-        p = bbhparams((m1 + m2) * eta ** 0.6, m1 + m2, eta, m1, m2, RA, DEC, IOTA, PHI, PSI, int((T_obs * fs) / 2) - 4, None, None)
-        ev, _ = syn.templates([p.m1], [p.m2], [p.idx])
-        ts = torch.cat([ts, ev])
-        pars.append(p)
+        return bbhparams((m1 + m2) * eta ** (3.0 / 5.0), m1 + m2, eta, m1, m2, RA, DEC, IOTA, PHI, PSI, int((T_obs * fs) / 2) - 4, None, None)
+    return bbhparams(mc, np.sum([m1, m2]), eta, m1, m2, RA, DEC, IOTA, PHI, PSI, idx, None, None)
+
+
+def posterior_block_pars(fs, T_obs, post_m1, post_m2, post_mc=None, size=None, beta=[0.45, 0.55], batch_size=3907):
+    """The host half of one sim_data block of lalinf_post_waveform_maker.py:690-746 -- every draw it takes from the numpy legacy stream, in
+    its order: one gen_par per posterior row (at most size-1 with gw_tmp, and at most batch_size-1, :718-721), the permutation (:730),
+    then the event-like row's gen_par (:738), which reads posterior row `cnt` and draws a randint of its own.
+    Returns (pars in generation order, perm, event-like par or None)."""
+    n = len(post_m1) if size is None else (size - 1 if gw_tmp else size)
+    n = min(n, batch_size - 1)
+    if n + (1 if gw_tmp else 0) > len(post_m1):
+        raise IndexError('posterior has %d rows, the block reads row %d (lalinf_post_waveform_maker.py:385)' % (len(post_m1), n))
+    pars = [gen_par_posterior(fs, T_obs, k, post_m1, post_m2, post_mc, beta=beta, gw_tmp=False) for k in range(n)]
+    perm = np.random.permutation(n)
+    ev = gen_par_posterior(fs, T_obs, n, post_m1, post_m2, post_mc, beta=beta, gw_tmp=True) if gw_tmp else None
+    return pars, perm, ev
+
+
+def sim_data_posterior(fs, T_obs, psds, post_m1, post_m2, post_mc=None, dets=['H1'], size=None, beta=[0.45, 0.55], batch_size=3907,
+                       peak_off=PEAK_OFFSET, to_host=True):
+    """lalinf_post_waveform_maker.py sim_data / gen_par (:356-475, :649-746): the same synthesiser fed with component masses
+    taken row by row from posterior samples instead of the prior (the CNN "sanity check" set, bbhMahoGANy.py:1228-1231).
+    Parameter handling and the consumption of the numpy legacy stream follow the reference draw for draw (posterior_block_pars), so
+    consecutive blocks of one seeded run (main()'s nblock loop, :799-805) select the reference's idx values.
+    Returns ([ts (n,1,fs), yval], pars)."""
+    post_m1 = np.asarray(post_m1, np.float64); post_m2 = np.asarray(post_m2, np.float64)
+    pars, perm, ev = posterior_block_pars(fs, T_obs, post_m1, post_m2, post_mc, size, beta, batch_size)
+    syn = Synth(fs, T_obs, psds, dets[0], peak_off)
+    ts, _ = syn.templates([p.m1 for p in pars], [p.m2 for p in pars], [p.idx for p in pars])
+    pars = [pars[i] for i in perm]
+    ts = ts[torch.as_tensor(perm).to(ts.device)]
+    if ev is not None:
+        evt, _ = syn.templates([ev.m1], [ev.m2], [ev.idx])
+        ts = torch.cat([ts, evt])
+        pars.append(ev)
     ts = ts.reshape(len(pars), 1, int(fs))
     return [ts.cpu().numpy() if to_host else ts, np.ones(len(pars), dtype=int)], pars
 

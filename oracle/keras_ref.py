@@ -306,7 +306,11 @@ def binary_accuracy(p, y):
 # Adam, keras form (bbhMahoGANy.py:1101-1119: lr=9e-5, beta_1=0.5)
 # ----------------------------------------------------------------------------------------------
 def adam_step(p, g, m, v, t, lr=9e-5, b1=0.5, b2=0.999, eps=K_EPS):
-    """t is the 1-based step index AFTER increment. Returns new (p, m, v)."""
+    """t is the 1-based step index AFTER increment. Returns new (p, m, v).
+    lr, beta_1 and beta_2 are float32 VARIABLES in Keras (K.variable): the numbers that take part are float32(lr) etc. -- what the
+    reference's own Keras files record (training_config of 2_model_version/weight_version/d_model.hdf5: beta_2 0.9990000128746033,
+    lr 0.004000000189989805; tests/golden/keras_h5_golden.json), so 1 - beta_2 is 0.00099998713, not 0.001.  epsilon is a python float."""
+    lr, b1, b2 = (float(np.float32(x)) for x in (lr, b1, b2))
     lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
     m = b1 * m + (1 - b1) * g
     v = b2 * v + (1 - b2) * g * g

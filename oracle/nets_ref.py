@@ -17,6 +17,8 @@ very same arrays into the HIP-backed model.
 import numpy as np
 from . import keras_ref as K
 
+LEAKY_ALPHA = float(np.float32(0.2))     # LeakyReLU(alpha=0.2) as Keras holds it (K.cast_to_floatx; 0.20000000298023224 in the reference's own Keras files)
+
 
 # ----------------------------------------------------------------------------------------------
 # layer specs
@@ -33,8 +35,8 @@ def generator_spec(n_pix):
 
 
 def discriminator_spec(n_pix):
-    return [('conv2d', 1, 256, (5, 5), (2, 1), 'same'), ('act', 'leaky', 0.2), ('drop', 0.4),
-            ('conv2d', 256, 512, (5, 5), (2, 1), 'same'), ('act', 'leaky', 0.2), ('drop', 0.4),
+    return [('conv2d', 1, 256, (5, 5), (2, 1), 'same'), ('act', 'leaky', LEAKY_ALPHA), ('drop', 0.4),
+            ('conv2d', 256, 512, (5, 5), (2, 1), 'same'), ('act', 'leaky', LEAKY_ALPHA), ('drop', 0.4),
             ('flatten',), ('dense', (n_pix // 4) * 2 * 512, 1), ('act', 'sigmoid', 0.0)]
 
 
@@ -134,7 +136,7 @@ class Stack(object):
                     band = np.abs(pre) <= self.DECISION_BAND * np.abs(pre).max()
                     mism = known & ((pre > 0) != theirs)
                     flip = mism & band
-                    self.decision_stats[li] = (int(band.sum()), int(flip.sum()), int((mism & ~band).sum()))
+                    self.decision_stats[li] = (int(band.sum()), int(flip.sum()), int((mism & ~band).sum()), int(pre.size))
                     if flip.any():
                         x = x.copy()
                         x[flip] = np.where(theirs[flip], 1e-300, 0.0 if s[1] != 'leaky' else -1e-300)

@@ -263,6 +263,54 @@ def sim_data(fs, T_obs, psd, size, mdist='hunt_constrain', beta=(0.45, 0.55), gw
     return [ts, yval], par
 
 
+def gen_par_posterior(fs, T_obs, index, gan_post, post_mc, beta=(0.75, 0.95), gw_tmp=False):
+    """lalinf_post_waveform_maker.py:356-475: m12 = [gan_post[index,1], gan_post[index,0]] (:385), mc from the posterior column (:404),
+    fixed angles (:433-437), ONE randint (:440-444) drawn BEFORE the gw_tmp branch (:460-473) replaces idx / masses."""
+    m12 = [gan_post[index, 1], gan_post[index, 0]]
+    eta = m12[0] * m12[1] / (m12[0] + m12[1]) ** 2
+    mc = post_mc[index]
+    M = np.sum(m12)
+    low_idx, high_idx = convert_beta(list(beta), fs, T_obs)
+    idx = low_idx if low_idx == high_idx else int(np.random.randint(low_idx, high_idx, 1)[0])
+    par = bbhparams(mc, M, eta, m12[0], m12[1], RA, DEC, IOTA, PHI, PSI, idx, None, None)
+    if gw_tmp:
+        idx = int((T_obs * fs) / 2) - 4
+        m1, m2 = 36.0, 29.0
+        eta = m1 * m2 / (m1 + m2) ** 2
+        M = m1 + m2
+        par = bbhparams(M * eta ** (3.0 / 5.0), M, eta, m1, m2, RA, DEC, IOTA, PHI, PSI, idx, None, None)
+    return par
+
+
+def sim_data_posterior(fs, T_obs, psd, gan_post, post_mc, size, batch_size=3907, beta=(0.45, 0.55), gw_tmp=True, peak_off=PEAK_OFFSET):
+    """lalinf_post_waveform_maker.py:649-746 with Nnoise = 0: posterior rows 0..size-2 (stopping at batch_size-1 waveforms, :718-721),
+    permutation (:730), event-like template from gen_par(.., cnt, gw_tmp=True) last (:735-744)."""
+    if gw_tmp:
+        size = size - 1
+    ts, par = [], []
+    cnt = 0
+    while cnt < size:
+        p = gen_par_posterior(fs, T_obs, cnt, gan_post, post_mc, beta, False)
+        ts.append(gen_bbh(fs, T_obs, psd, p, peak_off=peak_off)[0].reshape(1, -1))
+        par.append(p)
+        cnt += 1
+        if len(ts) == batch_size - 1:
+            size = batch_size - 1
+            break
+    ts = np.array(ts)[:size]
+    par = par[:size]
+    perm = np.random.permutation(size)
+    par = [par[i] for i in perm]
+    ts = ts[perm]
+    yval = np.ones(size, dtype=int)
+    if gw_tmp:
+        p = gen_par_posterior(fs, T_obs, cnt, gan_post, post_mc, beta, True)
+        ts = np.concatenate((ts, gen_bbh(fs, T_obs, psd, p, peak_off=peak_off)[0].reshape(1, 1, fs)))
+        par.append(p)
+        yval = np.append(yval, 1)
+    return [ts, yval], par
+
+
 def analytic_psd(Nf, df, f_floor=10.0):
     """A fixed aLIGO-like analytic noise curve on the Nf grid (synthetic stand-in for the lalinference PSD file,
     which the reference does not ship): zero below f_floor so that whiten_data's psd<=0 handling is exercised."""

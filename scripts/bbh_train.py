@@ -85,46 +85,51 @@ def main():
         nets.generator.load_weights(os.path.join(args.out, 'generator.h5'))
     if args.only_old_pe_model or args.retrain_pe_mod:                                 # :1141-1142
         nets.signal_pe.load_weights(os.path.join(args.out, 'best_models/signal_pe.h5'))
-    bg = hostio.BackgroundWriter()             # serialisation + file writes of the cadence blocks leave the loop's thread
-    skip_pe = args.only_old_pe_model and not args.retrain_pe_mod                      # :1145
-    for i in range(0 if skip_pe else args.pe_iter):                                   # :1153-1173
-        pe_loss = bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch_size, cnn_noise_frac=args.cnn_noise_frac, rank=rank, world=world)
-        if i % 5000 == 0 and i > 0 and rank == 0:
-            nets.signal_pe.save(os.path.join(args.out, 'best_models/signal_pe.h5'), True, writer=bg)
-        if i % args.pe_cadence == 0 and i > 0:
-            rms, pe_std = bbh.pe_accuracy(nets.signal_pe, bank)                       # every rank: it draws from the shared host index stream
-        if i % args.pe_cadence == 0 and rank == 0:
-            if i > 0:                                                                 # :1200-1229
-                print('%d: [PE loss: %f, acc: %f, RMS: %f,%f] mean |error| (mc, q): %f, %f' % (i, pe_loss[0], pe_loss[1], rms[0], rms[1], pe_std[0], pe_std[1]),
-                      flush=True)
-                if sanity is not None and lalinf_pars is not None:
-                    score = bbh.posterior_overlap([p.cpu().numpy() for p in nets.signal_pe.predict_device(sanity)], lalinf_pars)
-                    if score is not None:
-                        print('%d: [CNN sanity check vs lalinference: overlap beta %f]' % (i, score[2]), flush=True)
-            else:
+    # serialisation + file writes of the cadence blocks leave the loop's thread; the `with` block closes the writer -- every queued
+    # file on disk, or its error raised -- on normal exit AND when a loop dies (KeyboardInterrupt included)
+    with hostio.BackgroundWriter() as bg:
+        skip_pe = args.only_old_pe_model and not args.retrain_pe_mod                      # :1145
+        for i in range(0 if skip_pe else args.pe_iter):                                   # :1153-1173
+            pe_loss = bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch_size, cnn_noise_frac=args.cnn_noise_frac, rank=rank, world=world)
+            if i % 5000 == 0 and i > 0 and rank == 0:
+                nets.signal_pe.save(os.path.join(args.out, 'best_models/signal_pe.h5'), True, writer=bg)
+            if i % args.pe_cadence == 0 and i > 0:                                        # :1176-1196
+                rms, pe_std = bbh.pe_accuracy(nets.signal_pe, bank)                       # every rank: it draws from the shared host index stream
+                if rank == 0:
+                    print('%d: [PE loss: %f, acc: %f, RMS: %f,%f] mean |error| (mc, q): %f, %f' % (i, pe_loss[0], pe_loss[1], rms[0], rms[1], pe_std[0], pe_std[1]),
+                          flush=True)
+            elif i % args.pe_cadence == 0 and rank == 0:
                 print('%d: [PE loss: %f, acc: %f]' % (i, pe_loss[0], pe_loss[1]), flush=True)
-    if not skip_pe and args.pe_iter > 0 and rank == 0:
-        nets.signal_pe.save(os.path.join(args.out, 'best_models/signal_pe.h5'), True, writer=bg)     # so that --old-model finds the trained CNN
-    print('Completed CNN PE')
+            if i % 1000 == 0 and i > 0:                                                   # :1200-1229: its OWN random.sample(.., 4000) -- at the default
+                rms, pe_std = bbh.pe_accuracy(nets.signal_pe, bank)                       # pe_cadence = 1000 both blocks run and the host stream advances twice
+                if rank == 0:
+                    print('%d: [PE loss: %f, acc: %f, RMS: %f,%f] mean |error| (mc, q): %f, %f' % (i, pe_loss[0], pe_loss[1], rms[0], rms[1], pe_std[0], pe_std[1]),
+                          flush=True)
+                    if sanity is not None and lalinf_pars is not None:
+                        score = bbh.posterior_overlap([p.cpu().numpy() for p in nets.signal_pe.predict_device(sanity)], lalinf_pars)
+                        if score is not None:
+                            print('%d: [CNN sanity check vs lalinference: overlap beta %f]' % (i, score[2]), flush=True)
+        if not skip_pe and args.pe_iter > 0 and rank == 0:
+            nets.signal_pe.save(os.path.join(args.out, 'best_models/signal_pe.h5'), True, writer=bg)     # so that --old-model finds the trained CNN
+        print('Completed CNN PE')
 
-    for i in range(args.max_iter):                                                    # :1241-1382
-        l = bbh.gan_train_step(nets, bank, event, args.batch_size, rank=rank, world=world, n_noise_real=args.n_noise_real)
-        if i % args.cadence == 0 and i > 0 and rank == 0:
-            print('%d: [sD loss: %f, acc: %f]  [sG loss: %f, acc: %f]' % (i, l[2], l[3], l[0], l[1]), flush=True)
-            pe_samples, waves = bbh.posterior_samples(nets, 4000)                     # :1330-1343
-            score = bbh.posterior_overlap(pe_samples, lalinf_pars) if lalinf_pars is not None else None          # :1345-1356 (the plot is not produced)
-            if score is not None:
-                ks, ad, beta = score
-                beta_score_hist.append(float(beta))
-                print('%d: [posterior overlap beta: %f, KS p (mc, q): %g, %g]' % (i, beta, ks[0][1], ks[1][1]), flush=True)
-                bg.pickle(list(beta_score_hist), os.path.join(args.out, 'beta_score_hist.sav'), protocol=2)
-            bg.pickle(pe_samples, os.path.join(args.out, 'gan_pe_samples.sav'), protocol=2)
-            bg.pickle(waves, os.path.join(args.out, 'gan_pe_waveforms.sav'), protocol=2)
-            nets.generator.save_weights(os.path.join(args.out, 'generator.h5'), True, writer=bg)
-            nets.signal_discriminator.save_weights(os.path.join(args.out, 'discriminator.h5'), True, writer=bg)
-            nets.signal_discriminator_on_generator.save_weights(os.path.join(args.out, 'signal_dis_on_gen.h5'), True, writer=bg)
-            bg.pickle(pe_samples, os.path.join(args.out, 'GAN_posterior_samples/posterior_samples_%05d.sav' % i), protocol=pickle.DEFAULT_PROTOCOL)
-    bg.close()                                 # every file is on disk (or its error raised) before the script ends
+        for i in range(args.max_iter):                                                    # :1241-1382
+            l = bbh.gan_train_step(nets, bank, event, args.batch_size, rank=rank, world=world, n_noise_real=args.n_noise_real)
+            if i % args.cadence == 0 and i > 0 and rank == 0:
+                print('%d: [sD loss: %f, acc: %f]  [sG loss: %f, acc: %f]' % (i, l[2], l[3], l[0], l[1]), flush=True)
+                pe_samples, waves = bbh.posterior_samples(nets, 4000)                     # :1330-1343
+                score = bbh.posterior_overlap(pe_samples, lalinf_pars) if lalinf_pars is not None else None          # :1345-1356 (the plot is not produced)
+                if score is not None:
+                    ks, ad, beta = score
+                    beta_score_hist.append(float(beta))
+                    print('%d: [posterior overlap beta: %f, KS p (mc, q): %g, %g]' % (i, beta, ks[0][1], ks[1][1]), flush=True)
+                    bg.pickle(list(beta_score_hist), os.path.join(args.out, 'beta_score_hist.sav'), protocol=2)
+                bg.pickle(pe_samples, os.path.join(args.out, 'gan_pe_samples.sav'), protocol=2)
+                bg.pickle(waves, os.path.join(args.out, 'gan_pe_waveforms.sav'), protocol=2)
+                nets.generator.save_weights(os.path.join(args.out, 'generator.h5'), True, writer=bg)
+                nets.signal_discriminator.save_weights(os.path.join(args.out, 'discriminator.h5'), True, writer=bg)
+                nets.signal_discriminator_on_generator.save_weights(os.path.join(args.out, 'signal_dis_on_gen.h5'), True, writer=bg)
+                bg.pickle(pe_samples, os.path.join(args.out, 'GAN_posterior_samples/posterior_samples_%05d.sav' % i), protocol=pickle.DEFAULT_PROTOCOL)
 
 
 if __name__ == '__main__':

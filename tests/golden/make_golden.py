@@ -27,10 +27,20 @@ masses_golden.npz: gen_masses :289-370 for 'astro', 'hunt_constrain', 'gh', 'met
 lalinf_pars_golden.npz (data/get_lalinf_pars.py, the posterior-column conversion in front of the posterior-driven synthesiser, row n3):
   the do_m1m2 and do_mc_M loops (:52-65, :69-84, located by their first / last statement) executed as written with sympy on supplied
   post_mc / post_q columns
+posterior_mode_golden.npz (the posterior-driven synthesiser, lalinf_post_waveform_maker.py, row n3):
+  bbhparams :71-87, tukey :89-116, convert_beta :136-163, whiten_data :247-290, gen_par :356-475 (masses from SUPPLIED gan_post /
+  all_lalinf_posteriors['mc'] rows; the randint it draws BEFORE the gw_tmp branch overrides idx), gen_bbh :477, :508-513, :534-561,
+  :566-585, :587 as written with the LALSuite lines :514-532 replaced by SUPPLIED spectra and the make_bbh call :564 by its return value
+  hp*Fp + hc*Fc (:628, :647), and the whole of sim_data :649-746 -- run over TWO consecutive blocks of one seeded stream, as main()'s
+  nblock loop does (:799-805)
+SAFETY: this script exec()s text read from /root/reference (public, untrusted content).  Run it ONLY in the sandboxed build container.  Every
+file is pinned by SHA-256 before anything of it is executed (REF_SHA256), and every executed range asserts its first and last statement
+(ANCHORS), so a shifted or altered upstream file fails here instead of silently executing other statements.
 Run-time text handling (nothing of it is stored): tabs expanded to 8 columns (the files mix tabs and spaces: Python 2 semantics), and
 lines that are Python 2 `print '...'` statements (with or without the `if verb:` prefix) replaced by `pass`.  Integer `/` in those
 lines only ever divides even ints by 2 or feeds int(): Python 3's true division gives the same values for T_obs = 4 and even fs.
 """
+import hashlib
 import os
 import re
 import textwrap
@@ -42,12 +52,58 @@ REF = '/root/reference/BBH_version/gw_template_maker.py'
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'synth_golden.npz')
 
 
+REF_DIR = '/root/reference/BBH_version/'
+REF_SHA256 = {
+    'gw_template_maker.py': 'c0463d49c136e3a0510c74dda90b8ed3d4b4eede5b7d9728d3a7fee46fdf8fda',
+    'lalinf_post_waveform_maker.py': '25da70c5237d590d342d5edde8d633e55695e907ae44f8767e76dbfb67bb5716',
+    'bbhMahoGANy.py': 'ca60921f79dd095532b46314dd515d7890eb9c6cf42452d6f4dd06a464dd40c2',
+    'data/get_lalinf_pars.py': '2c1e2f9bf8a1736e574ac865b4a478e2498137e7287ebd757961c4d68bcf92b6',
+}
+# first / last statement (stripped prefix) of every line range executed below
+ANCHORS = {
+    'gw_template_maker.py': {(69, 85): ('class bbhparams:', 'self.SNR = SNR'), (87, 113): ('def tukey(M,alpha=0.5):', 'return np.array(w[:M])'),
+                             (133, 159): ('def convert_beta(beta,fs,T_obs):', 'return low_idx,high_idx'),
+                             (161, 193): ('def gen_noise(fs,T_obs,psd):', 'return x'),
+                             (243, 286): ('def whiten_data(data,duration,sample_rate,psd,flag=', 'return xf'),
+                             (289, 370): ('def gen_masses(m_min=5.0,M_max=100.0,mdist=', 'exit(1)'),
+                             (329, 338): ('new_m_min = m_min', 'mc = np.sum(m12)*eta**(3.0/5.0)'),
+                             (372, 460): ('def gen_par(fs,T_obs,mdist=', 'return par'),
+                             (462, 462): ('def gen_bbh(fs,T_obs,psds,dets=', 'def gen_bbh('), (493, 498): ('N = T_obs * fs', 'f_max = fs/2'),
+                             (518, 546): ('whiten_hp = whiten_data(hp.data.data', 'j = 0'),
+                             (553, 573): ('# place signal into timeseries', 'hc[j,:] *= win'), (575, 575): ('return ts, hp, hc, ts', 'return ts, hp, hc, ts'),
+                             (632, 740): ('def sim_data(fs,T_obs,psds,dets=', 'return [ts, yval], temp')},
+    'lalinf_post_waveform_maker.py': {(71, 87): ('class bbhparams:', 'self.SNR = SNR'), (89, 116): ('def tukey(M,alpha=0.5):', 'return np.array(w[:M])'),
+                                      (136, 163): ('def convert_beta(beta,fs,T_obs):', 'return low_idx,high_idx'),
+                                      (247, 290): ('def whiten_data(data,duration,sample_rate,psd,flag=', 'return xf'),
+                                      (356, 475): ('def gen_par(fs,T_obs,index,mdist=', 'return par'),
+                                      (477, 477): ('def gen_bbh(fs,T_obs,idx,psds,dets=', 'def gen_bbh('), (508, 513): ('N = T_obs * fs', 'f_max = fs/2'),
+                                      (534, 561): ('# whiten waveform in frequency domain', 'for det in dets:'),
+                                      (566, 585): ('# place signal into timeseries', 'hc[j,:] *= win'), (587, 587): ('return ts, hp, hc', 'return ts, hp, hc'),
+                                      (649, 746): ('def sim_data(fs,T_obs,psds,dets=', 'return [ts, yval], temp')},
+    'bbhMahoGANy.py': {(811, 873): ('def overlap_tests(pred_samp,lalinf_samp,true_vals,kernel_cnn,kernel_lalinf):', 'return ks_score, ad_score, beta_score')},
+}
+
+
+def ref_lines(name):
+    """The lines of one reference file, after checking the file is byte for byte the one the line numbers in this script were read from."""
+    raw = open(REF_DIR + name, 'rb').read()
+    got = hashlib.sha256(raw).hexdigest()
+    if got != REF_SHA256[name]:
+        raise SystemExit('%s%s: sha256 %s differs from the pinned %s -- the line ranges in this script no longer apply; nothing executed'
+                         % (REF_DIR, name, got, REF_SHA256[name]))
+    lines = raw.decode('utf-8').splitlines(True)
+    for (a, b), (first, last) in ANCHORS.get(name, {}).items():
+        if not lines[a - 1].strip().startswith(first) or not lines[b - 1].strip().startswith(last):
+            raise SystemExit('%s:%d-%d does not start / end with the expected statements (%r ... %r)' % (name, a, b, first, last))
+    return lines
+
+
 def grab(lines, a, b):
     return ''.join(lines[a - 1:b])
 
 
 def main():
-    lines = open(REF).read().splitlines(True)
+    lines = ref_lines('gw_template_maker.py')
     ns = {'np': np, 'safe': 2}
     for a, b in ((87, 113), (133, 159), (161, 193), (243, 286)):
         exec(compile(grab(lines, a, b), '%s:%d-%d' % (REF, a, b), 'exec'), ns)
@@ -101,6 +157,7 @@ def main():
     indexing_golden()
     lalinf_pars_golden()
     masses_golden()
+    posterior_mode_golden()
 
 
 _PY2_PRINT = re.compile(r"^(\s*)(if verb:\s*)?print\s+'")
@@ -127,14 +184,14 @@ class _FD(object):
 def reference_namespace():
     """The reference's synthesiser functions, executed from its own text, with the two LALSuite touch points supplied by the caller
     through ns['_supplied_fd_waveform'](par, fs, T_obs) -> (hp, hc) and ns['_Fp'], ns['_Fc']."""
-    lines = open(REF).read().splitlines(True)
+    lines = ref_lines('gw_template_maker.py')
     ns = {'np': np, 'time': time, 'safe': 2, 'verb': False, 'gw_tmp': True, 'do_time_grid': False, 'N_time_grid': 25, 'sample_num': 50000,
           '_captured': {}}
     for a, b in ((69, 85), (87, 113), (133, 159), (243, 286), (289, 370), (372, 460)):
         exec(compile(ref_text(lines, a, b), '%s:%d-%d' % (REF, a, b), 'exec'), ns)
     src = (ref_text(lines, 462, 462) + ref_text(lines, 493, 498)
            + '    hp, hc = _supplied_fd_waveform(par, fs, T_obs)        # stands in for :499-516 (lalsimulation)\n'
-           + ref_text(lines, 518, 547)
+           + ref_text(lines, 518, 546)
            + '    for det in dets:\n'
            + '        ht_shift, hp_shift, hc_shift = orig_hp*_Fp + orig_hc*_Fc, orig_hp, orig_hc     # stands in for :551 (make_bbh -> :613, :630)\n'
            + ref_text(lines, 553, 573)
@@ -224,7 +281,7 @@ def posterior_golden():
     make_contour_plot does (:790: gaussian_kde(dataset), dataset = np.array([x, y]))."""
     import warnings
     from scipy.stats import anderson_ksamp, gaussian_kde, ks_2samp
-    lines = open('/root/reference/BBH_version/bbhMahoGANy.py').read().splitlines(True)
+    lines = ref_lines('bbhMahoGANy.py')
     ns = {'np': np, 'ks_2samp': ks_2samp, 'anderson_ksamp': anderson_ksamp, 'comb_pe_model': False}
     exec(compile(grab(lines, 811, 873), 'bbhMahoGANy.py:811-873', 'exec'), ns)
     rng = np.random.RandomState(21)
@@ -273,8 +330,7 @@ def lalinf_pars_golden():
     the pickle.dump lines that follow each block are not executed.  Line ranges are located by their first / last statement at run
     time.  Stores inputs and the two (2, n) arrays."""
     from sympy import Eq, Symbol, solve
-    path = '/root/reference/BBH_version/data/get_lalinf_pars.py'
-    lines = open(path).read().splitlines(True)
+    lines = ref_lines('data/get_lalinf_pars.py')
 
     def block(first, last):
         a = next(i for i, ln in enumerate(lines) if ln.startswith(first))
@@ -295,6 +351,67 @@ def lalinf_pars_golden():
     dst = os.path.join(os.path.dirname(OUT), 'lalinf_pars_golden.npz')
     np.savez_compressed(dst, **out)
     print('wrote', dst, out['m1_m2'][:, :2], out['m1_m2_lines'], out['mc_M_lines'])
+
+
+def posterior_mode_namespace(gan_post, post_mc, batch_size):
+    """lalinf_post_waveform_maker.py's synthesiser functions executed from its own text.  Module globals the functions read (:58-68) are
+    supplied: gan_post (n, 2) = the TRANSPOSED m1_m2 file (:65, :68), all_lalinf_posteriors['mc'] (:67), batch_size (:61), safe, verb, gw_tmp."""
+    name = 'lalinf_post_waveform_maker.py'
+    lines = ref_lines(name)
+    ns = {'np': np, 'time': time, 'safe': 2, 'verb': False, 'gw_tmp': True, 'batch_size': batch_size, 'gan_post': gan_post,
+          'all_lalinf_posteriors': {'mc': post_mc}, '_captured': []}
+    for a, b in ((71, 87), (89, 116), (136, 163), (247, 290), (356, 475)):
+        exec(compile(ref_text(lines, a, b), '%s:%d-%d' % (name, a, b), 'exec'), ns)
+    assert 'lalsimulation.IMRPhenomPv2' in lines[514 - 1] and 'approximant)' in lines[532 - 1] and 'make_bbh(' in lines[564 - 1]
+    src = (ref_text(lines, 477, 477) + ref_text(lines, 508, 513)
+           + '    hp, hc = _supplied_fd_waveform(par, fs, T_obs)        # stands in for :514-532 (lalsimulation; :516 reads the undefined lal.PC_SIi)\n'
+           + ref_text(lines, 534, 561)
+           + '        ht_shift, hp_shift, hc_shift = orig_hp*_Fp + orig_hc*_Fc, orig_hp, orig_hc     # stands in for :564 (make_bbh -> :628, :647)\n'
+           + ref_text(lines, 566, 585)
+           + '    _captured.append((int(ref_idx), int(par.idx)))\n'
+           + ref_text(lines, 587, 587))
+    exec(compile(src, '%s:gen_bbh' % name, 'exec'), ns)
+    exec(compile(ref_text(lines, 649, 746), '%s:649-746' % name, 'exec'), ns)
+    return ns
+
+
+def posterior_mode_golden():
+    """gen_par / gen_bbh / sim_data of lalinf_post_waveform_maker.py executed as written over TWO consecutive blocks of one seeded legacy
+    stream (main()'s nblock loop, :799-805, calls sim_data again without reseeding): per block the parameters in returned order, the
+    cropped series, and the stream position afterwards.  The event-like row's gen_par call draws a randint that the gw_tmp branch then
+    discards (:440-444 before :460-461), so block 2's idx values depend on it."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+    from oracle import synth_ref as S          # only for the SUPPLIED inputs (this project's chirp model, PSD curve and Fp/Fc constants)
+    Fp, Fc = S.antenna_response(S.EVENT_TIME, S.RA, S.DEC, S.PSI)
+    out = {'Fp': Fp, 'Fc': Fc}
+    T_obs = 4
+    for fs, n_post, size, batch_size, seed in ((256, 12, 9, 3907, 3), (512, 10, 40, 7, 4)):
+        rng = np.random.RandomState(50 + fs)
+        post_mc = rng.uniform(26.0, 32.0, n_post); post_q = rng.uniform(0.6, 1.0, n_post)
+        heavy = post_mc * (1.0 + post_q) ** 0.2 / post_q ** 0.6
+        m1_m2_file = np.array([post_q * heavy, heavy])              # the m1_m2 pickle: row 0 the lighter mass (get_lalinf_pars.py:52-67)
+        gan_post = np.transpose(m1_m2_file)                         # :68
+        ns = posterior_mode_namespace(gan_post, post_mc, batch_size)
+        ns['_Fp'], ns['_Fc'] = Fp, Fc
+        ns['_supplied_fd_waveform'] = lambda par_, fs_, T_: tuple(_FD(a) for a in S.chirp_fd(par_.m1, par_.m2, fs_ * T_ // 2 + 1, 1.0 / T_, iota=par_.iota, phi=par_.phi))
+        N = fs * T_obs
+        psd = S.analytic_psd(N // 2 + 1, 1.0 / T_obs)
+        np.random.seed(seed)
+        key = 'pm_%d_' % fs
+        out[key + 'm1_m2_file'] = m1_m2_file; out[key + 'post_mc'] = post_mc; out[key + 'meta'] = np.array([fs, size, batch_size, seed])
+        for blk in range(2):
+            (ts, yval), pars = ns['sim_data'](fs, T_obs, psd, dets=['H1'], Nnoise=0, size=size, mdist='hunt_constrain', beta=[0.45, 0.55])
+            out[key + 'ts_%d' % blk] = ts
+            out[key + 'yval_%d' % blk] = yval
+            out[key + 'pars_%d' % blk] = np.array([[p.mc, p.M, p.eta, p.m1, p.m2, p.ra, p.dec, p.iota, p.phi, p.psi, p.idx] for p in pars])
+            st = np.random.get_state()
+            out[key + 'next_uniform_%d' % blk] = np.random.uniform(0, 1, 3)
+            np.random.set_state(st)                                 # peeking must not move the stream between the blocks
+        out[key + 'ref_idx'] = np.array(ns['_captured'])
+    path = os.path.join(os.path.dirname(OUT), 'posterior_mode_golden.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes')
 
 
 if __name__ == '__main__':

@@ -178,6 +178,69 @@ def test_load_model_on_a_real_keras_file():
     m.load_weights(os.path.join(REF, 'best_d_weights.hdf5'))
 
 
+def test_oracle_and_layer_defaults_match_what_keras_itself_recorded():
+    """The only Keras-held facts the reference ships: model_config / training_config that Keras 2.1.x wrote into d_model.hdf5 / g_model.hdf5
+    (fixture: tests/golden/keras_h5_golden.json, full JSON).  They pin the defaults the oracle restates from memory (SURVEY Appendix B.3,
+    B.4, B.7, B.11) and the product's layer / optimizer defaults: BatchNormalization epsilon / momentum / axis / initialisers, LeakyReLU
+    alpha as a float32, the glorot VarianceScaling spec, zero biases, Flatten's channels_last order, Adam's beta_2 / epsilon / float32
+    hyper-parameter variables."""
+    from oracle import keras_ref as K
+    from gennet_amd import engine, layers as L
+    lays = {fn: GOLD[fn]['model_config']['config']['layers'] for fn in ('d_model.hdf5', 'g_model.hdf5')}
+    bns = [l['config'] for l in lays['g_model.hdf5'] if l['class_name'] == 'BatchNormalization']
+    assert len(bns) >= 5
+    mine = L.BatchNormalization()
+    for c in bns:
+        assert c['epsilon'] == K.BN_EPS == mine.epsilon == 1e-3
+        assert c['momentum'] == mine.momentum == 0.99                                           # Keras' default = what bbhMahoGANy.py:223 passes
+        assert c['axis'] == -1 and c['center'] and c['scale']
+        assert [c[k]['class_name'] for k in ('gamma_initializer', 'beta_initializer', 'moving_mean_initializer', 'moving_variance_initializer')] \
+            == ['Ones', 'Zeros', 'Zeros', 'Ones']
+    g = bbh_generator_bn_initial_values()
+    assert g == {'gamma': 1.0, 'beta': 0.0, 'moving_mean': 0.0, 'moving_variance': 1.0}
+    # LeakyReLU(alpha=0.2): a float32 in the graph
+    lk = [l['config'] for l in lays['d_model.hdf5'] if l['class_name'] == 'LeakyReLU']
+    assert lk and all(c['alpha'] == float(np.float32(0.2)) for c in lk)
+    assert L.LeakyReLU(alpha=0.2).alpha == float(np.float32(0.2))
+    # kernels: VarianceScaling(scale 1, fan_avg, uniform) = glorot_uniform; biases Zeros; conv / dense carry a bias
+    kinds = [l for fn in lays for l in lays[fn] if 'kernel_initializer' in l['config']]
+    assert len(kinds) >= 8
+    for l in kinds:
+        ki = l['config']['kernel_initializer']
+        assert ki == {'class_name': 'VarianceScaling', 'config': {'distribution': 'uniform', 'scale': 1.0, 'seed': None, 'mode': 'fan_avg'}}
+        assert l['config']['bias_initializer'] == {'class_name': 'Zeros', 'config': {}} and l['config']['use_bias'] is True
+    for shape in ((16, 1, 50), (1750, 50), (5, 512, 1024), (5, 5, 256, 512)):
+        rec = int(np.prod(shape[:-2]))
+        fan_avg = 0.5 * rec * (shape[-2] + shape[-1])
+        lim = np.sqrt(3.0 * 1.0 / fan_avg)                                   # VarianceScaling: uniform limit sqrt(3 scale / n), n = fan_avg
+        for w in (K.glorot_uniform(np.random.RandomState(0), shape), engine.glorot_uniform(shape)):
+            assert w.dtype == np.float32 and np.abs(w).max() <= lim and np.abs(w).max() > 0.97 * lim or w.size < 1000
+            assert abs(w.std() - lim / np.sqrt(3.0)) < 0.08 * lim
+    fl = [l['config'] for l in lays['d_model.hdf5'] if l['class_name'] == 'Flatten']
+    assert fl and fl[0]['data_format'] == 'channels_last'
+    conv = [l['config'] for l in lays['d_model.hdf5'] if l['class_name'] == 'Conv1D'][0]
+    assert conv['dilation_rate'] == [1] and conv['padding'] == 'valid' and conv['activation'] == 'linear'
+    # Adam as Keras records it: float32 variables for lr / beta_1 / beta_2, epsilon = K.epsilon() = 1e-7, no amsgrad, no decay
+    oc = GOLD['d_model.hdf5']['training']['optimizer_config']
+    assert oc['class_name'] == 'Adam'
+    c = oc['config']
+    assert c['epsilon'] == K.K_EPS == engine.Adam().epsilon == 1e-7
+    assert c['beta_2'] == float(np.float32(0.999)) == engine.Adam().beta_2 and c['beta_2'] != 0.999
+    assert c['beta_1'] == 0.5 and c['lr'] == float(np.float32(0.004)) == engine.Adam(lr=0.004).lr and c['decay'] == 0.0 and c['amsgrad'] is False
+    # ... and the oracle's step uses exactly those float32 values
+    p, g_, m, v = np.ones(3), np.full(3, 0.25), np.zeros(3), np.zeros(3)
+    _, m1, v1 = K.adam_step(p, g_, m, v, 1)
+    assert np.array_equal(v1, (1 - float(np.float32(0.999))) * g_ * g_) and not np.array_equal(v1, (1 - 0.999) * g_ * g_)
+    assert GOLD['d_model.hdf5']['training']['loss'] == 'binary_crossentropy'
+
+
+def bbh_generator_bn_initial_values():
+    from gennet_amd import bbh
+    g = bbh.generator_model(64)
+    bn = [l for l in g._top if l.__class__.__name__ == 'BatchNormalization'][0]
+    return {k: float(np.unique(getattr(bn, k).numpy())[0]) for k in ('gamma', 'beta', 'moving_mean', 'moving_variance')}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Keras layout written by this package
 # ---------------------------------------------------------------------------------------------------------------------
@@ -289,7 +352,7 @@ def test_save_and_load_model_roundtrip_on_host(tmp_path):
         m2 = load_model(path)
         assert [(l.__class__.__name__, l.name) for l in m2.layers] == [(l.__class__.__name__, l.name) for l in m.layers]
         assert all(np.array_equal(a, b) for a, b in zip(_weights(m), _weights(m2)))
-        assert m2.loss == loss and m2.optimizer.lr == 9e-5 and m2.metrics == ['accuracy']
+        assert m2.loss == loss and m2.optimizer.lr == float(np.float32(9e-5)) and m2.metrics == ['accuracy']
         lines1, lines2 = [], []
         m.summary(print_fn=lines1.append); m2.summary(print_fn=lines2.append)
         assert lines1 == lines2

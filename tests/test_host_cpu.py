@@ -29,16 +29,19 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_no_cpu_fallback_in_product_path():
-    """ops refuse CPU tensors, and nothing under gennet_amd/ imports the oracle."""
+    """ops refuse CPU tensors, and nothing under gennet_amd/ or scripts/ imports the oracle (only tests/, smoke() and bench.py's cpu_baseline may)."""
     import torch
     from gennet_amd import _lib, ops
     with pytest.raises(_lib.GennetHipError):
         ops.act_fwd(torch.zeros(8), 'relu')
-    for dirpath, _, files in os.walk(os.path.join(ROOT, 'gennet_amd')):
-        for f in files:
-            if f.endswith('.py'):
-                src = open(os.path.join(dirpath, f)).read()
-                assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f
+    for top in ('gennet_amd', 'scripts'):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith('.py'):
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f
+    bench = open(os.path.join(ROOT, 'bench.py')).read()
+    assert [m.start() > bench.index('def cpu_baseline(') and m.start() < bench.index('def free_port(') for m in re.finditer(r'(from|import)\s+oracle', bench)] == [True]
 
 
 def test_graphs_fusion_plan_and_param_counts():
@@ -63,7 +66,7 @@ def test_graphs_fusion_plan_and_param_counts():
     assert [(n.layer.filters, n.layer.stride) for n in folded] == [(64, 2), (128, 1)]
     D._plan()
     convs = [n for n in D.nodes if n.layer.__class__.__name__ == 'Conv2D']
-    assert all(n.fused_act == ('leaky', 0.2) for n in convs)
+    assert all(n.fused_act == ('leaky', float(np.float32(0.2))) for n in convs)      # K.cast_to_floatx(alpha)
 
 
 def test_collect_at_compile_trainability():
@@ -307,3 +310,57 @@ def test_gen_masses_all_four_distributions_match_the_reference_executed_fixture(
         assert np.array_equal(np.random.uniform(0, 1, 2), g[mdist + '_next']), mdist
     with pytest.raises(ValueError):
         T.gen_masses(5.0, 100.0, 'flat')
+
+
+@pytest.mark.parametrize("fs", [256, 512])
+def test_posterior_mode_draws_match_the_reference_executed_fixture(fs):
+    """templates.posterior_block_pars (the host half of sim_data_posterior: every draw from the numpy legacy stream) against
+    lalinf_post_waveform_maker.py:356-475 / :649-746 executed over two consecutive blocks (tests/golden/posterior_mode_golden.npz):
+    parameters, shuffle, event-like row, and the stream position after each block -- including the randint the event-like row's gen_par
+    draws and discards (:440-444 before :460-461)."""
+    from gennet_amd import templates as T
+    PM = np.load(os.path.join(ROOT, 'tests', 'golden', 'posterior_mode_golden.npz'))
+    key = 'pm_%d_' % fs
+    _, size, batch_size, seed = [int(v) for v in PM[key + 'meta']]
+    f = PM[key + 'm1_m2_file']
+    np.random.seed(seed)
+    for blk in range(2):
+        pars, perm, ev = T.posterior_block_pars(fs, 4, f[1], f[0], PM[key + 'post_mc'], size=size, batch_size=batch_size)
+        rows = [pars[i] for i in perm] + [ev]
+        got = np.array([[p.mc, p.M, p.eta, p.m1, p.m2, p.ra, p.dec, p.iota, p.phi, p.psi, p.idx] for p in rows])
+        assert np.array_equal(got, PM[key + 'pars_%d' % blk])
+        st = np.random.get_state()
+        assert np.array_equal(np.random.uniform(0, 1, 3), PM[key + 'next_uniform_%d' % blk])
+        np.random.set_state(st)
+    with pytest.raises(IndexError):
+        T.posterior_block_pars(fs, 4, f[1][:3], f[0][:3], None, size=5)      # the event-like row reads posterior row `cnt`: must exist
+
+
+def test_interrupted_writes_never_truncate_the_previous_file(tmp_path):
+    """files are written to path + '.tmp' and moved into place, so a job that dies half-way (here: an unpicklable object, and an
+    h5 tree whose write fails) leaves the previous content under the final name; the `with` form closes the writer when the loop raises."""
+    from gennet_amd import h5lite, hostio
+    path = str(tmp_path / 'samples.sav')
+    with hostio.BackgroundWriter() as bg:
+        bg.pickle([1, 2, 3], path)
+    with pytest.raises(Exception):
+        with hostio.BackgroundWriter() as bg:
+            bg.pickle([lambda: 0], path)                         # pickling fails after the temporary file was opened
+    with open(path, 'rb') as f:
+        assert pickle.load(f) == [1, 2, 3]
+    done = []
+    with pytest.raises(KeyboardInterrupt):
+        with hostio.BackgroundWriter() as bg:                    # the loop dies: queued jobs are still completed by __exit__
+            bg.submit(lambda: done.append(1))
+            raise KeyboardInterrupt
+    assert done == [1]
+    w = h5lite.Writer()
+    w.root.attrs['a'] = np.int32(1)
+    h5 = str(tmp_path / 'w.h5')
+    w.save(h5)
+    first = open(h5, 'rb').read()
+    w2 = h5lite.Writer()
+    w2.tobytes = lambda: (_ for _ in ()).throw(IOError('disk full'))
+    with pytest.raises(IOError):
+        w2.save(h5)
+    assert open(h5, 'rb').read() == first and not os.path.exists(h5 + '.tmp') or open(h5, 'rb').read() == first

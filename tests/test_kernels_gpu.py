@@ -377,10 +377,11 @@ def test_adam_keras_form():
     for t in (1, 2, 3):
         gr = f32(rng.randn(n) * 0.01)
         pr, m, v = K.adam_step(pr, gr, m, v, t)
-        lr_t = 9e-5 * np.sqrt(1 - 0.999 ** t) / (1 - 0.5 ** t)
+        lr32, b2 = float(np.float32(9e-5)), float(np.float32(0.999))
+        lr_t = lr32 * np.sqrt(1 - b2 ** t) / (1 - 0.5 ** t)
         ops.adam_step(pt, g(gr), mt, vt, lr_t, 0.5, 0.999, 1e-7)
-    # (1 - beta_2) is evaluated in fp32 like TF does: 1 - 0.999f carries a 3e-5 relative error into v
-    close(pt, pr, 1e-6); close(mt, m, 1e-5); close(vt, v, 1e-4)
+    # beta_2 is the float32 variable 0.999f on both sides (1 - 0.999f = 0.00099998713), so v agrees to fp32 rounding
+    close(pt, pr, 1e-6); close(mt, m, 1e-6); close(vt, v, 2e-6)
 
 
 def test_rng_fills_and_gather():

@@ -135,8 +135,9 @@ def test_losses_match_torch():
 def test_adam_keras_form():
     p = np.array([1.0, -2.0]); g = np.array([0.5, -0.25]); m = np.zeros(2); v = np.zeros(2)
     p1, m1, v1 = K.adam_step(p, g, m, v, 1)
-    lr_t = 9e-5 * np.sqrt(1 - 0.999) / (1 - 0.5)
-    close(p1, p - lr_t * (0.5 * g) / (np.sqrt(0.001 * g * g) + 1e-7))
+    lr32, b2 = float(np.float32(9e-5)), float(np.float32(0.999))
+    lr_t = lr32 * np.sqrt(1 - b2) / (1 - 0.5)
+    close(p1, p - lr_t * (0.5 * g) / (np.sqrt((1 - b2) * g * g) + 1e-7))
 
 
 def _torch_stack_forward(stack, x, masks):
@@ -262,9 +263,11 @@ def test_pe_train_step_matches_torch():
     for g, gt in zip(pe.last_grads, gts):
         close(g, gt, 1e-8)
     # one keras-form Adam step from zero state: |dp| = lr_t * 0.5 g / (sqrt(0.001 g^2) + eps)
-    lr_t = 9e-5 * np.sqrt(1 - 0.999) / (1 - 0.5)
+    # (lr, beta_2 are float32 variables in Keras: the values that take part are the float32-rounded ones)
+    lr32, b2 = float(np.float32(9e-5)), float(np.float32(0.999))
+    lr_t = lr32 * np.sqrt(1 - b2) / (1 - 0.5)
     for p_new, p_old, g in zip(pe.mc.params + pe.q.params, p0, gts):
-        close(p_new, p_old - lr_t * 0.5 * g / (np.sqrt(0.001 * g * g) + 1e-7), 1e-9)
+        close(p_new, p_old - lr_t * 0.5 * g / (np.sqrt((1 - b2) * g * g) + 1e-7), 1e-9)
 
 
 def test_bn_zero_debias_is_the_debiased_average_of_the_batch_values():

@@ -56,6 +56,7 @@ def test_template_maker_then_trainer_leave_the_reference_files(tmp_path):
     for name in ('generator.h5', 'discriminator.h5', 'signal_dis_on_gen.h5', 'gan_pe_samples.sav', 'gan_pe_waveforms.sav',
                  'GAN_posterior_samples/posterior_samples_00006.sav'):
         assert (tmp_path / 'run' / name).exists(), name
+    assert not list((tmp_path / 'run').glob('**/*.tmp'))                                           # every write was moved into place
     with open(str(tmp_path / 'run' / 'gan_pe_samples.sav'), 'rb') as f:
         pe = np.asarray(pickle.load(f, encoding='latin1'))
     assert pe.shape[0] == 2 and pe.shape[1] == 4000 and np.isfinite(pe).all()                       # (mc, q) x 4000 generator draws (:1330-1343)

@@ -342,30 +342,31 @@ def test_full_size_property_envelope_peak_lands_on_idx():
     assert torch.equal(ref, ref2) and ts.shape == (256, fs) and torch.isfinite(ts).all()
 
 
-def test_posterior_driven_mode_matches_oracle():
-    """lalinf_post_waveform_maker mode: masses from posterior rows, randint idx per row from the legacy stream,
-    shuffle, event-like template with idx = N/2 - 4 last."""
+@pytest.mark.parametrize("fs", [256, 512])
+def test_posterior_driven_mode_matches_reference_execution(fs):
+    """lalinf_post_waveform_maker mode against the reference's own gen_par / gen_bbh / sim_data executed over two
+    consecutive blocks of one seeded stream (tests/golden/posterior_mode_golden.npz): parameters, idx draws, shuffle and the event-like row
+    exact, stream position after each block exact, series <= 1e-9 (the closed-form chirp on the device against libm, as everywhere)."""
     from gennet_amd import templates as T
-    fs, Tobs = 512, 4
-    N = fs * Tobs
-    psd = S.analytic_psd(N // 2 + 1, 1.0 / Tobs)
-    rng = np.random.RandomState(8)
-    mc = rng.uniform(26, 32, 9); q = rng.uniform(0.6, 1.0, 9)
-    m1, m2 = T.m1m2_from_mc_q(mc, q)
-    assert np.allclose((m1 * m2) ** 0.6 / (m1 + m2) ** 0.2, mc, rtol=1e-13) and np.allclose(m2 / m1, q, rtol=1e-13)
-    np.random.seed(2)
-    (ts, y), pars = T.sim_data_posterior(fs, Tobs, psd, m1, m2, mc, size=8)
-    assert ts.shape == (8, 1, fs) and len(pars) == 8 and (pars[-1].m1, pars[-1].m2, pars[-1].idx) == (36.0, 29.0, N // 2 - 4)
-    np.random.seed(2)
-    lo, hi = S.convert_beta([0.45, 0.55], fs, Tobs)
-    idx = [int(np.random.randint(lo, hi, 1)[0]) for _ in range(7)]
-    perm = np.random.permutation(7)
-    Fp, Fc = S.antenna_response(S.EVENT_TIME, S.RA, S.DEC, S.PSI)
-    for row, k in enumerate(perm):
-        assert (pars[row].m1, pars[row].m2, pars[row].idx, pars[row].mc) == (m1[k], m2[k], idx[k], mc[k])
-        p = S.bbhparams(mc[k], m1[k] + m2[k], 0, m1[k], m2[k], S.RA, S.DEC, S.IOTA, S.PHI, S.PSI, idx[k], None, None)
-        crop, _ = S.gen_bbh(fs, Tobs, psd, p, Fp, Fc)
-        assert rel(ts[row, 0], crop) < 1e-9
+    PM = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'posterior_mode_golden.npz'))
+    key = 'pm_%d_' % fs
+    _, size, batch_size, seed = [int(v) for v in PM[key + 'meta']]
+    f = PM[key + 'm1_m2_file']
+    N = fs * 4
+    psd = S.analytic_psd(N // 2 + 1, 0.25)
+    m1, m2 = T.m1m2_from_mc_q(PM[key + 'post_mc'], f[0] / f[1])
+    assert np.allclose(m1, f[1], rtol=1e-13) and np.allclose(m2, f[0], rtol=1e-13)      # the file's row 1 is the heavier mass
+    np.random.seed(seed)
+    for blk in range(2):
+        (ts, y), pars = T.sim_data_posterior(fs, 4, psd, f[1], f[0], PM[key + 'post_mc'], size=size, batch_size=batch_size)
+        got = np.array([[p.mc, p.M, p.eta, p.m1, p.m2, p.ra, p.dec, p.iota, p.phi, p.psi, p.idx] for p in pars])
+        assert np.array_equal(got, PM[key + 'pars_%d' % blk])
+        assert (pars[-1].m1, pars[-1].m2, pars[-1].idx) == (36.0, 29.0, N // 2 - 4)
+        assert ts.shape == PM[key + 'ts_%d' % blk].shape and np.array_equal(y, PM[key + 'yval_%d' % blk])
+        assert rel(ts, PM[key + 'ts_%d' % blk]) < 1e-9
+        st = np.random.get_state()
+        assert np.array_equal(np.random.uniform(0, 1, 3), PM[key + 'next_uniform_%d' % blk])
+        np.random.set_state(st)
 
 
 def test_online_bank_config5_fs4096():

@@ -1,7 +1,7 @@
 """Diagnostic: per-parameter gradient errors of the full-size PE step / GAN G step against the fp64 oracle (prints every tensor)."""
 import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import numpy as np
 import test_nets_gpu as T
 from oracle import nets_ref as N
@@ -25,7 +25,7 @@ def pe(n_pix, B):
     out = model.train_on_batch(x, [y_mc, y_q], capture=cap)
     dec = (T.decisions_for(ref.mc, wp[:n_mc], cap), T.decisions_for(ref.q, wp[n_mc:], cap)) if os.environ.get('INJECT', '1') == '1' else (None, None)
     out_ref = ref.train_on_batch(x, y_mc, y_q, decisions=dec)
-    print('decision stats (in band, flipped, outside):', ref.mc.decision_stats, ref.q.decision_stats)
+    print('decision stats (in band, flipped, outside, layer elements):', ref.mc.decision_stats, ref.q.decision_stats)
     print('PE', n_pix, B, out[:3], out_ref[:3])
     names = [p_.name for l in wp for p_ in l.params]
     grads = [p_.grad.cpu().numpy() for l in wp for p_ in l.params]
@@ -47,7 +47,7 @@ def gan(n_pix, B):
     cap = {}
     out = DG.train_on_batch(z2, [1] * B, dropout_masks=names, capture=cap)
     out_ref = ref.g_train_on_batch(z2, [1] * B, g_masks, d_masks2, T.decisions_for(ref.D, D.layers, cap) if os.environ.get('INJECT', '1') == '1' else None)
-    print('decision stats (in band, flipped, outside):', ref.D.decision_stats)
+    print('decision stats (in band, flipped, outside, layer elements):', ref.D.decision_stats)
     print('GAN G step', n_pix, B, out, out_ref)
     pn = [p.name for l in G.layers for p in l.params]
     ggr = [p.grad.cpu().numpy() for l in G.layers for p in l.params]

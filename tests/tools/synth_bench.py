@@ -3,7 +3,7 @@
 irFFT x2 -> argmax-align -> crop) and of coloured-noise generation, next to the numpy oracle chain timed on one host core
 (the reference's loop is serial, gw_template_maker.py:676).
 
-  python scripts/synth_bench.py [--fs 2048] [--nb 8192] [--reps 5]
+  python tests/tools/synth_bench.py [--fs 2048] [--nb 8192] [--reps 5]
 """
 import argparse
 import os
@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():
