@@ -34,6 +34,7 @@ WORKLOADS = {
 }
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = 1/16 of the bf16 peak
 PEAK_HBM_TBS = 8.0                 # MI355X_MICROARCH.md: HBM3E spec peak
+PEAK_F64_VALU_TFLOPS = 78.6        # fp64 vector: half the guide's FP32 vector peak (157.3; the guide has no FP64 row; MI355X datasheet 78.6)
 
 
 def pmc_traffic_per_launch():
@@ -65,42 +66,50 @@ def host_cores():
 
 
 def cpu_baseline(n_pix, seconds_budget=30.0):
-    """The torch-CPU port of the same two steps (oracle/torch_ref.py) on this box's host cores, bounded sample: CNN train steps at
-    batch 32 (repeated) plus ONE at the benchmark's batch 256, GAN iterations at batch 8 (a batch-512 iteration is ~40 TFLOP: minutes
-    on the host).  `value` combines the batch-256 CNN rate with the batch-8 GAN rate; every batch size is a field of the object."""
+    """The torch-CPU port of the same two steps (oracle/torch_ref.py) on this box's host cores.  Protocol of BASELINE.md section 2 / SURVEY 8d:
+    same batch as the GPU line where the budget allows, >= 3 warm-up + >= 5 timed iterations, MEDIAN.
+      CNN leg: train_on_batch at the benchmark's batch 256 (3 + 5 steps; ~4 s each on 16 cores).
+      GAN leg: a batch-512 iteration is ~40 TFLOP (minutes on the host), so the leg runs at the largest power-of-two batch whose 3 + 5
+               iterations fit `seconds_budget`, chosen from one probe iteration at batch 8; the batch is a field of the object.
+    value = 1 / (t_CNN + t_GAN) per waveform, the CPU counterpart of the GPU line's B / (t_CNN + t_GAN)."""
     from oracle import torch_ref as T
     cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    bc, bg, bc_big = 32, 8, 256
-    pe = T.PENet(n_pix)
+    WARM, TIMED = 3, 5
 
-    def cnn_batch(b):
-        return torch.randn(b, n_pix, 1), torch.rand(b) * 15 + 20, torch.rand(b) * 0.5 + 0.5
-    x, ymc, yq = cnn_batch(bc)
-    pe.train_on_batch(x, ymc, yq)
-    t0 = time.time(); n = 0
-    while n < 2 or (time.time() - t0 < seconds_budget * 0.25 and n < 20):
-        pe.train_on_batch(x, ymc, yq); n += 1
-    t_cnn_small = (time.time() - t0) / n / bc
-    xb, ymcb, yqb = cnn_batch(bc_big)
-    t0 = time.time()
-    pe.train_on_batch(xb, ymcb, yqb)
-    t_cnn = (time.time() - t0) / bc_big
-    del xb
+    def median_time(fn):
+        for _ in range(WARM):
+            fn()
+        ts = []
+        for _ in range(TIMED):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), ts
+
+    bc = 256
+    pe = T.PENet(n_pix)
+    x, ymc, yq = torch.randn(bc, n_pix, 1), torch.rand(bc) * 15 + 20, torch.rand(bc) * 0.5 + 0.5
+    t_cnn_batch, cnn_ts = median_time(lambda: pe.train_on_batch(x, ymc, yq))
+    t_cnn = t_cnn_batch / bc
+    del pe, x
     gan = T.GAN(n_pix, np.random.RandomState(0).randn(n_pix))
+    probe = torch.randn(8, n_pix)
+    gan.iteration(probe, 8)                                        # first call: allocations, oneDNN primitive creation
+    t0 = time.perf_counter(); gan.iteration(probe, 8); per_wave = (time.perf_counter() - t0) / 8
+    bg = 8
+    while bg < 512 and (WARM + TIMED) * per_wave * (2 * bg) <= seconds_budget:
+        bg *= 2
     real = torch.randn(bg, n_pix)
-    gan.iteration(real, bg)
-    t0 = time.time(); m = 0
-    while m < 2 or (time.time() - t0 < seconds_budget * 0.4 and m < 20):
-        gan.iteration(real, bg); m += 1
-    t_gan = (time.time() - t0) / m / bg
+    t_gan_batch, gan_ts = median_time(lambda: gan.iteration(real, bg))
+    t_gan = t_gan_batch / bg
     return {'value': 1.0 / (t_cnn + t_gan), 'unit': 'waveforms/s', 'cores': cores, 'kind': 'port',
-            'sample': 'torch-CPU fp32 port (oracle/torch_ref.py), n_pix=%d: 1 CNN train step at batch %d (+ %d at batch %d) and %d GAN iterations at batch %d'
-                      % (n_pix, bc_big, n, bc, m, bg),
-            'cnn_batch': bc_big, 'cnn_batch_small': bc, 'gan_batch': bg,
-            'cnn_waveforms_per_s': 1.0 / t_cnn, 'cnn_waveforms_per_s_small_batch': 1.0 / t_cnn_small, 'gan_waveforms_per_s': 1.0 / t_gan,
-            'note': 'the GPU line runs CNN batch 256 and GAN batch 512; the CPU GAN leg is timed at batch %d (baseline only)' % bg}
+            'sample': 'torch-CPU fp32 port (oracle/torch_ref.py), n_pix=%d: median of %d CNN train steps at batch %d and of %d GAN iterations at batch %d, '
+                      'each after %d warm-up iterations' % (n_pix, TIMED, bc, TIMED, bg, WARM),
+            'protocol': {'warmup': WARM, 'timed': TIMED, 'statistic': 'median'},
+            'cnn_batch': bc, 'gan_batch': bg, 'cnn_waveforms_per_s': 1.0 / t_cnn, 'gan_waveforms_per_s': 1.0 / t_gan,
+            'cnn_step_seconds': [round(t, 3) for t in cnn_ts], 'gan_iteration_seconds': [round(t, 3) for t in gan_ts],
+            'note': 'the GPU line runs CNN batch 256 and GAN batch 512; the CPU GAN leg runs at batch %d, the largest power of two whose %d iterations '
+                    'fit %.0f s on this host (baseline only)' % (bg, WARM + TIMED, seconds_budget)}
 
 
 def free_port():
@@ -172,7 +181,7 @@ def main():
     bank_n = 0 if wl['online'] else args.bank
     if wl['online']:
         bank = None
-        online = T.OnlineBank(N_PIX, 4, psd, gw_norm_constant=synth.g, seed=2000 + rank, noise='white')
+        online = T.OnlineBank(N_PIX, 4, psd, gw_norm_constant=synth.g, seed=2000 + rank, noise='coloured')
     else:
         images, pars = synth.draw(bank_n)
         bank = bbh.DeviceBank(images, pars)
@@ -197,10 +206,14 @@ def main():
         def gan_step():
             return bbh.gan_train_step(nets, bank, event, GAN_BATCH, rank=rank, world=world, predict_batch=predict_batch)
 
+    last = {}
+
     def step():
+        # the return values of the three train_on_batch calls the loop prints (bbhMahoGANy.py:1165, :1292, :1296) are kept and checked after
+        # the timed region: a launch that wrote garbage at these batch sizes must not score
         for _ in range(WAVES // CNN_BATCH):
-            cnn_step()
-        gan_step()
+            last['cnn'] = cnn_step()
+        last['gan'] = gan_step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -223,6 +236,15 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     conv = ops.prof_collect(0); wgrad = ops.prof_collect(1); syn_in_step = ops.prof_collect(3)
+    last_losses = {'cnn [total, mc_loss, q_loss, mc_acc, q_acc]': [float(v) for v in last['cnn']],
+                   'gan [sg_loss, sg_acc, sd_loss, sd_acc]': [float(v) for v in last['gan']]}
+    bad = [k for k, v in last_losses.items() if not np.all(np.isfinite(v))]
+    sg_loss, sg_acc, sd_loss, sd_acc = last['gan']
+    if not (0.0 <= sg_acc <= 1.0 and 0.0 <= sd_acc <= 1.0 and sg_loss >= 0.0 and sd_loss >= 0.0 and all(v >= 0.0 for v in last['cnn'][:3])):
+        bad.append('range')
+    if bad:
+        sys.stderr.write('bench.py: rank %d: the last step returned non-finite or out-of-range losses (%s): %r\n' % (rank, bad, last_losses))
+        sys.exit(3)
 
     # SURVEY 8d also asks for the two loops and the synthesiser separately: timed AFTER the K steps (not part of `value`)
     def timed(fn, reps):
@@ -234,14 +256,22 @@ def main():
         return (time.perf_counter() - t) / reps
     t_cnn = timed(cnn_step, 4)
     t_gan = timed(gan_step, 2)
-    # metric iii: templates/s of the fused synthesiser (chirp -> whiten -> both inverse FFTs -> arg-max -> slide -> crop, one kernel),
-    # kernel time from HIP events on the launch stream; algorithmic bytes per template = 2*Nf*16 + Nf*8 read, n_pix*4 written
+    # metric iii: rows/s of the fused synthesiser, kernel time from HIP events on the launch stream.  default: templates only (prior -> chirp ->
+    # whiten -> both inverse FFTs -> arg-max -> slide -> crop, one kernel); cfg5: the launch the CNN loop makes -- the same plus gen_noise ->
+    # whiten_data('td') -> crop -> add in the same workgroup.  Priced twice: fp64 VALU operations (what bounds it) and SURVEY 8d's byte figure.
     SYN_NB = 16384
-    synth.draw(1024)
+    syn_bank = online if wl['online'] else synth
+    syn_bank.draw(1024)
     ops.prof_enable(True); ops.prof_reset()
-    t_syn = timed(lambda: synth.draw(SYN_NB), 3)
+    t_syn = timed(lambda: syn_bank.draw(SYN_NB), 3)
     ops.prof_enable(False)
     syn = ops.prof_collect(3)
+    nz = None
+    if wl['online']:
+        ops.prof_enable(True); ops.prof_reset()
+        timed(lambda: online.draw_noise(SYN_NB), 3)
+        ops.prof_enable(False)
+        nz = ops.prof_collect(4)
 
     if rank == 0:
         value = world * WAVES * args.steps / dt
@@ -253,10 +283,11 @@ def main():
             'n_gpus': world, 'ranks': world, 'collective_backend': ('rccl' if backend == 'nccl' else backend) if dp else None, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'last_losses': last_losses,
             'config': {'workload': ('BASELINE %s; per GPU and step: 2 x CNN point-estimator train_on_batch(batch=%d) + 1 GAN iteration(batch=%d) '
                                     '(G.predict, D step on 2B, G step through frozen D); n_pix=%d; %s')
                                    % ('configs[4] (cfg5)' if wl['online'] else 'configs[1]+[2]', CNN_BATCH, GAN_BATCH, N_PIX,
-                                      'every batch synthesised on the GPU inside the step (fused chirp->irFFT->align->crop kernel + white noise)' if wl['online']
+                                      'every batch synthesised on the GPU inside the step: CNN rows = template + PSD-coloured noise whitened with the same PSD, one launch (prior -> chirp -> irFFT -> align -> crop -> gen_noise -> whiten_data(td) -> add); GAN real images = [noise-free template | coloured whitened noise], two launches' if wl['online']
                                       else '%d whitened BBH templates synthesised on the GPU into an HBM-resident bank before the timed region' % bank_n),
                        'name': args.config, 'n_pix': N_PIX, 'cnn_batch': CNN_BATCH, 'gan_batch': GAN_BATCH, 'predict_batch': predict_batch,
                        'waveforms_per_step_per_gpu': WAVES, 'bank_rows': bank_n, 'parallelism': 'dp%d' % world},
@@ -274,20 +305,30 @@ def main():
                                                'algorithmic_bytes_per_launch': wgrad['bytes'] / max(wgrad['launches'], 1)},
                          'mfma_kernel_time_share': (conv['ms'] + wgrad['ms']) * 1e-3 / dt,
                          'step_algorithmic_tflops': world * WAVES * args.steps * (wl['gflop_cnn'] + wl['gflop_gan']) * 1e-3 / dt},
-            'roofline_synth': {'bound': 'hbm', 'kernel': 'synth_fused_kernel (gn_synth_templates)', 'achieved': syn_tbs, 'peak': PEAK_HBM_TBS, 'unit': 'TB/s',
-                               'frac': syn_tbs / PEAK_HBM_TBS, 'traffic': None, 'templates_per_launch': SYN_NB,
-                               'launches': syn['launches'], 'avg_launch_ms': syn['ms'] / max(syn['launches'], 1),
-                               'algorithmic_bytes_per_template': syn['bytes'] / max(syn['launches'], 1) / SYN_NB,
-                               'kernel_templates_per_s': syn['launches'] * SYN_NB / (syn['ms'] * 1e-3) if syn['ms'] > 0 else 0.0,
+            'roofline_synth': {'bound': 'valu_f64', 'kernel': 'synth_fused_kernel<.., NOISE=%s> (%s)' % (('true', 'gn_synth_templates_noise: prior + template + coloured whitened noise')
+                                                                                                         if wl['online'] else ('false', 'gn_synth_templates_prior')),
+                               'achieved': syn['flop'] / (syn['ms'] * 1e-3) / 1e12 if syn['ms'] > 0 else 0.0, 'peak': PEAK_F64_VALU_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': (syn['flop'] / (syn['ms'] * 1e-3) / 1e12 if syn['ms'] > 0 else 0.0) / PEAK_F64_VALU_TFLOPS, 'traffic': None,
+                               'rows_per_launch': SYN_NB, 'launches': syn['launches'], 'avg_launch_ms': syn['ms'] / max(syn['launches'], 1),
+                               'algorithmic_f64_flop_per_row': syn['flop'] / max(syn['launches'], 1) / SYN_NB,
+                               'algorithmic_bytes_per_row': syn['bytes'] / max(syn['launches'], 1) / SYN_NB,
+                               'algorithmic_equivalent_TBps': syn_tbs, 'algorithmic_equivalent_frac_of_hbm_peak': syn_tbs / PEAK_HBM_TBS,
+                               'kernel_rows_per_s': syn['launches'] * SYN_NB / (syn['ms'] * 1e-3) if syn['ms'] > 0 else 0.0,
                                'launches_inside_timed_steps': syn_in_step['launches'], 'ms_inside_timed_steps': syn_in_step['ms'],
-                               'note': 'algorithmic bytes = SURVEY 8d per-template figure (2 spectra of Nf complex128 + PSD read, n_pix fp32 written); the fused '
-                                       'kernel keeps the spectra in registers/LDS, so its real HBM traffic is ~the output row: the kernel is fp64-VALU/LDS-bound, '
-                                       'not HBM-bound'},
+                               'noise_kernel': None if nz is None else {
+                                   'kernel': 'noise_whitened_kernel (gn_noise_whitened: gen_noise -> whiten_data(td) -> crop)', 'launches': nz['launches'],
+                                   'avg_launch_ms': nz['ms'] / max(nz['launches'], 1), 'achieved': nz['flop'] / (nz['ms'] * 1e-3) / 1e12 if nz['ms'] > 0 else 0.0,
+                                   'frac': (nz['flop'] / (nz['ms'] * 1e-3) / 1e12 if nz['ms'] > 0 else 0.0) / PEAK_F64_VALU_TFLOPS,
+                                   'kernel_rows_per_s': nz['launches'] * SYN_NB / (nz['ms'] * 1e-3) if nz['ms'] > 0 else 0.0},
+                               'note': 'the kernel keeps spectra and series in registers / LDS and writes only the output row, so fp64 vector arithmetic (and LDS traffic) '
+                                       'bounds it, not HBM: achieved = counted fp64 operations (transforms 5 M log2 M each, ~150 per spectrum bin, Box-Muller ~120 per noise '
+                                       'bin; csrc/synth_fused.hip, noise_fused.hip) / kernel time against the fp64 vector peak.  algorithmic_equivalent_TBps prices the '
+                                       'same launches with the SURVEY 8d byte figure (spectra + PSD + window read, row written) -- traffic the fused kernel never issues'},
             'breakdown': {'cnn_train_waveforms_per_s': world * CNN_BATCH / t_cnn, 'gan_iteration_waveforms_per_s': world * GAN_BATCH / t_gan,
                           'cnn_ms_per_batch': 1e3 * t_cnn, 'gan_ms_per_iteration': 1e3 * t_gan,
                           'synth_templates_per_s': world * SYN_NB / t_syn,
                           'note': 'rank-0 clock, measured after the timed steps; value = B / (t_CNN + t_GAN) comes from the K timed steps only; '
-                                  'synth_templates_per_s = OnlineBank.draw wall clock (ONE kernel: prior draw, chirp, both inverse FFTs, arg-max, slide, crop; no host random numbers)'},
+                                  'synth_templates_per_s = OnlineBank.draw wall clock of the launch priced in roofline_synth (no host random numbers)'},
         }
         conv_math = os.environ.get('GENNET_CONV_MATH', 'fp32')
         if conv_math != 'fp32':      # the opt-in experiment: say so in the line; never the default configuration

@@ -74,6 +74,9 @@ _SIGS = {
     'gn_synth_templates': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f64, f64, f64, f64, f64, f64, f64, f64, vp],
     'gn_synth_templates_prior': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f64, f64, f64, f64, f64, f64, f64, f64, u64, u64, i32, i32,
                                  f64, f64, vp],
+    'gn_noise_whitened': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f64, u64, u64, vp],
+    'gn_synth_templates_noise': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f64, f64, f64, f64, f64, f64, f64, f64,
+                                 u64, u64, i32, i32, f64, f64, u64, u64, vp, vp],
     'gn_kde2d_pdf': [vp, i32, vp, i32, f64, f64, f64, f64, vp, vp],
     'gn_scale_f64': [vp, f64, sz, vp],
     'gn_f64_to_f32': [vp, vp, f64, sz, vp],

@@ -245,15 +245,18 @@ def assemble_discriminator_batch(real, noise, fake, event):
 
 def gan_train_step_online(nets, online_bank, event, batch, predict_batch=32):
     """The GAN loop body with the real half of the discriminator batch synthesised on the GPU for this iteration (BASELINE config 5;
-    templates.OnlineBank) instead of gathered from a stored bank; otherwise identical to gan_train_step."""
-    real, _ = online_bank.draw(batch)
-    return gan_train_step(nets, None, event, batch, predict_batch=predict_batch, real=real)
+    templates.OnlineBank) instead of gathered from a stored bank: column 0 = noise-free templates from the prior, column 1 = the bank's
+    noise (PSD-coloured and whitened by the fused kernel for noise='coloured', N(0,1) otherwise); otherwise identical to gan_train_step."""
+    real, _ = online_bank.draw_clean(batch)
+    noise = online_bank.draw_noise(batch) if online_bank.noise == 'coloured' else None
+    return gan_train_step(nets, None, event, batch, predict_batch=predict_batch, real=real, noise=noise)
 
 
-def gan_train_step(nets, bank, event, batch, rng=_pyrandom, rank=0, world=1, predict_batch=32, real=None, n_noise_real=1):
+def gan_train_step(nets, bank, event, batch, rng=_pyrandom, rank=0, world=1, predict_batch=32, real=None, n_noise_real=1, noise=None):
     """One iteration of the GAN loop, bbhMahoGANy.py:1243-1299.  Returns [sg_loss, sg_acc, sd_loss, sd_acc] (:1299).
     n_noise_real (:107, default 1): noise realisations per sampled template -- the `batch` sampled templates are stacked n_noise_real times
-    (:1280-1283) and every other batch of the iteration (latents, fakes, noise, labels) has batch * n_noise_real rows."""
+    (:1280-1283) and every other batch of the iteration (latents, fakes, noise, labels) has batch * n_noise_real rows.
+    noise: (rows, n_pix) device tensor for column 1 of the real images (:1277; default: fresh N(0,1) drawn here)."""
     if real is None:
         it = bank.sample(batch, rng, rank, world)
         real = ops.gather_rows(bank.images, it)
@@ -264,8 +267,11 @@ def gan_train_step(nets, bank, event, batch, rng=_pyrandom, rank=0, world=1, pre
     seed, off = device_rng().take(batch * 100)
     z = ops.fill_uniform((batch, 100), -1.0, 1.0, seed, off, device())
     fake = nets.generator.predict_device(z, batch_size=predict_batch)                    # inference phase (:1248)
-    seed, off = device_rng().take(batch * n)
-    noise = ops.fill_normal((batch, n, 1), 0.0, 1.0, seed, off, device())
+    if noise is None:
+        seed, off = device_rng().take(batch * n)
+        noise = ops.fill_normal((batch, n, 1), 0.0, 1.0, seed, off, device())
+    elif tuple(noise.shape[:2]) != (batch, n):
+        raise ValueError('gan_train_step: noise has shape %r, the real half has (%d, %d)' % (tuple(noise.shape), batch, n))
     sX, sy = assemble_discriminator_batch(real, noise, fake, event)
     sd_loss = nets.signal_discriminator.train_on_batch(sX, sy)
     seed, off = device_rng().take(batch * 100)

@@ -24,6 +24,12 @@ def _stale(out, deps):
 
 
 def build(force=False, verbose=True):
+    """Incremental by default (a source or header newer than its object is recompiled); force=True compiles every translation unit and
+    relinks -- the "does it build from scratch" check (__graft_entry__.build() forces it).  Returns the library path; what was done is
+    recorded in lib/build_info.json: {"mode": "clean" | "incremental", "compiled": [...], "seconds": ...}."""
+    import json
+    import time
+    t0 = time.time()
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, 'obj')
     os.makedirs(objdir, exist_ok=True)
@@ -54,6 +60,12 @@ def build(force=False, verbose=True):
         rc, out = run([HIPCC, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', LIB] + objs)
         if rc:
             raise RuntimeError('link failed:\n' + out)
+    info = {'mode': 'clean' if force else 'incremental', 'compiled': [os.path.basename(j[-3]) for j in jobs], 'sources': len(srcs),
+            'seconds': round(time.time() - t0, 1), 'hipcc': HIPCC, 'flags': FLAGS}
+    with open(os.path.join(LIBDIR, 'build_info.json'), 'w') as f:
+        json.dump(info, f)
+    if verbose:
+        print('build_mode=%s compiled=%d/%d translation units in %.1f s' % (info['mode'], len(jobs), len(srcs), info['seconds']), flush=True)
     return LIB
 
 

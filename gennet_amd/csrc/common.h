@@ -12,7 +12,7 @@ int check_launch(const char* what);
 
 // Event-based timing of the MFMA kernels (bench.py roofline leg).  No-ops unless gn_prof_enable(1).
 void prof_begin(hipStream_t s);
-void prof_end(hipStream_t s, double flop, int kind, double bytes = 0.0);  // kind 0: conv_mfma (fwd, dgrad), 1: wgrad_mfma, 2: bf16x3 conv, 3: fused synthesiser
+void prof_end(hipStream_t s, double flop, int kind, double bytes = 0.0);  // kind 0: conv_mfma (fwd, dgrad), 1: wgrad_mfma, 2: bf16x3 conv, 3: fused synthesiser, 4: fused noise chain
 
 
 // ---------------------------------------------------------------------------------------------

@@ -384,7 +384,9 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
     minoff = std::min(minoff, a.t.off[j]);
     maxoff = std::max(maxoff, a.t.off[j]);
   }
-  if (no_pipe || nt < 2 || nt > 5 || maxoff - minoff + 1 > nt || (size_t)a.Ly * a.Cout * 4 >= 0x40000000ull) return GN_OK;
+  if (no_pipe || nt < 2 || nt > 5 || maxoff - minoff + 1 > nt || (size_t)a.Ly * a.Cout * 4 >= 0x40000000ull ||
+      (size_t)a.Lin * a.Cin * 4 >= 0x40000000ull)      // the input descriptor's byte count and its out-of-range sentinel offset 0x40000000 must stay apart
+    return GN_OK;
   if (a.t.in_stride != 1 && !(a.t.in_stride == 2 && nt == 5)) return GN_OK;
   *launched = true;
   if (a.stat_part && (a.act != GN_ACT_LINEAR || a.mask || a.gy || a.t.out_stride != 1)) {   // statistics are defined for the plain linear forward only

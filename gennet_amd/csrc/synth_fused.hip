@@ -16,6 +16,8 @@
 // ref_idx = argmax(h+^2 + hx^2) over the rolled series (first maximum), slide = ref_idx - idx - peak_off with python slice
 // semantics, zero fill past the end, exactly as align_crop_kernel (synth.hip) does.
 #include "common.h"
+#include "fft_lds.h"
+#include "noise_chain.h"
 
 namespace gn {
 
@@ -46,6 +48,9 @@ struct SynthArgs {
   float* labels;           // (nb, 2) [mc, m2/m1] or NULL
   double* m_out;           // (nb, 2) [m1, m2] or NULL
   int32_t* idx_out;        // (nb,) or NULL
+  // noise mode (nz.amp != NULL; BASELINE configs[4]): after the template's crop is formed the SAME workgroup runs gen_noise ->
+  // whiten_data('td') (noise_chain.h) in the same LDS image and writes template * g + whitened noise; the template crop waits in registers
+  NoiseArgs nz;
 };
 
 constexpr int kPriorTrials = 1024;   // Philox counters reserved per template (acceptance of the prior box is ~4.5 % per trial)
@@ -99,102 +104,9 @@ __device__ __forceinline__ double2 chirp_bin(const ChirpCoeffsF& c, int k, doubl
   return make_double2(amp * cs * w, -amp * sn * w);       // h = amp * exp(-i phase)
 }
 
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ double2 cmulf(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ double2 muli(double2 a) { return make_double2(-a.y, a.x); }         // i * a
-
-// inverse (exp(+i ..)) 8-point DFT, natural order in and out
-__device__ __forceinline__ void dft8_inv(double2 (&a)[8]) {
-  const double r = 0.70710678118654752440;
-  const double2 t0 = cadd(a[0], a[4]), t1 = csub(a[0], a[4]), t2 = cadd(a[2], a[6]), t3 = csub(a[2], a[6]);
-  const double2 t4 = cadd(a[1], a[5]), t5 = csub(a[1], a[5]), t6 = cadd(a[3], a[7]), t7 = csub(a[3], a[7]);
-  const double2 e0 = cadd(t0, t2), e1 = csub(t0, t2), e2 = cadd(t4, t6), e3 = muli(csub(t4, t6));
-  a[0] = cadd(e0, e2); a[4] = csub(e0, e2); a[2] = cadd(e1, e3); a[6] = csub(e1, e3);
-  const double2 v1 = make_double2((t5.x - t5.y) * r, (t5.x + t5.y) * r), v2 = muli(t3), v3 = make_double2((-t7.x - t7.y) * r, (t7.x - t7.y) * r);
-  const double2 f0 = cadd(t1, v2), f1 = csub(t1, v2), f2 = cadd(v1, v3), f3 = muli(csub(v1, v3));
-  a[1] = cadd(f0, f2); a[5] = csub(f0, f2); a[3] = cadd(f1, f3); a[7] = csub(f1, f3);
-}
-
-// LDS image: one complex slot of padding after every 8 (the span-1 stage reads 8 consecutive values per thread: 144-byte lane stride
-// instead of 128 keeps ds_read_b128 conflict-free; later stages read consecutive values across lanes)
-__device__ __forceinline__ int PH(int i) { return i + (i >> 3); }
-
-// Stage radices: LOGM/3 radix-8 stages (span 1, 8, 64, ...) then one radix-2 (LOGM % 3 == 1) or radix-4 (== 2) stage.  Storage position
-// of input bin k for the in-place decimation-in-time transform = mixed-radix digit reversal: the LAST stage's digit is the least
-// significant digit of k and selects the outermost block.
-template <int LOGM>
-__device__ __forceinline__ int digitrev(int k) {
-  constexpr int NR8 = LOGM / 3, REM = LOGM % 3;
-  int p = 0;
-  if (REM) {
-    p = (k & ((1 << REM) - 1)) << (3 * NR8);
-    k >>= REM;
-  }
-#pragma unroll
-  for (int j = NR8 - 1; j >= 0; --j) {
-    p += (k & 7) << (3 * j);
-    k >>= 3;
-  }
-  return p;
-}
-
-template <int LOGM, int NT>
-__device__ void ifft_lds(double2* d, const double2* __restrict__ W) {
-  constexpr int M = 1 << LOGM, NR8 = LOGM / 3, REM = LOGM % 3;
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int s = 0; s < NR8; ++s) {
-    const int lspan = 3 * s, span = 1 << lspan;
-    const int lstep = LOGM + 1 - lspan - 3;                  // table step N / (8 span), N = 2 M
-    for (int bf = tid; bf < M / 8; bf += NT) {
-      const int g = bf >> lspan, pos = bf & (span - 1);
-      const int base = (g << (lspan + 3)) + pos;
-      double2 a[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) a[q] = d[PH(base + (q << lspan))];
-      if (s > 0) {
-        const int i1 = pos << lstep;
-        const double2 w1 = W[i1], w2 = W[2 * i1], w4 = W[4 * i1];
-        const double2 w3 = cmulf(w1, w2);
-        a[1] = cmulf(a[1], w1); a[2] = cmulf(a[2], w2); a[3] = cmulf(a[3], w3); a[4] = cmulf(a[4], w4);
-        a[5] = cmulf(a[5], cmulf(w4, w1)); a[6] = cmulf(a[6], cmulf(w4, w2)); a[7] = cmulf(a[7], cmulf(w4, w3));
-      }
-      dft8_inv(a);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) d[PH(base + (q << lspan))] = a[q];
-    }
-    __syncthreads();
-  }
-  if (REM == 1) {
-    constexpr int lspan = 3 * NR8, span = 1 << lspan;        // last stage: span = M / 2, table step N / (2 span) = 2
-    for (int bf = tid; bf < M / 2; bf += NT) {
-      const int pos = bf & (span - 1);
-      const double2 x0 = d[PH(pos)], x1 = cmulf(d[PH(pos + span)], W[pos << 1]);
-      d[PH(pos)] = cadd(x0, x1);
-      d[PH(pos + span)] = csub(x0, x1);
-    }
-    __syncthreads();
-  } else if (REM == 2) {
-    constexpr int lspan = 3 * NR8, span = 1 << lspan;        // last stage: span = M / 4, table step N / (4 span) = 2
-    for (int bf = tid; bf < M / 4; bf += NT) {
-      const int pos = bf & (span - 1);
-      const int i1 = pos << 1;
-      const double2 w1 = W[i1], w2 = W[2 * i1];
-      const double2 u0 = d[PH(pos)], u1 = cmulf(d[PH(pos + span)], w1), u2 = cmulf(d[PH(pos + 2 * span)], w2), u3 = cmulf(d[PH(pos + 3 * span)], cmulf(w1, w2));
-      const double2 s02 = cadd(u0, u2), d02 = csub(u0, u2), s13 = cadd(u1, u3), d13 = muli(csub(u1, u3));
-      d[PH(pos)] = cadd(s02, s13);
-      d[PH(pos + span)] = cadd(d02, d13);
-      d[PH(pos + 2 * span)] = csub(s02, s13);
-      d[PH(pos + 3 * span)] = csub(d02, d13);
-    }
-    __syncthreads();
-  }
-}
-
-template <int LOGM, int NT>
+template <int LOGM, int NT, bool NOISE>
 __global__ __launch_bounds__(NT, 2) void synth_fused_kernel(SynthArgs a) {
-  constexpr int M = 1 << LOGM, N = 2 * M, KPT = M / NT;
+  constexpr int M = 1 << LOGM, N = 2 * M, KPT = M / NT, KC = (KPT + 1) / 2;      // KC crop samples per thread in noise mode (crop_len <= M/2 = N/4)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double2* d = reinterpret_cast<double2*>(smem_raw);                                           // PH(M) padded complex values
   ChirpCoeffsF* cf = reinterpret_cast<ChirpCoeffsF*>(smem_raw + (size_t)(M + M / 8) * sizeof(double2));
@@ -272,24 +184,36 @@ __global__ __launch_bounds__(NT, 2) void synth_fused_kernel(SynthArgs a) {
     }
   };
   long start = 0;
-  auto emit = [&](int parity) {
+  // sample n of the crop, if this parity pass owns it (the zero fill past the end of the slid series belongs to the odd pass)
+  auto crop_value = [&](int n, int parity, double* v) -> bool {
+    const long sidx = start + a.crop0 + n;
+    if (sidx >= N) { *v = 0.0; return parity == 1; }
+    const int s = (int)((sidx + a.roll) % N);
+    if ((s & 1) != parity) return false;
     const double sg = parity ? -1.0 : 1.0;
-    for (int n = tid; n < a.crop_len; n += NT) {
-      const long sidx = start + a.crop0 + n;
-      int s = (int)((sidx + a.roll) % N);
-      if ((s & 1) != parity && sidx < N) continue;            // the other pass owns this sample (zero fill is written by the odd pass)
-      double v = 0.0;
-      if (sidx < N) {
-        const double2 z = d[PH(s >> 1)];
-        const double hp = fpn * (2.0 * z.x + c.nyq_re * sg), hc = cin * (2.0 * z.y + c.nyq_im * sg);
-        const double t1 = hp * a.Fp, t2 = hc * a.Fc;
-        v = (t1 + t2) * a.g;
-      } else if (!parity) {
-        continue;
+    const double2 z = d[PH(s >> 1)];
+    const double hp = fpn * (2.0 * z.x + c.nyq_re * sg), hc = cin * (2.0 * z.y + c.nyq_im * sg);
+    const double t1 = hp * a.Fp, t2 = hc * a.Fc;
+    *v = (t1 + t2) * a.g;
+    return true;
+  };
+  double keep[KC];                                            // noise mode: the template crop, n = tid + j NT
+  auto emit = [&](int parity) {
+    if constexpr (NOISE) {
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        const int n = tid + j * NT;
+        double v;
+        if (n < a.crop_len && crop_value(n, parity, &v)) keep[j] = v;
       }
-      const size_t o = (size_t)b * a.crop_len + n;
-      if (a.out64) a.out64[o] = v;
-      if (a.out32) a.out32[o] = (float)v;
+    } else {
+      for (int n = tid; n < a.crop_len; n += NT) {
+        double v;
+        if (!crop_value(n, parity, &v)) continue;
+        const size_t o = (size_t)b * a.crop_len + n;
+        if (a.out64) a.out64[o] = v;
+        if (a.out32) a.out32[o] = (float)v;
+      }
     }
   };
 
@@ -333,18 +257,54 @@ __global__ __launch_bounds__(NT, 2) void synth_fused_kernel(SynthArgs a) {
   load_pass(0);
   ifft_lds<LOGM, NT>(d, a.W);
   emit(0);
+  if constexpr (NOISE) {
+    __syncthreads();                                          // every read of the template image is done: the noise chain reuses it
+    noise_chain<LOGM, NT>(d, a.nz, b);
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      const int n = tid + j * NT;
+      if (n < a.crop_len) {
+        const double v = keep[j] + noise_sample<LOGM>(d, a.crop0 + n);
+        const size_t o = (size_t)b * a.crop_len + n;
+        if (a.out64) a.out64[o] = v;
+        if (a.out32) a.out32[o] = (float)v;
+      }
+    }
+  }
 }
+
+// fp64 operations per template (the figure roofline_synth prices the kernel with): three M-point transforms (5 M log2 M each), the
+// spectrum (cbrt, pow, sincos and the phase polynomial: ~150 flop per live bin, M bins), the twiddle multiply of the odd pass (6 M),
+// two arg-max passes and the emit (~12 per sample, N samples)
+static double synth_flops_per_template(int M) {
+  double l2 = 0;
+  for (int m = M; m > 1; m >>= 1) l2 += 1;
+  return 3.0 * 5.0 * M * l2 + 150.0 * M + 6.0 * M + 12.0 * 2.0 * M;
+}
+double noise_flops_per_row(int M);
 
 template <int LOGM, int NT>
 static int launch_synth(const SynthArgs& a, hipStream_t s) {
   constexpr int M = 1 << LOGM;
   const size_t lds = (size_t)(M + M / 8) * sizeof(double2) + sizeof(ChirpCoeffsF) + 16 * sizeof(double) + 16 * sizeof(int);
-  static unsigned long long lds_done = 0;
-  allow_big_lds((const void*)synth_fused_kernel<LOGM, NT>, &lds_done);
+  const bool noise = a.nz.amp != nullptr;
+  if (noise && a.crop_len > M / 2) {
+    set_error("synth_templates: noise mode needs crop_len <= N/4 (crop %d, N %d)", a.crop_len, 2 * M);
+    return GN_EINVAL;
+  }
+  static unsigned long long lds_done = 0, lds_done_nz = 0;
   prof_begin(s);
-  hipLaunchKernelGGL((synth_fused_kernel<LOGM, NT>), dim3(a.nb), dim3(NT), lds, s, a);
-  // algorithmic bytes: per template 2 spectra of Nf complex128 + the PSD read, the cropped row written
-  prof_end(s, 0.0, 3, (double)a.nb * (2.0 * (M + 1) * 16.0 + (M + 1) * 8.0 + (double)a.crop_len * (a.out64 ? 8.0 : 4.0)));
+  if (noise) {
+    allow_big_lds((const void*)synth_fused_kernel<LOGM, NT, true>, &lds_done_nz);
+    hipLaunchKernelGGL((synth_fused_kernel<LOGM, NT, true>), dim3(a.nb), dim3(NT), lds, s, a);
+  } else {
+    allow_big_lds((const void*)synth_fused_kernel<LOGM, NT, false>, &lds_done);
+    hipLaunchKernelGGL((synth_fused_kernel<LOGM, NT, false>), dim3(a.nb), dim3(NT), lds, s, a);
+  }
+  // algorithmic bytes: per template 2 spectra of Nf complex128 + the PSD read, the cropped row written; noise mode adds the
+  // noise spectrum (Nf complex128) and the window (N doubles) the unfused chain reads
+  prof_end(s, (double)a.nb * (synth_flops_per_template(M) + (noise ? noise_flops_per_row(M) : 0.0)), 3,
+           (double)a.nb * (2.0 * (M + 1) * 16.0 + (M + 1) * 8.0 + (double)a.crop_len * (a.out64 ? 8.0 : 4.0) + (noise ? (M + 1) * 16.0 + 2.0 * M * 8.0 : 0.0)));
   return check_launch("synth_fused");
 }
 
@@ -377,6 +337,7 @@ extern "C" int gn_synth_templates(const double* m1, const double* m2, const int3
   a.nb = nb; a.N = N; a.roll = roll; a.crop0 = crop0; a.crop_len = crop_len; a.peak_off = peak_off;
   a.df = df; a.f_low = f_low; a.dist_mpc = dist_mpc; a.iota = iota; a.phi0 = phi0; a.Fp = Fp; a.Fc = Fc; a.g = g;
   a.seed = 0; a.counter = 0; a.idx_lo = a.idx_hi = 0; a.m_min = 5.0; a.M_max = 100.0; a.labels = nullptr; a.m_out = nullptr; a.idx_out = nullptr;
+  a.nz = NoiseArgs{};
   return synth_templates(a, (hipStream_t)stream);
 }
 
@@ -393,5 +354,28 @@ extern "C" int gn_synth_templates_prior(const double* scale, const double* twidd
   a.nb = nb; a.N = N; a.roll = roll; a.crop0 = crop0; a.crop_len = crop_len; a.peak_off = peak_off;
   a.df = df; a.f_low = f_low; a.dist_mpc = dist_mpc; a.iota = iota; a.phi0 = phi0; a.Fp = Fp; a.Fc = Fc; a.g = g;
   a.seed = seed; a.counter = counter; a.idx_lo = idx_lo; a.idx_hi = idx_hi; a.m_min = m_min; a.M_max = M_max; a.labels = labels; a.m_out = m_out; a.idx_out = idx_out;
+  a.nz = NoiseArgs{};
+  return synth_templates(a, (hipStream_t)stream);
+}
+
+// Templates (given parameters, or with m1 == NULL drawn from the prior in the kernel) PLUS PSD-coloured noise whitened with the same PSD, one
+// launch, one workgroup per row: gw_template_maker.py:462-575 + :695, then :161-193 and :243-286 ('td'), crop, add (BASELINE configs[4]).
+extern "C" int gn_synth_templates_noise(const double* m1, const double* m2, const int32_t* idx, const double* scale, const double* twiddle, const double* noise_amp,
+                                        const double* window, double* out_f64, float* out_f32, float* labels, double* m_out, int32_t* idx_out, int32_t* ref_idx,
+                                        int nb, int N, int roll, int crop0, int crop_len, int peak_off, double df, double f_low, double dist_mpc, double iota,
+                                        double phi0, double Fp, double Fc, double g, uint64_t seed, uint64_t counter, int idx_lo, int idx_hi, double m_min,
+                                        double M_max, uint64_t noise_seed, uint64_t noise_counter, double* normals_out, void* stream) {
+  GN_REQUIRE(scale && twiddle && noise_amp && window && (out_f64 || out_f32) && nb >= 0, "synth_templates_noise: bad arguments");
+  GN_REQUIRE((m1 && m2 && idx) || (!m1 && !m2 && !idx), "synth_templates_noise: m1, m2, idx are given together or not at all (prior mode)");
+  GN_REQUIRE(roll >= 0 && roll < N && crop0 >= 0 && crop_len > 0 && crop0 + crop_len <= N && df > 0, "synth_templates_noise: bad window (N %d roll %d crop %d+%d)",
+             N, roll, crop0, crop_len);
+  GN_REQUIRE(m1 || (idx_hi >= idx_lo && m_min > 0 && M_max > 2 * m_min), "synth_templates_noise: bad prior (idx [%d, %d), masses %g .. %g)", idx_lo, idx_hi, m_min, M_max);
+  SynthArgs a;
+  a.m1 = m1; a.m2 = m2; a.idx = idx; a.scale = scale; a.W = (const double2*)twiddle; a.out64 = out_f64; a.out32 = out_f32; a.ref_out = ref_idx;
+  a.nb = nb; a.N = N; a.roll = roll; a.crop0 = crop0; a.crop_len = crop_len; a.peak_off = peak_off;
+  a.df = df; a.f_low = f_low; a.dist_mpc = dist_mpc; a.iota = iota; a.phi0 = phi0; a.Fp = Fp; a.Fc = Fc; a.g = g;
+  a.seed = seed; a.counter = counter; a.idx_lo = idx_lo; a.idx_hi = idx_hi; a.m_min = m_min; a.M_max = M_max; a.labels = labels; a.m_out = m_out; a.idx_out = idx_out;
+  a.nz.amp = noise_amp; a.nz.wscale = scale; a.nz.win = window; a.nz.W = (const double2*)twiddle; a.nz.normals_in = nullptr; a.nz.normals_out = normals_out;
+  a.nz.seed = noise_seed; a.nz.counter = noise_counter; a.nz.df = df;
   return synth_templates(a, (hipStream_t)stream);
 }

@@ -49,21 +49,29 @@ def make_kernels(pred_samp, lalinf_samp):
     return k_cnn, k_lal
 
 
+def score_grid(lo, hi, n=100):
+    """(2, n*n) evaluation points: n x n nodes spanning [lo[0], hi[0]] x [lo[1], hi[1]] inclusive, first coordinate slowest -- the point set
+    and order of the reference's 100j x 100j mesh (bbhMahoGANy.py:858-859); the order only matters for bit-for-bit sums."""
+    axes = [lo[k] + np.arange(n) * ((hi[k] - lo[k]) / (n - 1)) for k in range(2)]      # node k = lo + k * step: the same doubles the mesh holds
+    return np.stack([np.repeat(axes[0], n), np.tile(axes[1], n)])
+
+
+def pdf_overlap(pa, pb):
+    """Normalised inner product of two densities sampled on the same points: sum(a b) / sqrt(sum(a^2) sum(b^2)) (:870)."""
+    return np.divide(np.sum(pa * pb), np.sqrt(np.sum(pa ** 2) * np.sum(pb ** 2)))
+
+
 def overlap_tests(pred_samp, lalinf_samp, true_vals=None, kernel_cnn=None, kernel_lalinf=None):
     """bbhMahoGANy.py:811-873 for the two-network read-out (comb_pe_model = False): pred_samp = [mc (n,1), q (n,1)],
-    lalinf_samp (2, m).  Returns (ks_score, ad_score, beta_score)."""
+    lalinf_samp (2, m).  Returns (ks_score, ad_score, beta_score): per-parameter two-sample KS and Anderson-Darling tests, and the overlap of
+    the two KDEs on a 100 x 100 grid spanning the joint range of both sample sets."""
     from scipy.stats import anderson_ksamp, ks_2samp
     if kernel_cnn is None or kernel_lalinf is None:
         kernel_cnn, kernel_lalinf = make_kernels(pred_samp, lalinf_samp)
-    p0 = np.reshape(pred_samp[0], (-1,)); p1 = np.reshape(pred_samp[1], (-1,))
-    l0 = np.asarray(lalinf_samp[0][:]); l1 = np.asarray(lalinf_samp[1][:])
-    ks_score = np.array([ks_2samp(p0, l0), ks_2samp(p1, l1)])
-    ad_score = [anderson_ksamp([p0, l0]), anderson_ksamp([p1, l1])]
-    comb_mc = np.concatenate((np.reshape(pred_samp[0], (-1, 1)), l0.reshape(-1, 1)))
-    comb_q = np.concatenate((np.reshape(pred_samp[1], (-1, 1)), l1.reshape(-1, 1)))
-    X, Y = np.mgrid[np.min(comb_mc):np.max(comb_mc):100j, np.min(comb_q):np.max(comb_q):100j]
-    positions = np.vstack([X.ravel(), Y.ravel()])
-    cnn_pdf = kernel_cnn.pdf(positions)
-    lalinf_pdf = kernel_lalinf.pdf(positions)
-    beta_score = np.divide(np.sum(cnn_pdf * lalinf_pdf), np.sqrt(np.sum(cnn_pdf ** 2) * np.sum(lalinf_pdf ** 2)))
-    return ks_score, ad_score, beta_score
+    ours = [np.reshape(pred_samp[k], (-1,)) for k in range(2)]
+    theirs = [np.asarray(lalinf_samp[k]).reshape(-1) for k in range(2)]
+    ks_score = np.array([ks_2samp(ours[k], theirs[k]) for k in range(2)])
+    ad_score = [anderson_ksamp([ours[k], theirs[k]]) for k in range(2)]
+    both = [np.concatenate((ours[k], theirs[k])) for k in range(2)]
+    pts = score_grid([b.min() for b in both], [b.max() for b in both])
+    return ks_score, ad_score, pdf_overlap(kernel_cnn.pdf(pts), kernel_lalinf.pdf(pts))

@@ -182,6 +182,47 @@ def gen_noise_device(fs, T_obs, psd, nb, seed, offset=0):
     return x
 
 
+class NoiseSynth(object):
+    """gen_noise (gw_template_maker.py:161-193) -> whiten_data(flag='td') (:243-286) -> central crop, fused: ONE kernel, one workgroup per row,
+    every N-point real transform an N/2-point complex transform in LDS, fp64 like numpy (gn_noise_whitened; BASELINE configs[4]).  Keeps
+    the three tables of one (fs, T_obs, psd) in HBM: amp = sqrt(0.25 T psd) (0 where psd == 0), the whitening scale, the Tukey(1/8) window."""
+
+    def __init__(self, fs, T_obs, psd):
+        self.fs, self.T_obs = int(fs), int(T_obs)
+        self.N = self.fs * self.T_obs
+        self.Nf = self.N // 2 + 1
+        if self.N not in Synth.FUSED_N:
+            raise NotImplementedError('NoiseSynth: series length %d is outside the fused kernel\'s range %r' % (self.N, Synth.FUSED_N))
+        psd = np.asarray(psd, np.float64)
+        assert psd.size == self.Nf, 'psd must have N/2+1 = %d bins' % self.Nf
+        amp = np.sqrt(0.25 * T_obs * psd)
+        amp[psd == 0.0] = 0.0
+        self.amp = _d64(amp)
+        self.wscale = _d64(_whiten_scale(psd, fs))
+        self.win = _d64(tukey(self.N, alpha=1.0 / 8.0))
+        twiddles(self.N)
+
+    def draw(self, nb, seed=0, counter=0, normals=None, add=None, dtype=torch.float32, crop=None, want_normals=False):
+        """nb whitened-noise rows -> (nb, crop_len) device tensor of `dtype` (fp32 or fp64).  normals: (nb, 2 Nf) numpy array of standard
+        normals per row in numpy's draw order [re block | im block] (what gen_noise consumes from the legacy stream), or None: Philox
+        stream (seed, counter), which the caller advances by nb * Nf.  add: (nb, crop_len) fp64 device rows the noise is added to.
+        crop = (start, length), default the central second [1.5 fs, 2.5 fs).  want_normals: also return the (nb, 2 Nf) normals used."""
+        c0, cl = crop if crop is not None else (int((self.T_obs / 2) * self.fs - self.fs / 2), self.fs)
+        out = torch.empty((nb, cl), dtype=dtype, device=device())
+        nin = None
+        if normals is not None:
+            nin = _d64(np.asarray(normals, np.float64).reshape(nb, 2 * self.Nf))
+        nout = torch.empty((nb, 2 * self.Nf), dtype=torch.float64, device=device()) if want_normals else None
+        if add is not None:
+            assert add.dtype == torch.float64 and tuple(add.shape) == (nb, cl) and add.is_contiguous()
+        if nb:
+            _lib.call('gn_noise_whitened', self.amp.data_ptr(), self.wscale.data_ptr(), self.win.data_ptr(), twiddles(self.N).data_ptr(),
+                      None if nin is None else nin.data_ptr(), None if nout is None else nout.data_ptr(), None if add is None else add.data_ptr(),
+                      out.data_ptr() if dtype == torch.float64 else None, out.data_ptr() if dtype == torch.float32 else None, nb, self.N, c0, cl,
+                      1.0 / self.T_obs, int(seed), int(counter), _s())
+        return (out, nout) if want_normals else out
+
+
 def gen_masses(m_min=5.0, M_max=100.0, mdist='astro'):
     """gw_template_maker.py:289-370, all four distributions, same draws from the numpy legacy stream per rejection trial:
     'astro' / 'hunt_constrain' (:312-339: two log-uniform component masses per trial; the latter adds q >= 0.5, 20 <= mc <= 35),
@@ -314,10 +355,12 @@ class Synth(object):
 
     PRIOR_TRIALS = 1024           # Philox counters one template of templates_prior consumes (csrc/synth_fused.hip: kPriorTrials)
 
-    def templates_prior(self, nb, seed, counter, idx_lo, idx_hi, g=1.0, dtype=torch.float32, want_params=False):
+    def templates_prior(self, nb, seed, counter, idx_lo, idx_hi, g=1.0, dtype=torch.float32, want_params=False, noise=None, noise_seed=0, noise_counter=0):
         """nb templates whose (m1, m2, idx) are drawn from the hunt_constrain prior INSIDE the synthesis kernel (gn_synth_templates_prior):
         returns (crops (nb, fs), labels (nb, 2) = [mc, m2/m1] fp32, ref_idx) -- plus (m1m2 (nb, 2) f64, idx (nb,) i32) with want_params.
-        A pure function of (seed, counter); the caller advances counter by nb * PRIOR_TRIALS."""
+        A pure function of (seed, counter); the caller advances counter by nb * PRIOR_TRIALS.
+        noise: a NoiseSynth of the same (fs, T_obs, psd) -- the same launch then adds PSD-coloured, whitened noise from the Philox stream
+        (noise_seed, noise_counter) to every row (gn_synth_templates_noise; the caller advances noise_counter by nb * Nf)."""
         if self.N not in self.FUSED_N:
             raise NotImplementedError('templates_prior: series length %d is outside the fused kernel\'s range %r' % (self.N, self.FUSED_N))
         out = torch.empty((nb, self.fs), dtype=dtype, device=device())
@@ -327,12 +370,40 @@ class Synth(object):
         io = torch.empty((nb,), dtype=torch.int32, device=device()) if want_params else None
         if nb:
             c0 = int((self.T_obs / 2) * self.fs - self.fs / 2)
-            _lib.call('gn_synth_templates_prior', self.scale.data_ptr(), twiddles(self.N).data_ptr(), out.data_ptr() if dtype == torch.float64 else None,
-                      out.data_ptr() if dtype == torch.float32 else None, labels.data_ptr(), None if mo is None else mo.data_ptr(),
-                      None if io is None else io.data_ptr(), ref.data_ptr(), nb, self.N, self.fs, c0, self.fs, self.peak_off, 1.0 / self.T_obs, self.f_low,
-                      self.dist_mpc, float(IOTA), float(PHI), float(self.Fp), float(self.Fc), float(g), int(seed), int(counter), int(idx_lo), int(idx_hi), 5.0, 100.0, _s())
+            o64 = out.data_ptr() if dtype == torch.float64 else None
+            o32 = out.data_ptr() if dtype == torch.float32 else None
+            mo_p, io_p = None if mo is None else mo.data_ptr(), None if io is None else io.data_ptr()
+            if noise is None:
+                _lib.call('gn_synth_templates_prior', self.scale.data_ptr(), twiddles(self.N).data_ptr(), o64, o32, labels.data_ptr(), mo_p, io_p,
+                          ref.data_ptr(), nb, self.N, self.fs, c0, self.fs, self.peak_off, 1.0 / self.T_obs, self.f_low,
+                          self.dist_mpc, float(IOTA), float(PHI), float(self.Fp), float(self.Fc), float(g), int(seed), int(counter), int(idx_lo), int(idx_hi),
+                          5.0, 100.0, _s())
+            else:
+                assert (noise.fs, noise.T_obs) == (self.fs, self.T_obs)
+                _lib.call('gn_synth_templates_noise', None, None, None, self.scale.data_ptr(), twiddles(self.N).data_ptr(), noise.amp.data_ptr(),
+                          noise.win.data_ptr(), o64, o32, labels.data_ptr(), mo_p, io_p, ref.data_ptr(), nb, self.N, self.fs, c0, self.fs, self.peak_off,
+                          1.0 / self.T_obs, self.f_low, self.dist_mpc, float(IOTA), float(PHI), float(self.Fp), float(self.Fc), float(g), int(seed),
+                          int(counter), int(idx_lo), int(idx_hi), 5.0, 100.0, int(noise_seed), int(noise_counter), None, _s())
         return (out, labels, ref, mo, io) if want_params else (out, labels, ref)
 
+    def templates_noise(self, m1, m2, idx, noise, noise_seed, noise_counter, g=1.0, dtype=torch.float32, want_normals=False):
+        """templates() with the coloured-noise chain run by the same workgroups (gn_synth_templates_noise, given parameters): (nb, fs) rows
+        = template * g + whitened noise of stream (noise_seed, noise_counter), and ref_idx; want_normals adds the (nb, 2 Nf) normals used."""
+        m1 = np.atleast_1d(np.asarray(m1, np.float64)); m2 = np.atleast_1d(np.asarray(m2, np.float64)); idx = np.atleast_1d(idx)
+        nb = m1.size
+        out = torch.empty((nb, self.fs), dtype=dtype, device=device())
+        ref = torch.empty((nb,), dtype=torch.int32, device=device())
+        nout = torch.empty((nb, 2 * noise.Nf), dtype=torch.float64, device=device()) if want_normals else None
+        if nb:
+            c0 = int((self.T_obs / 2) * self.fs - self.fs / 2)
+            m1d, m2d = _d64(m1), _d64(m2)
+            idx_t = torch.as_tensor(np.ascontiguousarray(idx, np.int32)).to(device())
+            _lib.call('gn_synth_templates_noise', m1d.data_ptr(), m2d.data_ptr(), idx_t.data_ptr(), self.scale.data_ptr(), twiddles(self.N).data_ptr(),
+                      noise.amp.data_ptr(), noise.win.data_ptr(), out.data_ptr() if dtype == torch.float64 else None,
+                      out.data_ptr() if dtype == torch.float32 else None, None, None, None, ref.data_ptr(), nb, self.N, self.fs, c0, self.fs, self.peak_off,
+                      1.0 / self.T_obs, self.f_low, self.dist_mpc, float(IOTA), float(PHI), float(self.Fp), float(self.Fc), float(g), 0, 0, 0, 0, 5.0, 100.0,
+                      int(noise_seed), int(noise_counter), None if nout is None else nout.data_ptr(), _s())
+        return (out, ref, nout) if want_normals else (out, ref)
 
 
 def make_bbh(hp, hc, fs, ra, dec, psi, det):
@@ -535,7 +606,8 @@ class OnlineBank(object):
     the hunt_constrain rejection rule and its idx from randint(convert_beta(beta)) out of a counter-based Philox stream, evaluates
     the chirp, whitens, transforms, aligns and crops, scales by gw_norm_constant and writes the fp32 row and its labels [mc, m2/m1].
     The stream is (seed, counter): data-parallel ranks pass different seeds and never exchange anything; two banks with
-    the same seed produce the same batches.  noise='coloured' adds gen_noise (Philox) -> whiten_data('td') -> central crop;
+    the same seed produce the same batches.  noise='coloured' adds gen_noise (Philox) -> whiten_data('td') -> central crop, generated and
+    whitened inside the same kernel launch (gn_synth_templates_noise; NoiseSynth);
     noise='white' adds N(0,1) as the reference's train loops do (bbhMahoGANy.py:1161, :1277).  Series lengths the fused kernel does
     not cover (N < 1024) draw the parameters on the host (prior='host' forces that everywhere)."""
 
@@ -553,7 +625,8 @@ class OnlineBank(object):
         self.prior_counter = 0             # parameter stream position (seed + 2^32: disjoint from the noise stream)
         self.n_pix = self.fs
         self.prior = prior or ('device' if self.N in Synth.FUSED_N else 'host')
-        self._win = _d64(tukey(self.N, alpha=1.0 / 8.0)) if noise == 'coloured' else None
+        self.nsyn = NoiseSynth(fs, T_obs, self.psd) if (noise == 'coloured' and self.N in Synth.FUSED_N) else None
+        self._win = _d64(tukey(self.N, alpha=1.0 / 8.0)) if (noise == 'coloured' and self.nsyn is None) else None
 
     def draw_masses(self, n):
         """hunt_constrain prior (gw_template_maker.py:327-339), vectorised rejection sampling on the host (prior='host')."""
@@ -582,9 +655,40 @@ class OnlineBank(object):
         labels = torch.as_tensor(np.stack([(m1 + m2) * eta ** 0.6, m2 / m1], axis=1).astype(np.float32)).to(device())
         return out, labels
 
+    def draw_clean(self, batch):
+        """-> (noise-free templates (batch, fs) fp32, labels): what the GAN loop's real images carry in column 0 (bbhMahoGANy.py:1277-1284)."""
+        return self._templates(batch, torch.float32)
+
+    def draw_noise(self, batch):
+        """-> (batch, fs) fp32 noise rows of this bank's kind: 'coloured' = gen_noise -> whiten_data('td') -> crop in one launch
+        (gn_noise_whitened), otherwise N(0,1) (what the reference's loops draw, :1161, :1277).  The GAN loop's noise column."""
+        if self.noise == 'coloured' and self.nsyn is not None:
+            out = self.nsyn.draw(batch, self.seed, self.counter, dtype=torch.float32)
+            self.counter += batch * (self.N // 2 + 1)
+            return out
+        out = torch.empty((batch, self.fs), dtype=torch.float32, device=device())
+        _lib.call('gn_fill_normal', out.data_ptr(), out.numel(), 0.0, 1.0, self.seed, self.counter, _s())
+        self.counter += out.numel()
+        return out
+
     def draw(self, batch):
-        """-> (images (batch, fs) fp32, labels (batch, 2) fp32), both device tensors."""
+        """-> (images (batch, fs) fp32 = template + this bank's noise, labels (batch, 2) fp32), both device tensors.
+        noise='coloured': ONE launch per batch when the prior is drawn on the device (gn_synth_templates_noise: prior -> chirp -> inverse
+        transforms -> align -> crop, then gen_noise -> whiten_data('td') -> crop in the same workgroup, sum written as fp32); with host-drawn
+        parameters the template kernel writes fp64 rows and the fused noise kernel adds to them.  Series lengths below 1024 run the
+        separate fp64 kernels."""
         c0 = int((self.T_obs / 2) * self.fs - self.fs / 2)
+        if self.noise == 'coloured' and self.nsyn is not None:
+            Nf = self.N // 2 + 1
+            if self.prior == 'device':
+                out, labels, _ = self.syn.templates_prior(batch, self.seed + (1 << 32), self.prior_counter, self.lo, self.hi, g=self.g, dtype=torch.float32,
+                                                          noise=self.nsyn, noise_seed=self.seed, noise_counter=self.counter)
+                self.prior_counter += batch * Synth.PRIOR_TRIALS
+            else:
+                ts, labels = self._templates(batch, torch.float64)
+                out = self.nsyn.draw(batch, self.seed, self.counter, add=ts.contiguous(), dtype=torch.float32)
+            self.counter += batch * Nf
+            return out, labels
         if self.noise == 'coloured':
             ts, labels = self._templates(batch, torch.float64)
             nz = gen_noise_device(self.fs, self.T_obs, self.psd, batch, self.seed, self.counter)
@@ -597,7 +701,5 @@ class OnlineBank(object):
         else:
             out, labels = self._templates(batch, torch.float32)       # fp32 rows straight from the fused kernel
         if self.noise == 'white':
-            _lib.call('gn_fill_normal', (nz32 := torch.empty_like(out)).data_ptr(), out.numel(), 0.0, 1.0, self.seed, self.counter, _s())
-            self.counter += out.numel()
-            _lib.call('gn_axpy', out.data_ptr(), nz32.data_ptr(), 1.0, out.numel(), _s())
+            _lib.call('gn_axpy', out.data_ptr(), self.draw_noise(batch).data_ptr(), 1.0, out.numel(), _s())
         return out, labels

@@ -290,6 +290,27 @@ int gn_synth_templates_prior(const double* scale, const double* twiddle, double*
                              int32_t* idx_out, int32_t* ref_idx, int nb, int N, int roll, int crop0, int crop_len, int peak_off,
                              double df, double f_low, double dist_mpc, double iota, double phi0, double Fp, double Fc, double g,
                              uint64_t seed, uint64_t counter, int idx_lo, int idx_hi, double m_min, double M_max, void* stream);
+/* PSD-coloured Gaussian noise generated AND whitened in one launch, one workgroup per row, nothing but the crop written (BASELINE
+ * configs[4]): replaces gen_noise (gw_template_maker.py:161-193: amp = sqrt(0.25 T psd), 0 where psd == 0; re, im = amp * N(0,1), Nf draws
+ * each, re block first; DC = 0; x = N * irfft(re + i im) * df) followed by whiten_data(x, flag='td') (:243-286: rfft(tukey(N, 1/8) * x) *
+ * sqrt(2 invpsd / fs), DC = 0, irfft) and the crop [crop0, crop0 + crop_len) of sim_data (:695), all fp64 in LDS.
+ * amp, wscale: (N/2+1) tables; window: (N) tukey(N, 1/8); twiddle as for gn_irfft_f64.  normals_in (nb, 2 (N/2+1)) = numpy's draws per row
+ * [re block | im block], or NULL: Philox (bin k of row b = counter + b (N/2+1) + k of stream `seed`, Box-Muller -> (re, im)); normals_out
+ * (same layout) or NULL receives the normals used.  add_f64 (nb, crop_len) or NULL: rows the noise is added to (template crops).
+ * out_f64 / out_f32 (nb, crop_len): at least one.  N in {1024, 2048, 4096, 8192, 16384}. */
+int gn_noise_whitened(const double* amp, const double* wscale, const double* window, const double* twiddle, const double* normals_in,
+                      double* normals_out, const double* add_f64, double* out_f64, float* out_f32, int nb, int N, int crop0, int crop_len,
+                      double df, uint64_t seed, uint64_t counter, void* stream);
+/* gn_synth_templates / gn_synth_templates_prior (m1 == m2 == idx == NULL: prior mode) with that noise chain run by the SAME workgroup after
+ * the template's crop is formed: out = template * g + whitened coloured noise, one launch per batch (BASELINE configs[4]: "template + noise
+ * synth fused into the train loop").  scale doubles as the whitening scale of the noise; noise_amp, window as for gn_noise_whitened; the
+ * noise stream is (noise_seed, noise_counter), row b bin k = noise_counter + b (N/2+1) + k.  crop_len <= N/4. */
+int gn_synth_templates_noise(const double* m1, const double* m2, const int32_t* idx, const double* scale, const double* twiddle,
+                             const double* noise_amp, const double* window, double* out_f64, float* out_f32, float* labels, double* m_out,
+                             int32_t* idx_out, int32_t* ref_idx, int nb, int N, int roll, int crop0, int crop_len, int peak_off, double df,
+                             double f_low, double dist_mpc, double iota, double phi0, double Fp, double Fc, double g, uint64_t seed,
+                             uint64_t counter, int idx_lo, int idx_hi, double m_min, double M_max, uint64_t noise_seed,
+                             uint64_t noise_counter, double* normals_out, void* stream);
 /* gen_noise (gw_template_maker.py:161-193) spectrum: X[b,f] = amp[f]*(xi_re + i xi_im), DC = 0 (Philox normals, re block then im block) */
 int gn_noise_fd(const double* amp, double* X, int nb, int Nf, uint64_t seed, uint64_t offset, void* stream);
 /* x *= s (fp64), used for N*df and gw_norm_constant scalings; and fp64 -> fp32 narrowing with scale */

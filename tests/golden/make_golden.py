@@ -143,6 +143,19 @@ def main():
     out['noise_out'] = ns['gen_noise'](fs, T, psd)
     np.random.seed(7)
     out['noise_normals'] = np.random.normal(0, 1, 2 * Nf)          # the draws it consumed: re block then im block
+    # gen_noise -> whiten_data('td') composed (BASELINE configs[4]: coloured noise whitened with the same PSD), the reference's two functions
+    # as written, at N = 1024 and N = 8192; the normals consumed are stored so that the fused kernel can be fed the same draws
+    for fs_, seed_ in ((256, 17), (2048, 18)):
+        N_ = fs_ * T; Nf_ = N_ // 2 + 1
+        prng = np.random.RandomState(seed_)
+        psd_ = np.abs(prng.randn(Nf_)) * 1e-3 + 1e-4
+        psd_[:5] = 0.0; psd_[Nf_ // 3] = 0.0
+        np.random.seed(seed_)
+        x_ = ns['gen_noise'](fs_, T, psd_)
+        np.random.seed(seed_)
+        out['nchain_%d_normals' % fs_] = np.random.normal(0, 1, 2 * Nf_)
+        out['nchain_%d_psd' % fs_] = psd_
+        out['nchain_%d_out' % fs_] = ns['whiten_data'](x_.copy(), T, fs_, psd_, 'td')
     # hunt_constrain rejection sampler: 200 accepted draws and the stream position afterwards
     np.random.seed(1)
     acc = []

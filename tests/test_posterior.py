@@ -41,3 +41,16 @@ def test_posterior_samples_pipeline_shapes():
     pe, waves = bbh.posterior_samples(nets, 96)
     assert waves.shape == (96, 64, 1) and pe[0].shape == (96, 1) and pe[1].shape == (96, 1)
     assert pe[0].dtype == np.float32 and np.isfinite(pe[0]).all() and np.all((pe[1] >= 0) & (pe[1] <= 1))
+
+
+def test_score_grid_is_the_100j_mesh():
+    """posterior.score_grid produces the point set and order of np.mgrid[a:b:100j, c:d:100j] -> vstack(ravel) (the mesh of bbhMahoGANy.py:858-859)
+    bit for bit (host helper, no device call)."""
+    from gennet_amd import posterior
+    rng = np.random.RandomState(3)
+    for _ in range(20):
+        lo = rng.randn(2) * 10; hi = lo + np.abs(rng.randn(2)) * 5 + 1e-3
+        X, Y = np.mgrid[lo[0]:hi[0]:100j, lo[1]:hi[1]:100j]
+        assert np.array_equal(posterior.score_grid(lo, hi), np.vstack([X.ravel(), Y.ravel()]))
+    a = rng.rand(50); b = rng.rand(50)
+    assert posterior.pdf_overlap(a, a) == pytest.approx(1.0) and 0 < posterior.pdf_overlap(a, b) < 1

@@ -369,6 +369,87 @@ def test_posterior_driven_mode_matches_reference_execution(fs):
         np.random.set_state(st)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# fused coloured noise (BASELINE configs[4]): gen_noise -> whiten_data('td') -> crop in one kernel (csrc/noise_chain.h)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fs", [256, 2048])
+def test_fused_noise_matches_the_reference_composition(fs):
+    """gn_noise_whitened fed the SAME normals against whiten_data(gen_noise(...), 'td') as the reference's own two functions produced it
+    (tests/golden/synth_golden.npz: nchain_*), whole series (crop = [0, N)) and the central second, <= 1e-12; a PSD with zero bins."""
+    from gennet_amd import templates as T
+    psd = G['nchain_%d_psd' % fs]
+    N = 4 * fs
+    ns = T.NoiseSynth(fs, 4, psd)
+    ref = G['nchain_%d_out' % fs]
+    nrm = G['nchain_%d_normals' % fs].reshape(1, -1)
+    full = ns.draw(1, normals=nrm, dtype=torch.float64, crop=(0, N)).cpu().numpy()[0]
+    assert rel(full, ref) < 1e-12
+    mid = ns.draw(1, normals=nrm, dtype=torch.float64).cpu().numpy()[0]
+    assert np.array_equal(mid, full[int(1.5 * fs):int(2.5 * fs)])
+    # three rows at once, fp32 output added to a template row: out = float(add + noise)
+    nrm3 = np.stack([nrm[0], -nrm[0], nrm[0][::-1]])
+    add = dev64(np.random.RandomState(1).randn(3, fs))
+    o32 = ns.draw(3, normals=nrm3, add=add, dtype=torch.float32)
+    o64 = ns.draw(3, normals=nrm3, dtype=torch.float64)
+    assert torch.equal(o32, (add + o64).float())
+    assert rel(o64[0].cpu().numpy(), mid) == 0 and rel(o64[1].cpu().numpy(), -mid) < 1e-13          # the chain is linear in the normals
+    assert ns.draw(0).shape == (0, fs)
+
+
+@pytest.mark.parametrize("fs", [1024, 4096])
+def test_fused_noise_philox_stream_against_the_oracle_chain(fs):
+    """Philox mode: the normals the kernel drew (normals_out) pushed through the numpy oracle (gen_noise's spectrum construction, irfft,
+    whiten_data('td')) reproduce its output to 1e-12; the stream is a pure function of (seed, counter, row); statistics of the whitened
+    series (std ~ sqrt(mean tukey^2) = 0.96 over the whole series, ~1 inside the flat part of the window)."""
+    from gennet_amd import templates as T
+    N = 4 * fs; Nf = N // 2 + 1
+    psd = S.analytic_psd(Nf, 0.25)
+    ns = T.NoiseSynth(fs, 4, psd)
+    out, nrm = ns.draw(4, seed=5, counter=1000, dtype=torch.float64, crop=(0, N), want_normals=True)
+    out = out.cpu().numpy(); nrm = nrm.cpu().numpy()
+    amp = np.sqrt(0.25 * 4 * psd); amp[psd == 0.0] = 0.0
+    for b in range(4):
+        re = amp * nrm[b, :Nf]; im = amp * nrm[b, Nf:]
+        re[0] = 0.0; im[0] = 0.0
+        x = N * np.fft.irfft(re + 1j * im) * 0.25
+        assert rel(out[b], S.whiten_data(x, 4, fs, psd, 'td')) < 1e-12
+    assert abs(nrm.mean()) < 0.02 and abs(nrm.std() - 1.0) < 0.02
+    again = ns.draw(4, seed=5, counter=1000, dtype=torch.float64, crop=(0, N)).cpu().numpy()
+    assert np.array_equal(out, again)
+    shifted = ns.draw(3, seed=5, counter=1000 + Nf, dtype=torch.float64, crop=(0, N)).cpu().numpy()
+    assert np.array_equal(shifted, out[1:])                            # row b of a launch = row 0 of a launch whose counter is b * Nf further
+    assert not np.array_equal(ns.draw(1, seed=6, counter=1000, dtype=torch.float64, crop=(0, N)).cpu().numpy()[0], out[0])
+    mid = out[:, int(1.5 * fs):int(2.5 * fs)]
+    live = psd > 0                                                      # bins below the PSD floor carry no noise: expected variance = live fraction
+    assert abs(mid.std() - np.sqrt(live[1:].mean())) < 0.05
+
+
+@pytest.mark.parametrize("fs", [512, 2048, 4096])
+def test_template_plus_noise_in_one_launch_equals_the_two_kernels(fs):
+    """gn_synth_templates_noise (template and coloured noise by the same workgroup, crop waiting in registers) against the template kernel
+    writing fp64 rows + gn_noise_whitened adding to them, same Philox stream: bit-identical, fp64 and fp32, given parameters and prior mode."""
+    from gennet_amd import templates as T
+    N = 4 * fs; Nf = N // 2 + 1
+    psd = S.analytic_psd(Nf, 0.25)
+    syn = T.Synth(fs, 4, psd); ns = T.NoiseSynth(fs, 4, psd)
+    np.random.seed(fs)
+    pars = [T.gen_par(fs, 4, mdist='hunt_constrain', beta=[0.45, 0.55]) for _ in range(5)]
+    m1 = [p.m1 for p in pars]; m2 = [p.m2 for p in pars]; idx = [p.idx for p in pars]
+    g = 817.98
+    ts, ref = syn.templates(m1, m2, idx, g=g, dtype=torch.float64)
+    two64 = ns.draw(5, seed=9, counter=77, add=ts, dtype=torch.float64)
+    two32 = ns.draw(5, seed=9, counter=77, add=ts, dtype=torch.float32)
+    one64, ref1 = syn.templates_noise(m1, m2, idx, ns, 9, 77, g=g, dtype=torch.float64)
+    one32, _ = syn.templates_noise(m1, m2, idx, ns, 9, 77, g=g, dtype=torch.float32)
+    assert torch.equal(ref, ref1) and torch.equal(one64, two64) and torch.equal(one32, two32)
+    assert float((two64 - ts).std()) > 0.5                              # the noise really is there
+    lo, hi = T.convert_beta([0.45, 0.55], fs, 4)
+    p_ts, p_lab, p_ref = syn.templates_prior(6, 3, 0, lo, hi, g=g, dtype=torch.float64)
+    p_two = ns.draw(6, seed=4, counter=11, add=p_ts, dtype=torch.float32)
+    p_one, p_lab1, p_ref1 = syn.templates_prior(6, 3, 0, lo, hi, g=g, dtype=torch.float32, noise=ns, noise_seed=4, noise_counter=11)
+    assert torch.equal(p_one, p_two) and torch.equal(p_lab, p_lab1) and torch.equal(p_ref, p_ref1)
+
+
 def test_online_bank_config5_fs4096():
     """BASELINE config 5 (srate 4096): on-GPU synthesis inside the loop.  Size-independent properties at full size: labels obey the
     prior box, the envelope peak lands inside the crop-relative window [1649, 2468) + peak offset, draws are
@@ -388,9 +469,14 @@ def test_online_bank_config5_fs4096():
     x3, _ = T.OnlineBank(fs, Tobs, psd, seed=4).draw(64)
     assert not torch.equal(x, x3)
     obn = T.OnlineBank(fs, Tobs, psd, seed=3, noise='coloured')
-    xn, _ = obn.draw(64)
+    xn, yn = obn.draw(64)
+    assert torch.equal(yn, y)                                # same prior stream: the same templates underneath
     resid = (xn - x).cpu().numpy()
-    assert abs(resid.std() - 0.95) < 0.06                    # sqrt(mean tukey^2) loss of the 'td' whitening path
+    assert abs(resid.std() - 0.99) < 0.06                    # whitened coloured noise has unit variance inside the flat part of the Tukey window
+    xn2, _ = T.OnlineBank(fs, Tobs, psd, seed=3, noise='coloured').draw(64)
+    assert torch.equal(xn, xn2)
+    xh, _ = T.OnlineBank(fs, Tobs, psd, seed=3, noise='coloured', prior='host').draw(8)      # host-drawn parameters: template kernel + noise kernel
+    assert xh.shape == (8, fs) and torch.isfinite(xh).all()
 
 
 def test_pe_train_step_online_runs_at_fs2048():

@@ -105,6 +105,17 @@ def test_config5_both_loops_at_n_pix_4096_with_synthesis_in_the_loop():
     r = bbh.gan_train_step(nets, bank, ev, 4, predict_batch=4)
     assert len(r) == 4 and np.isfinite(r).all() and 0.0 <= r[1] <= 1.0 and 0.0 <= r[3] <= 1.0
     assert any(not torch.equal(a, q.data) for a, q in zip(d_before, [q for l in D.layers for q in l.params]))       # the D step moved D
+    # ... and the loop body the bench's cfg5 runs: real column 0 = noise-free templates drawn in the kernel, column 1 = coloured + whitened noise
+    seen = {}
+    orig = D.train_on_batch
+    D.train_on_batch = lambda x_, y_, **kw: (seen.update(x=x_), orig(x_, y_, **kw))[1]
+    r2 = bbh.gan_train_step_online(nets, ob, ev, 4, predict_batch=4)
+    D.train_on_batch = orig
+    assert len(r2) == 4 and np.isfinite(r2).all()
+    col0, col1 = seen['x'][:4, :, 0, 0], seen['x'][:4, :, 1, 0]
+    assert 0.9 < float(col1.std()) < 1.1 and abs(float(col1.mean())) < 0.1                       # whitened coloured noise: unit variance
+    pk = col0.abs().argmax(dim=1).cpu().numpy()                                                  # a clean chirp: its peak sits in the idx window (Appendix D)
+    assert np.all((pk >= 7782 + 11 - 6144 - 40) & (pk < 8601 + 11 - 6144 + 40))
     d_mid = [q.data.clone() for l in D.layers for q in l.params]
     z = ops.fill_uniform((4, 100), -1.0, 1.0, 3, 0, engine.device())
     DG.train_on_batch(z, np.ones(4, np.float32))
