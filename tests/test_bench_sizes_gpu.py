@@ -23,16 +23,19 @@ def flat_grads(model):
     return [grp.grad[a:b].clone() for grp, a, b in segments(model._train_params)]
 
 
-def per_param_rel(model, ga, gb):
-    """max |ga - gb| / max |gb| per trainable tensor."""
+def per_param_rel(model, ga, gb, gabs):
+    """max |ga - gb| per trainable tensor, relative to the larger of max |gb| and max of gabs = the mean over chunks of |chunk gradient|: the
+    size of the terms that were summed (a one-element bias gradient is a sum of 1024 values of both signs that nearly cancels at
+    initialisation; its rounding error scales with the terms, not with the small sum)."""
     from gennet_amd.engine import segments
     segs = segments(model._train_params)
     out = {}
     for p in model._train_params:
-        for (grp, a, b), fa, fb in zip(segs, ga, gb):
+        for (grp, a, b), fa, fb, fs in zip(segs, ga, gb, gabs):
             if grp is p.group and a <= p.offset and p.offset + p.size <= b:
-                x = fa[p.offset - a:p.offset - a + p.size]; y = fb[p.offset - a:p.offset - a + p.size]
-                out[p.name + str(tuple(p.shape))] = float((x - y).abs().max() / y.abs().max().clamp_min(1e-30))
+                sl = slice(p.offset - a, p.offset - a + p.size)
+                scale = torch.maximum(fb[sl].abs().max(), fs[sl].max()).clamp_min(1e-30)
+                out[p.name + str(tuple(p.shape))] = float((fa[sl] - fb[sl]).abs().max() / scale)
     return out
 
 
@@ -53,18 +56,19 @@ def test_discriminator_step_on_2x512_rows_equals_its_64_row_chunks():
     full = D.train_on_batch(sX, sy, dropout_masks=masks)
     g_full = flat_grads(D)
     assert np.isfinite(full).all() and 0.2 < full[0] < 3.0
-    acc = None
+    acc = gabs = None
     losses, hits = [], []
     for s in range(0, 2 * B, CHUNK):
         r = D.train_on_batch(sX[s:s + CHUNK], sy[s:s + CHUNK], dropout_masks={k: m[s:s + CHUNK] for k, m in masks.items()})
         losses.append(r[0]); hits.append(r[1])
         g = flat_grads(D)
         acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+        gabs = [x.abs() for x in g] if gabs is None else [a + b.abs() for a, b in zip(gabs, g)]
     n_chunks = 2 * B // CHUNK
-    acc = [a / n_chunks for a in acc]
+    acc = [a / n_chunks for a in acc]; gabs = [a / n_chunks for a in gabs]
     assert abs(full[0] - np.mean(losses)) <= 1e-5 * abs(np.mean(losses)), (full, np.mean(losses))
     assert abs(full[1] - np.mean(hits)) < 1e-9                                                      # binary accuracy is a count
-    rels = per_param_rel(D, g_full, acc)
+    rels = per_param_rel(D, g_full, acc, gabs)
     assert max(rels.values()) < 1e-4, rels
     w0 = [p.data.clone() for p in D._train_params]
     D.train_on_batch(sX[:CHUNK], sy[:CHUNK])
@@ -86,16 +90,17 @@ def test_pe_step_on_256_rows_equals_its_64_row_chunks():
     full = pe.train_on_batch(x, [ymc, yq])
     g_full = flat_grads(pe)
     assert len(full) == 5 and np.isfinite(full).all()
-    acc, rows = None, []
+    acc, gabs, rows = None, None, []
     for s in range(0, B, CHUNK):
         rows.append(pe.train_on_batch(x[s:s + CHUNK], [ymc[s:s + CHUNK], yq[s:s + CHUNK]]))
         g = flat_grads(pe)
         acc = g if acc is None else [a + b for a, b in zip(acc, g)]
-    acc = [a / (B // CHUNK) for a in acc]
+        gabs = [v.abs() for v in g] if gabs is None else [a + b.abs() for a, b in zip(gabs, g)]
+    acc = [a / (B // CHUNK) for a in acc]; gabs = [a / (B // CHUNK) for a in gabs]
     mean = np.mean(np.array(rows), axis=0)
     for k in range(3):                                     # total, mc loss, q loss
         assert abs(full[k] - mean[k]) <= 1e-5 * abs(mean[k]) + 1e-9, (k, full, mean)
-    rels = per_param_rel(pe, g_full, acc)
+    rels = per_param_rel(pe, g_full, acc, gabs)
     assert max(rels.values()) < 1e-4, rels
     # predict: 256 rows at once == 4 x 64 rows, bit for bit (row-independent kernels, fixed reduction order per output)
     p_full = pe.predict_device(x, batch_size=B)
@@ -134,6 +139,8 @@ def test_generator_at_batch_512_predict_chunks_and_batchnorm_statistics():
         mm = bn.moving_mean.data.double(); mv = bn.moving_variance.data.double()
         assert float((mm - mean).abs().max()) <= 2e-6 * float(var.sqrt().max()) + 1e-7, (bn.name, n)
         want = var * n / (n - (1.0 + bn.epsilon))
-        assert float(((mv - want).abs() / want).max()) <= 2e-5, (bn.name, n)
+        # TF's update is variable -= variable - biased / (1 - m^t) in fp32: the difference from the OLD value 1.0 is rounded at 1.0's ulp
+        # (6e-8), an absolute error that the first layer's small variances (~2e-4) see as 1e-4 relative -- the reference arithmetic's own
+        assert float(((mv - want).abs() - 1.2e-7).clamp_min(0).div(want).max()) <= 2e-5, (bn.name, n)
     del cap
     assert all(torch.equal(a_, p.data) for a_, p in zip(d_before, nets.signal_discriminator._train_params))      # D frozen in the G step

@@ -25,6 +25,11 @@ def test_point_estimator_learns_chirp_mass_from_online_templates():
     print('mc loss first %.1f last %.3f prior variance %.2f; q loss first %.3f last %.4f' % (first, last, prior_var, np.mean([h[2] for h in hist[:5]]), np.mean([h[2] for h in hist[-100:]])))
     assert first > 300.0                                       # starts near E[mc^2]
     assert last < 0.25 * prior_var                             # and ends far below the trivial predictor (measured: 0.3-1.7 against 17.8)
+    # At lr 3e-4 one Adam step moves each of the head's 31 232 weights by ~lr in the direction of its gradient, i.e. the read-out by O(1):
+    # the LAST iterate is a noisy member of the trajectory (the averaged loss above is not).  150 steps at lr / 10 settle it before it is scored.
+    pe.optimizer.lr = 3e-5
+    for _ in range(150):
+        bbh.pe_train_step_online(pe, ob, B, cnn_noise_frac=0.0, nprng=rng)
     xt, yt = ob.draw(256)
     mc_hat, q_hat = pe.predict(xt.reshape(256, fs, 1).cpu().numpy())
     err = mc_hat[:, 0] - yt[:, 0].cpu().numpy()
