@@ -62,6 +62,10 @@ _SIGS = {
     'gn_bce_loss': [vp, vp, vp, vp, i32, i32, vp],
     'gn_mse_loss': [vp, vp, vp, vp, i32, i32, vp],
     'gn_adam_step': [vp, vp, vp, vp, sz, f32, f32, f32, f32, vp],
+    'gn_set_rng_base': [vp],
+    'gn_adam_step_dyn': [vp, vp, vp, vp, sz, vp, f32, f32, f32, vp],
+    'gn_fill_normal_dyn': [vp, sz, f32, vp, u64, u64, vp],
+    'gn_bn_finalize_zero_debias_dyn': [vp, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     'gn_prof_enable': [i32],
     'gn_prof_reset': [],
     'gn_prof_collect': [i32, vp],

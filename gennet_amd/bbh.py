@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .engine import Adam, Input, Model, Sequential, device, device_rng, to_device
+from .engine import Adam, Input, Model, Sequential, StepGraph, capturing, device, device_rng, to_device
 from .layers import (Activation, BatchNormalization, Conv1D, Conv2D, Dense, Dropout, Flatten, LeakyReLU, MyLayer, ReLU,
                      Reshape, UpSampling1D)
 
@@ -278,6 +278,105 @@ def gan_train_step(nets, bank, event, batch, rng=_pyrandom, rank=0, world=1, pre
     z = ops.fill_uniform((batch, 100), -1.0, 1.0, seed, off, device())
     sg_loss = nets.signal_discriminator_on_generator.train_on_batch(z, torch.ones(batch, device=device()))
     return [sg_loss[0], sg_loss[1], sd_loss[0], sd_loss[1]]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the two loop bodies as captured hipGraphs (the reference's own operating point, batch_size = pe_batch_size = 8, n_pix = 1024,
+# bbhMahoGANy.py:84-89, is launch-bound: a few hundred launches of microseconds each per iteration)
+# --------------------------------------------------------------------------------------------------------------
+class _GraphedStep(object):
+    """Call 1 runs the step eagerly (binds optimizer state, triggers every lazy initialisation); call 2 captures the step into a
+    hipGraph (engine.StepGraph) and replays it; later calls replay.  The sequence of results is bit-identical to calling the eager step
+    every time: same host index stream, same Philox stream positions, same Adam / BatchNormalization step counts.
+    want_losses=False skips the device -> host read of the loss statistics (and with it the per-step synchronisation)."""
+
+    def __init__(self, bank, batch, rng, rank, world):
+        self.bank, self.batch, self.rng, self.rank, self.world = bank, int(batch), rng, rank, world
+        self.calls = 0
+        self.sg = None
+        self.it = torch.zeros(self.batch, dtype=torch.int64, device=device())
+        self.it_host = torch.zeros(self.batch, dtype=torch.int64).pin_memory()
+
+    def _stage_indices(self):
+        idx = sample_indices(self.bank.n, self.batch, self.rng, self.rank, self.world)
+        self.it_host.numpy()[:] = idx
+        self.it.copy_(self.it_host, non_blocking=True)
+
+    def __call__(self, want_losses=True):
+        self.calls += 1
+        if self.calls == 1:
+            return self._eager()
+        if self.sg is None:
+            self.sg = StepGraph()
+            self._stage_indices()
+            torch.cuda.synchronize()
+            self.sg.capture(self._body)
+        else:
+            self.sg.wait_inputs_consumed()
+            self._stage_indices()
+        outs = self.sg.replay()
+        return self._result(outs) if want_losses else None
+
+
+class GraphedPEStep(_GraphedStep):
+    """pe_train_step (bbhMahoGANy.py:1155-1165) as a replayed hipGraph."""
+
+    def __init__(self, signal_pe, bank, batch, cnn_noise_frac=1.0 / 8.0, rng=_pyrandom, nprng=np.random, rank=0, world=1):
+        _GraphedStep.__init__(self, bank, batch, rng, rank, world)
+        if signal_pe.data_parallel is not None:
+            raise NotImplementedError('GraphedPEStep under data parallelism (the collectives are not captured)')
+        self.model, self.frac, self.nprng = signal_pe, cnn_noise_frac, nprng
+
+    def _eager(self):
+        return pe_train_step(self.model, self.bank, self.batch, self.frac, self.rng, self.nprng, self.rank, self.world)
+
+    def _body(self):
+        b, n = self.batch, self.bank.n_pix
+        x = ops.gather_rows(self.bank.images, self.it)
+        y = ops.gather_rows(self.bank.pars, self.it)
+        n_noisy = int(b * self.frac)
+        sigma = capturing().slot('f', lambda: float(self.nprng.uniform(0, 5)))          # drawn once per replay, like :1161's np.random.uniform(0, 5)
+        if n_noisy > 0:
+            seed, off = device_rng().take(n_noisy * n)
+            ops.axpy(x[:n_noisy], ops.fill_normal((n_noisy, n), 0.0, sigma, seed, off, device()), 1.0)
+        return self.model.train_on_batch_device([x.reshape(b, n, 1)], [y[:, 0].contiguous().reshape(b, 1), y[:, 1].contiguous().reshape(b, 1)])
+
+    def _result(self, stats):
+        return self.model.train_result(stats, self.batch)
+
+
+class GraphedGANStep(_GraphedStep):
+    """gan_train_step (bbhMahoGANy.py:1243-1299) -- latent draw, generator.predict, noise, batch assembly, discriminator step, latent draw,
+    generator step through the frozen discriminator -- as ONE replayed hipGraph."""
+
+    def __init__(self, nets, bank, event, batch, rng=_pyrandom, rank=0, world=1, predict_batch=32):
+        _GraphedStep.__init__(self, bank, batch, rng, rank, world)
+        if nets.signal_discriminator.data_parallel is not None:
+            raise NotImplementedError('GraphedGANStep under data parallelism (the collectives are not captured)')
+        self.nets, self.event, self.predict_batch = nets, event, predict_batch
+
+    def _eager(self):
+        return gan_train_step(self.nets, self.bank, self.event, self.batch, self.rng, self.rank, self.world, self.predict_batch)
+
+    def _body(self):
+        nets, b, n = self.nets, self.batch, self.bank.n_pix
+        real = ops.gather_rows(self.bank.images, self.it)
+        seed, off = device_rng().take(b * 100)
+        z = ops.fill_uniform((b, 100), -1.0, 1.0, seed, off, device())
+        fake = nets.generator.predict_device(z, batch_size=self.predict_batch)
+        seed, off = device_rng().take(b * n)
+        noise = ops.fill_normal((b, n, 1), 0.0, 1.0, seed, off, device())
+        sX, sy = assemble_discriminator_batch(real, noise, fake, self.event)
+        sd = nets.signal_discriminator.train_on_batch_device([sX], [sy.reshape(2 * b, 1)])
+        seed, off = device_rng().take(b * 100)
+        z = ops.fill_uniform((b, 100), -1.0, 1.0, seed, off, device())
+        sg = nets.signal_discriminator_on_generator.train_on_batch_device([z], [torch.ones(b, 1, device=device())])
+        return sg, sd
+
+    def _result(self, outs):
+        sg = self.nets.signal_discriminator_on_generator.train_result(outs[0], self.batch)
+        sd = self.nets.signal_discriminator.train_result(outs[1], 2 * self.batch)
+        return [sg[0], sg[1], sd[0], sd[1]]
 
 
 def posterior_samples(nets, n_samples=4000, predict_batch=32):

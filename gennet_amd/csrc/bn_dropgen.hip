@@ -9,8 +9,9 @@ namespace gn {
 
 __global__ void bn_apply_dropgen_kernel(const float4* __restrict__ x, const float4* __restrict__ scale, const float4* __restrict__ shift,
                                         uchar4* __restrict__ mask_out, float4* __restrict__ y, size_t n4, int C4, int act, float p, float rate,
-                                        float keep_scale, uint64_t seed, uint64_t offset) {
+                                        float keep_scale, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ base) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  if (base) offset += *base;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const int c = (int)(i % C4);
     const float4 v = x[i], sc = scale[c], sh = shift[c];
@@ -40,6 +41,6 @@ extern "C" int gn_bn_apply_dropgen(const float* x, const float* scale, const flo
   size_t blocks = (n4 + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(gn::bn_apply_dropgen_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (const float4*)scale,
-                     (const float4*)shift, (uchar4*)mask_out, (float4*)y, n4, C / 4, act, p, rate, 1.0f / (1.0f - rate), seed, offset);
+                     (const float4*)shift, (uchar4*)mask_out, (float4*)y, n4, C / 4, act, p, rate, 1.0f / (1.0f - rate), seed, offset, gn::rng_base());
   return gn::check_launch("bn_apply_dropgen");
 }

@@ -49,6 +49,9 @@ static hipEvent_t get_event() {
   return e;
 }
 
+static thread_local const uint64_t* g_rng_base = nullptr;
+const uint64_t* rng_base() { return g_rng_base; }
+
 void prof_begin(hipStream_t s) {
   if (!g_prof_on) return;
   g_cur = get_event();
@@ -589,6 +592,28 @@ int gn_mse_loss(const float* p, const float* y, float* dp, float* out, int B, in
 int gn_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, void* stream) {
   GN_REQUIRE(p && g && m && v, "adam_step: null pointer");
   return adam_step(p, g, m, v, n, lr_t, b1, b2, eps, (hipStream_t)stream);
+}
+
+// ---- step-varying scalars from DEVICE memory: what a captured hipGraph of a train step needs (a by-value argument is frozen at capture) ----
+int gn_set_rng_base(const uint64_t* base_dev) {
+  g_rng_base = base_dev;
+  return GN_OK;
+}
+int gn_adam_step_dyn(float* p, const float* g, float* m, float* v, size_t n, const float* lr_t_dev, float b1, float b2, float eps, void* stream) {
+  GN_REQUIRE(p && g && m && v && lr_t_dev, "adam_step_dyn: null pointer");
+  return adam_step(p, g, m, v, n, 0.f, b1, b2, eps, (hipStream_t)stream, lr_t_dev);
+}
+int gn_fill_normal_dyn(float* out, size_t n, float mean, const float* sd_dev, uint64_t seed, uint64_t offset, void* stream) {
+  GN_REQUIRE(out && sd_dev, "fill_normal_dyn: null pointer");
+  return fill_normal(out, n, mean, 0.f, seed, offset, (hipStream_t)stream, sd_dev);
+}
+int gn_bn_finalize_zero_debias_dyn(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum, float* moving_mean,
+                                   float* moving_var, float* biased_mean, float* biased_var, const int32_t* local_step_dev, float* scale, float* shift,
+                                   float* save_mean, float* save_invstd, int C, void* stream) {
+  GN_REQUIRE(sums && gamma && beta && scale && shift && save_mean && save_invstd && C > 0 && count > 1.0, "bn_finalize_zero_debias_dyn: bad arguments");
+  GN_REQUIRE(moving_mean && moving_var && biased_mean && biased_var && local_step_dev, "bn_finalize_zero_debias_dyn: needs moving statistics, accumulators, step");
+  return bn_finalize(sums, count, gamma, beta, eps, momentum, moving_mean, moving_var, biased_mean, biased_var, 1.f, scale, shift, save_mean, save_invstd, C,
+                     (hipStream_t)stream, local_step_dev);
 }
 
 }  // extern "C"

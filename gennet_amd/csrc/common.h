@@ -11,6 +11,9 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
 // Event-based timing of the MFMA kernels (bench.py roofline leg).  No-ops unless gn_prof_enable(1).
+// Step-varying scalars of a captured hipGraph live in device memory (a by-value kernel argument would be frozen into the graph):
+// rng_base() = the device word every Philox kernel adds to its counter offset (NULL outside graph capture; gn_set_rng_base).
+const uint64_t* rng_base();
 void prof_begin(hipStream_t s);
 void prof_end(hipStream_t s, double flop, int kind, double bytes = 0.0);  // kind 0: conv_mfma (fwd, dgrad), 1: wgrad_mfma, 2: bf16x3 conv, 3: fused synthesiser, 4: fused noise chain
 
@@ -142,20 +145,21 @@ int assemble_d_batch(const float* real, const float* noise, const float* fake, c
 int gather_rows(const float* src, const int64_t* idx, float* out, int rows, int width, hipStream_t s);
 int axpy(float* y, const float* x, float a, size_t n, hipStream_t s);
 int fill_uniform(float* out, size_t n, float lo, float hi, uint64_t seed, uint64_t offset, hipStream_t s);
-int fill_normal(float* out, size_t n, float mean, float sd, uint64_t seed, uint64_t offset, hipStream_t s);
+int fill_normal(float* out, size_t n, float mean, float sd, uint64_t seed, uint64_t offset, hipStream_t s, const float* sd_dev = nullptr);
 size_t colred_workspace_bytes(size_t rows, int C);
 int colred_run(int mode, ColRedArgs a, void* ws, size_t ws_bytes, double* out_f64, float* out_f32, hipStream_t s);
 int colred_finalize(const double* part, double* out_f64, size_t n, int chunks, hipStream_t s);   // out[i] = sum_k part[k*n + i], fixed order
 int colred_finalize_f32(const double* part, float* out_f32, size_t n, int chunks, hipStream_t s);
 int bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum, float* mm, float* mv,
-                float* bm, float* bv, float zd_step, float* scale, float* shift, float* smean, float* sinv, int C, hipStream_t s);
+                float* bm, float* bv, float zd_step, float* scale, float* shift, float* smean, float* sinv, int C, hipStream_t s,
+                const int32_t* zd_step_dev = nullptr);
 int bn_infer_coeffs(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, float* scale, float* shift, int C, hipStream_t s);
 int bn_apply(const float* x, const float* scale, const float* shift, const uint8_t* mask, float* y, size_t rows, int C, int act, float p, float rate, hipStream_t s);
 int bn_bwd_apply(const float* dy, const float* y, const float* x, const uint8_t* mask, const float* gamma, const float* mean, const float* invstd,
                  const double* dsums_global, double count, const double* dsums_local, float* dx, float* dgamma, float* dbeta, size_t rows, int C,
                  int act, float p, float rate, const float* scale, const float* shift, hipStream_t s, const LazyDy* lz = nullptr);
 int loss_run(int kind, const float* p, const float* y, float* dp, float* out, int B, int Bglobal, hipStream_t s);
-int adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s);
+int adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s, const float* lr_t_dev = nullptr);
 int transpose_w(const float* w, float* wt, int k, int Cin, int Cout, hipStream_t s);
 int conv2d_w2_fold(const float* w, const float* bias, float* wf, float* bf, int kh, int Cin, int Cout, hipStream_t s);
 int conv2d_w2_unfold(const float* dwf, const float* dbf, float* dw, float* db, int kh, int Cin, int Cout, hipStream_t s);

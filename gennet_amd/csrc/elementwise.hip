@@ -78,9 +78,10 @@ int act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float
 // ---------------------------------------------------------------------------------------------
 // dropout: one Philox call yields 4 uniforms -> 4 consecutive mask bytes
 // ---------------------------------------------------------------------------------------------
-__global__ void dropout_mask_kernel(uint8_t* __restrict__ mask, size_t n, float rate, uint64_t seed, uint64_t offset) {
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ mask, size_t n, float rate, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ base) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t n4 = (n + 3) >> 2;
+  if (base) offset += *base;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const Philox4 r = philox4x32_10(offset + i, seed);
 #pragma unroll
@@ -98,7 +99,7 @@ __global__ void dropout_apply_kernel(const float* __restrict__ x, const uint8_t*
 
 int dropout_mask(uint8_t* mask, size_t n, float rate, uint64_t seed, uint64_t offset, hipStream_t s) {
   if (n == 0) return GN_OK;
-  hipLaunchKernelGGL(dropout_mask_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, mask, n, rate, seed, offset);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, mask, n, rate, seed, offset, rng_base());
   return check_launch("dropout_mask");
 }
 int dropout_apply(const float* x, const uint8_t* mask, float* y, size_t n, float rate, hipStream_t s) {
@@ -242,9 +243,10 @@ int axpy(float* y, const float* x, float a, size_t n, hipStream_t s) {
   return check_launch("axpy");
 }
 
-__global__ void fill_uniform_kernel(float* __restrict__ out, size_t n, float lo, float hi, uint64_t seed, uint64_t offset) {
+__global__ void fill_uniform_kernel(float* __restrict__ out, size_t n, float lo, float hi, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ base) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t n4 = (n + 3) >> 2;
+  if (base) offset += *base;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const Philox4 r = philox4x32_10(offset + i, seed);
 #pragma unroll
@@ -255,9 +257,12 @@ __global__ void fill_uniform_kernel(float* __restrict__ out, size_t n, float lo,
   }
 }
 // Box-Muller on two 24-bit uniforms per pair; u1 in (0,1] so log is finite
-__global__ void fill_normal_kernel(float* __restrict__ out, size_t n, float mean, float sd, uint64_t seed, uint64_t offset) {
+__global__ void fill_normal_kernel(float* __restrict__ out, size_t n, float mean, float sd, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ base,
+                                   const float* __restrict__ sd_dev) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t n4 = (n + 3) >> 2;
+  if (base) offset += *base;
+  if (sd_dev) sd = *sd_dev;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const Philox4 r = philox4x32_10(offset + i, seed);
     float z[4];
@@ -280,12 +285,12 @@ __global__ void fill_normal_kernel(float* __restrict__ out, size_t n, float mean
 }
 int fill_uniform(float* out, size_t n, float lo, float hi, uint64_t seed, uint64_t offset, hipStream_t s) {
   if (!n) return GN_OK;
-  hipLaunchKernelGGL(fill_uniform_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, out, n, lo, hi, seed, offset);
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, out, n, lo, hi, seed, offset, rng_base());
   return check_launch("fill_uniform");
 }
-int fill_normal(float* out, size_t n, float mean, float sd, uint64_t seed, uint64_t offset, hipStream_t s) {
+int fill_normal(float* out, size_t n, float mean, float sd, uint64_t seed, uint64_t offset, hipStream_t s, const float* sd_dev) {
   if (!n) return GN_OK;
-  hipLaunchKernelGGL(fill_normal_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, out, n, mean, sd, seed, offset);
+  hipLaunchKernelGGL(fill_normal_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, out, n, mean, sd, seed, offset, rng_base(), sd_dev);
   return check_launch("fill_normal");
 }
 
@@ -567,9 +572,10 @@ int colred_finalize_f32(const double* part, float* out_f32, size_t n, int chunks
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* __restrict__ mm, float* __restrict__ mv, float* __restrict__ bm,
                                    float* __restrict__ bv, float zd_step, float* __restrict__ scale,
-                                   float* __restrict__ shift, float* __restrict__ smean, float* __restrict__ sinv, int C) {
+                                   float* __restrict__ shift, float* __restrict__ smean, float* __restrict__ sinv, int C, const int32_t* __restrict__ zd_step_dev) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (zd_step_dev) zd_step = (float)*zd_step_dev;
   const double mean = sums[c] / count;
   double var = sums[C + c] / count - mean * mean;
   if (var < 0) var = 0;
@@ -599,9 +605,9 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   }
 }
 int bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum, float* mm, float* mv,
-                float* bm, float* bv, float zd_step, float* scale, float* shift, float* smean, float* sinv, int C, hipStream_t s) {
+                float* bm, float* bv, float zd_step, float* scale, float* shift, float* smean, float* sinv, int C, hipStream_t s, const int32_t* zd_step_dev) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, sums, count, gamma, beta, eps, momentum, mm, mv, bm, bv, zd_step, scale, shift,
-                     smean, sinv, C);
+                     smean, sinv, C, zd_step_dev);
   return check_launch("bn_finalize");
 }
 
@@ -813,8 +819,9 @@ int loss_run(int kind, const float* p, const float* y, float* dp, float* out, in
 // Adam (keras form), one fused pass over the flat parameter segment
 // ---------------------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr_t, float b1,
-                            float b2, float eps) {
+                            float b2, float eps, const float* __restrict__ lr_t_dev) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  if (lr_t_dev) lr_t = *lr_t_dev;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float gi = g[i];
     const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -823,9 +830,9 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     p[i] -= lr_t * mi / (sqrtf(vi) + eps);
   }
 }
-int adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s) {
+int adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s, const float* lr_t_dev) {
   if (!n) return GN_OK;
-  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps);
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps, lr_t_dev);
   return check_launch("adam");
 }
 

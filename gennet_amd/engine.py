@@ -173,6 +173,97 @@ class PhiloxStream(object):
 _RNG = PhiloxStream(0)
 
 
+# --------------------------------------------------------------------------------------------------------------
+# hipGraph capture of a whole train step
+# --------------------------------------------------------------------------------------------------------------
+_CAPTURE = None
+
+
+def capturing():
+    """The StepGraph being captured, or None."""
+    return _CAPTURE
+
+
+class StepGraph(object):
+    """One train step captured as a hipGraph on the launch stream and replayed (the loops of bbhMahoGANy.py at the script's own batch
+    size 8 are launch-bound: ~250 launches of a few microseconds each per iteration).  The library never allocates or synchronises, torch's
+    allocator serves the step's temporaries from the graph's private pool, so the captured launches are exactly the eager ones.  What changes
+    from step to step cannot be a by-value kernel argument (it would be frozen): it lives in ONE small parameter block in device memory
+    that the host refreshes (pinned copy, stream-ordered) before every replay --
+      * the Philox stream position: every draw inside the graph adds the block's rng base (gn_set_rng_base) = stream position at replay
+        - stream position at capture, so a replay draws exactly what the eager step would have drawn at that point of the stream;
+      * Adam's lr_t, BatchNormalization's local_step, the CNN loop's noise sigma: slot(fmt, provider) -- the provider runs once per replay,
+        advances the host-side state (iteration counters) and returns the value.
+    Batch indices and other per-step inputs are static device tensors the caller overwrites before replay()."""
+    SLOTS = 64
+
+    def __init__(self):
+        import struct
+        self._struct = struct
+        self.host = torch.zeros(self.SLOTS * 8, dtype=torch.uint8).pin_memory()
+        self.hostbuf = self.host.numpy()
+        self.dev = torch.zeros(self.SLOTS * 8, dtype=torch.uint8, device=device())
+        self.providers = []
+        self.graph = None
+        self.rng_start = 0
+        self.rng_taken = 0
+        self.copied = torch.cuda.Event()
+        self._copied_once = False
+        self.outputs = None
+
+    def slot(self, fmt, provider):
+        """Reserve one 8-byte slot holding a scalar of struct format `fmt` ('f', 'i', 'Q'); provider() -> value is called before every replay."""
+        i = len(self.providers)
+        if i >= self.SLOTS:
+            raise RuntimeError('StepGraph: more than %d step-varying scalars' % self.SLOTS)
+        self.providers.append((i, fmt, provider))
+        return ops.DevScalar(self.dev.data_ptr() + 8 * i)
+
+    def capture(self, fn):
+        """Record fn() (kernel launches on the capture stream; nothing executes now).  Host-side counters that fn advances per step are
+        advanced by the providers at replay time instead; the Philox stream is rewound to where it stood."""
+        global _CAPTURE
+        if _CAPTURE is not None:
+            raise RuntimeError('StepGraph.capture: already capturing')
+        rng = device_rng()
+        self.rng_start = rng.offset
+
+        def rng_base():
+            base = device_rng().offset - self.rng_start
+            device_rng().offset += self.rng_taken
+            return base
+        base = self.slot('Q', rng_base)
+        self.graph = torch.cuda.CUDAGraph()
+        _CAPTURE = self
+        ops.set_rng_base(base.ptr)
+        try:
+            with torch.cuda.graph(self.graph):
+                self.outputs = fn()
+        finally:
+            ops.set_rng_base(None)
+            _CAPTURE = None
+        self.rng_taken = rng.offset - self.rng_start
+        rng.offset = self.rng_start
+        return self.outputs
+
+    def wait_inputs_consumed(self):
+        """Block until the previous replay's host -> device copies are done, so pinned staging buffers (this block, the caller's batch
+        indices) may be overwritten.  The host stays at most one step ahead of the device."""
+        if self._copied_once:
+            self.copied.synchronize()
+
+    def replay(self):
+        """Refresh the parameter block, then launch the graph on the current stream.  The caller has already waited
+        (wait_inputs_consumed) before touching its own staging buffers and enqueued their copies on the current stream."""
+        for i, fmt, provider in self.providers:
+            self._struct.pack_into('<' + fmt, self.hostbuf, 8 * i, provider())
+        self.dev.copy_(self.host, non_blocking=True)
+        self.copied.record()
+        self._copied_once = True
+        self.graph.replay()
+        return self.outputs
+
+
 def set_device_seed(seed):
     global _RNG
     _RNG = PhiloxStream(seed)
@@ -377,10 +468,15 @@ class Adam(object):
             n = b - a
             self.state.append((grp, a, b, torch.zeros(n, dtype=torch.float32, device=device()), torch.zeros(n, dtype=torch.float32, device=device())))
 
-    def step(self):
+    def _next_lr_t(self):
         self.iterations += 1
         t = self.iterations
-        lr_t = self.lr * np.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        return self.lr * np.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+
+    def step(self):
+        cap = capturing()
+        # inside a captured step graph the iteration count advances once per REPLAY and lr_t reaches the kernel through device memory
+        lr_t = self._next_lr_t() if cap is None else cap.slot('f', self._next_lr_t)
         for grp, a, b, m, v in self.state:
             ops.adam_step(grp.data[a:b], grp.grad[a:b], m, v, lr_t, self.beta_1, self.beta_2, self.epsilon)
 
@@ -755,12 +851,20 @@ class Model(Layer):
         """One optimizer step.  Returns [loss, (per-output losses,) (accuracies)] as python floats, keras order.
         `dropout_masks` ({dropout layer name: uint8 keep mask}) is a testing hook that replaces the Philox draws; `capture` (a dict) is
         another: it receives {layer name: output tensor} of every executed layer (outputs include the fused activation / dropout)."""
-        if self.optimizer is None:
-            raise RuntimeError('compile() the model before train_on_batch')
-        self._ensure_bound()
         xs = self._prep_inputs(x)
         B = xs[0].shape[0]
         ys = self._prep_targets(y, B)
+        stats = self.train_on_batch_device(xs, ys, dropout_masks, capture)
+        return self.train_result(stats, B)
+
+    def train_on_batch_device(self, xs, ys, dropout_masks=None, capture=None):
+        """train_on_batch on device tensors (inputs as the graph takes them, targets (B, 1)) without the final device -> host read: returns
+        the (n_outputs, 2) device tensor [summed loss term, metric hits] that train_result turns into keras' list.  No host synchronisation
+        anywhere in it, so the whole step can be captured into a hipGraph (engine.StepGraph)."""
+        if self.optimizer is None:
+            raise RuntimeError('compile() the model before train_on_batch')
+        self._ensure_bound()
+        B = xs[0].shape[0]
         dp = self.data_parallel
         world = dp.world_size if dp is not None else 1
         masks = {k: to_device(v, torch.uint8) for k, v in (dropout_masks or {}).items()}
@@ -782,6 +886,11 @@ class Model(Layer):
                 dp.all_reduce_sum(grp.grad[a:b])
             dp.all_reduce_sum(stats)
         self.optimizer.step()
+        return stats
+
+    def train_result(self, stats, B):
+        """[loss, (per-output losses,) (accuracies)] as python floats, keras order, from train_on_batch_device's statistics (one device -> host read)."""
+        world = self.data_parallel.world_size if self.data_parallel is not None else 1
         st = stats.cpu().numpy().astype(np.float64)
         losses = [float(v) * sc for v, sc in zip(st[:, 0], self._loss_scales)]
         res = [float(sum(losses))]

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .engine import Layer, Model, device, device_rng, glorot_uniform
+from .engine import Layer, Model, capturing, device, device_rng, glorot_uniform
 
 import os as _os
 _NO_DROPGEN = bool(_os.environ.get('GN_NO_DROPGEN'))      # A/B switch: separate dropout-mask kernel instead of drawing it inside bn_apply
@@ -334,8 +334,16 @@ class BatchNormalization(Layer):
         zd = None
         if self.moving_average == 'tf_zero_debias':
             st = self.zero_debias_state(ctx.site)
-            st[2] += 1
-            zd = (st[0], st[1], st[2])
+            cap = capturing()
+            if cap is None:
+                st[2] += 1
+                zd = (st[0], st[1], st[2])
+            else:                          # captured step graph: local_step advances once per REPLAY and reaches the kernel through device memory
+
+                def next_step(st=st):
+                    st[2] += 1
+                    return st[2]
+                zd = (st[0], st[1], cap.slot('i', next_step))
         scale, shift, smean, sinv = ops.bn_finalize(sums, count, self.gamma.data, self.beta.data, self.epsilon, self.momentum,
                                                     self.moving_mean.data, self.moving_variance.data, zd)
         mask, rate = None, 0.0

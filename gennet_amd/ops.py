@@ -377,7 +377,10 @@ def fill_uniform(shape, lo, hi, seed, offset, device):
 
 def fill_normal(shape, mean, std, seed, offset, device):
     t = torch.empty(shape, dtype=torch.float32, device=device)
-    _lib.call('gn_fill_normal', _p(t), t.numel(), float(mean), float(std), int(seed), int(offset), _stream())
+    if isinstance(std, DevScalar):
+        _lib.call('gn_fill_normal_dyn', _p(t), t.numel(), float(mean), std.ptr, int(seed), int(offset), _stream())
+    else:
+        _lib.call('gn_fill_normal', _p(t), t.numel(), float(mean), float(std), int(seed), int(offset), _stream())
     return t
 
 
@@ -415,8 +418,12 @@ def bn_finalize(sums, count, gamma, beta, eps, momentum, moving_mean, moving_var
     scale, shift, smean, sinv = (torch.empty((Cc,), dtype=torch.float32, device=dev) for _ in range(4))
     if zero_debias is not None:
         bm, bv, step = zero_debias
-        _lib.call('gn_bn_finalize_zero_debias', _p(sums), float(count), _p(gamma), _p(beta), float(eps), float(momentum), _p(moving_mean), _p(moving_var),
-                  _p(bm), _p(bv), int(step), _p(scale), _p(shift), _p(smean), _p(sinv), Cc, _stream())
+        if isinstance(step, DevScalar):
+            _lib.call('gn_bn_finalize_zero_debias_dyn', _p(sums), float(count), _p(gamma), _p(beta), float(eps), float(momentum), _p(moving_mean), _p(moving_var),
+                      _p(bm), _p(bv), step.ptr, _p(scale), _p(shift), _p(smean), _p(sinv), Cc, _stream())
+        else:
+            _lib.call('gn_bn_finalize_zero_debias', _p(sums), float(count), _p(gamma), _p(beta), float(eps), float(momentum), _p(moving_mean), _p(moving_var),
+                      _p(bm), _p(bv), int(step), _p(scale), _p(shift), _p(smean), _p(sinv), Cc, _stream())
     else:
         _lib.call('gn_bn_finalize', _p(sums), float(count), _p(gamma), _p(beta), float(eps), float(momentum), _p(moving_mean), _p(moving_var),
                   _p(scale), _p(shift), _p(smean), _p(sinv), Cc, _stream())
@@ -515,8 +522,23 @@ def loss(kind, p, y, Bglobal=None):
 
 
 def adam_step(p, g, m, v, lr_t, b1, b2, eps):
+    """lr_t: a python float, or (inside a captured step graph) the integer device address of a float the host refreshes before every replay."""
     _chk(p, g, m, v)
-    _lib.call('gn_adam_step', _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), float(b1), float(b2), float(eps), _stream())
+    if isinstance(lr_t, DevScalar):
+        _lib.call('gn_adam_step_dyn', _p(p), _p(g), _p(m), _p(v), p.numel(), lr_t.ptr, float(b1), float(b2), float(eps), _stream())
+    else:
+        _lib.call('gn_adam_step', _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), float(b1), float(b2), float(eps), _stream())
+
+
+class DevScalar(object):
+    """Address of one step-varying scalar in a step graph's parameter block (engine.StepGraph.slot)."""
+
+    def __init__(self, ptr):
+        self.ptr = int(ptr)
+
+
+def set_rng_base(ptr):
+    _lib.call('gn_set_rng_base', None if ptr is None else int(ptr))
 
 
 # ---------------------------------------------------------------------------------------------- profiling hooks

@@ -241,6 +241,23 @@ int gn_mse_loss(const float* p, const float* y, float* dp, float* out, int B, in
  * m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (host). */
 int gn_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, void* stream);
 
+/* ---- hipGraph capture of a whole train step (bbhMahoGANy.py:1153-1168, :1241-1299 at the script's own batch size 8, where the loop is
+ * launch-bound): every launch of the library is stream-ordered and allocation-free, so train_on_batch can be captured on the launch stream and
+ * replayed.  Scalars that change from step to step would be frozen into the graph as by-value kernel arguments; these entry points read them
+ * from device memory instead (the host refreshes one small block before each replay).
+ * gn_set_rng_base: from now on (this host thread) every Philox kernel of the library -- gn_dropout_mask, gn_fill_uniform, gn_fill_normal(_dyn),
+ * gn_bn_apply_dropgen -- adds *base_dev to its counter offset at run time; NULL switches it off.  With base = (stream position at replay) -
+ * (stream position at capture) a replay draws exactly what the un-captured step would have drawn. */
+int gn_set_rng_base(const uint64_t* base_dev);
+/* gn_adam_step with lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) read from device memory */
+int gn_adam_step_dyn(float* p, const float* g, float* m, float* v, size_t n, const float* lr_t_dev, float b1, float b2, float eps, void* stream);
+/* gn_fill_normal with the standard deviation read from device memory (the CNN loop's per-batch sigma ~ U(0, 5), bbhMahoGANy.py:1161) */
+int gn_fill_normal_dyn(float* out, size_t n, float mean, const float* sd_dev, uint64_t seed, uint64_t offset, void* stream);
+/* gn_bn_finalize_zero_debias with the (already incremented) local_step read from device memory */
+int gn_bn_finalize_zero_debias_dyn(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
+                                   float* moving_mean, float* moving_var, float* biased_mean, float* biased_var, const int32_t* local_step_dev,
+                                   float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream);
+
 /* ---- profiling hooks used by bench.py: accumulate HIP-event time of every MFMA conv / wgrad launch ---------- */
 int gn_prof_enable(int on);
 int gn_prof_reset(void);
