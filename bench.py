@@ -31,6 +31,9 @@ WORKLOADS = {
     'default': {'n_pix': 2048, 'cnn_batch': 256, 'gan_batch': 512, 'waves': 512, 'gflop_cnn': 15.36, 'gflop_gan': 79.6, 'online': False},
     # BASELINE configs[4]: srate 4096, every batch synthesised on the GPU inside the loop (no stored bank)
     'cfg5': {'n_pix': 4096, 'cnn_batch': 256, 'gan_batch': 512, 'waves': 512, 'gflop_cnn': 30.85, 'gflop_gan': 159.1, 'online': True},
+    # NOT a BASELINE config and never the headline: the reference script's own operating point (batch_size = pe_batch_size = 8, n_pix = 1024,
+    # bbhMahoGANy.py:84-89), what a user who drops the package into BBH_version/ unchanged runs.  Both loop bodies replay as captured hipGraphs.
+    'refdefaults': {'n_pix': 1024, 'cnn_batch': 8, 'gan_batch': 8, 'waves': 8, 'gflop_cnn': 7.62, 'gflop_gan': 39.8, 'online': False, 'graph': True},
 }
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = 1/16 of the bf16 peak
 PEAK_HBM_TBS = 8.0                 # MI355X_MICROARCH.md: HBM3E spec peak
@@ -138,7 +141,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--bank', type=int, default=100000, help='synthetic template bank size (BASELINE configs[1]: 100k segments)')
     ap.add_argument('--config', choices=sorted(WORKLOADS), default='default',
-                    help="default: BASELINE configs[1]+[2] (n_pix 2048, stored bank in HBM); cfg5: configs[4] (srate 4096, templates synthesised in the loop)")
+                    help="default: BASELINE configs[1]+[2] (n_pix 2048, stored bank in HBM); cfg5: configs[4] (srate 4096, templates synthesised in the loop); "
+                         "refdefaults: the reference script's own batch 8 / n_pix 1024 (not a BASELINE config), loop bodies replayed as hipGraphs")
+    ap.add_argument('--no-graph', action='store_true', help='refdefaults: run the loop bodies eagerly instead of replaying captured hipGraphs')
     ap.add_argument('--predict-batch', type=int, default=0, help='chunk size of generator.predict for the fake half (0: the GAN batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -163,6 +168,9 @@ def main():
     wl = WORKLOADS[args.config]
     N_PIX, CNN_BATCH, GAN_BATCH, WAVES = wl['n_pix'], wl['cnn_batch'], wl['gan_batch'], wl['waves']
     predict_batch = args.predict_batch or GAN_BATCH
+    graphed = bool(wl.get('graph')) and not args.no_graph and args.gpus == 1
+    if args.config == 'refdefaults' and args.bank == 100000:
+        args.bank = 50000                        # sample_num of gw_template_maker.py:60
     dev = engine.device()
     engine.set_init_seed(1)                     # identical initial weights on every rank
     engine.set_device_seed(1000 + rank)         # per-rank dropout / latent / noise streams
@@ -199,6 +207,9 @@ def main():
 
         def gan_step():
             return bbh.gan_train_step_online(nets, online, event, GAN_BATCH, predict_batch=predict_batch)
+    elif graphed:
+        cnn_step = bbh.GraphedPEStep(nets.signal_pe, bank, CNN_BATCH)
+        gan_step = bbh.GraphedGANStep(nets, bank, event, GAN_BATCH, predict_batch=predict_batch)
     else:
         def cnn_step():
             return bbh.pe_train_step(nets.signal_pe, bank, CNN_BATCH, rank=rank, world=world)
@@ -209,6 +220,7 @@ def main():
     last = {}
 
     def step():
+        # (refdefaults replays hipGraphs: every replay returns the step's losses through one device -> host read, as the eager loop does)
         # the return values of the three train_on_batch calls the loop prints (bbhMahoGANy.py:1165, :1292, :1296) are kept and checked after
         # the timed region: a launch that wrote garbage at these batch sizes must not score
         for _ in range(WAVES // CNN_BATCH):
@@ -286,11 +298,13 @@ def main():
             'last_losses': last_losses,
             'config': {'workload': ('BASELINE %s; per GPU and step: 2 x CNN point-estimator train_on_batch(batch=%d) + 1 GAN iteration(batch=%d) '
                                     '(G.predict, D step on 2B, G step through frozen D); n_pix=%d; %s')
-                                   % ('configs[4] (cfg5)' if wl['online'] else 'configs[1]+[2]', CNN_BATCH, GAN_BATCH, N_PIX,
+                                   % ('configs[4] (cfg5)' if wl['online'] else ('-- NOT a BASELINE config: the reference script\'s own defaults (bbhMahoGANy.py:84-89), loop bodies %s'
+                                                                                 % ('replayed as captured hipGraphs' if graphed else 'run eagerly')
+                                                                                 if args.config == 'refdefaults' else 'configs[1]+[2]'), CNN_BATCH, GAN_BATCH, N_PIX,
                                       'every batch synthesised on the GPU inside the step: CNN rows = template + PSD-coloured noise whitened with the same PSD, one launch (prior -> chirp -> irFFT -> align -> crop -> gen_noise -> whiten_data(td) -> add); GAN real images = [noise-free template | coloured whitened noise], two launches' if wl['online']
                                       else '%d whitened BBH templates synthesised on the GPU into an HBM-resident bank before the timed region' % bank_n),
                        'name': args.config, 'n_pix': N_PIX, 'cnn_batch': CNN_BATCH, 'gan_batch': GAN_BATCH, 'predict_batch': predict_batch,
-                       'waveforms_per_step_per_gpu': WAVES, 'bank_rows': bank_n, 'parallelism': 'dp%d' % world},
+                       'waveforms_per_step_per_gpu': WAVES, 'bank_rows': bank_n, 'parallelism': 'dp%d' % world, 'hipgraph_replay': graphed},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_pipe_kernel (+ conv_mfma_dma_kernel / conv_mfma_kernel for ragged or 1-tap shapes): implicit-GEMM Conv1D forward + data gradient, v_mfma_f32_32x32x2_f32',
                          'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                          'traffic_note': 'fabric-side bytes per conv_mfma launch (2*FETCH_SIZE + WRITE_SIZE KiB, gfx950 FETCH correction) from the separate PMC '

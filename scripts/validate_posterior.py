@@ -86,6 +86,9 @@ def main():
     ap.add_argument('--gan-iter', type=int, default=125000, help='500 000 x 8 waveforms of the reference = 125 000 iterations of 32')
     ap.add_argument('--gan-seconds', type=float, default=600.0)
     ap.add_argument('--cadence', type=int, default=5000)
+    ap.add_argument('--fine-until', type=int, default=0, help='score every --fine-cadence iterations up to this iteration (the early trajectory)')
+    ap.add_argument('--fine-cadence', type=int, default=500)
+    ap.add_argument('--predict-batch', type=int, default=32, help='chunk of generator.predict inside the GAN iteration')
     ap.add_argument('--lr', type=float, default=9e-5)
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--graph', action='store_true', help='run the train steps as captured hipGraphs (engine.GraphedStep)')
@@ -143,14 +146,14 @@ def main():
     pe_step = gan_step = None
     if args.graph:
         pe_step = bbh.GraphedPEStep(nets.signal_pe, bank, args.pe_batch)
-        gan_step = bbh.GraphedGANStep(nets, bank, ev_dev, args.gan_batch)
+        gan_step = bbh.GraphedGANStep(nets, bank, ev_dev, args.gan_batch, predict_batch=args.predict_batch)
 
     # ---- CNN point-estimator: the reference's loop body (bbhMahoGANy.py:1153-1168)
     t0 = time.time()
     hist = []
     i = 0
     while i < args.pe_iter and time.time() - t0 < args.cnn_seconds:
-        r = pe_step() if pe_step else bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch)
+        r = pe_step(want_losses=(i % 1000 == 0)) if pe_step else bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch)
         if i % 1000 == 0:
             hist.append([i] + [float(v) for v in r[:3]])
             print('cnn %6d: total %.4f mc %.4f q %.5f  (%.0f s)' % (i, r[0], r[1], r[2], time.time() - t0), flush=True)
@@ -178,13 +181,15 @@ def main():
             rec.update(beta=float(beta), ks_stat=[float(ks[0][0]), float(ks[1][0])], ks_p=[float(ks[0][1]), float(ks[1][1])])
         w = waves.reshape(4000, fs)
         rec['waveform_overlap_with_clean_event'] = float(np.mean((w @ (ev_raw.cpu().numpy()[0] * g)) / (np.linalg.norm(w, axis=1) * snr + 1e-30)))
+        rec['waveform_rms'] = float(np.sqrt(np.mean(w ** 2)))
         return rec
     t0 = time.time()
     traj = []
     it = 0
     while it < args.gan_iter and time.time() - t0 < args.gan_seconds:
-        r = gan_step() if gan_step else bbh.gan_train_step(nets, bank, ev_dev, args.gan_batch)
-        if it % args.cadence == 0:
+        at_cadence = it % args.cadence == 0 or (it < args.fine_until and it % args.fine_cadence == 0)
+        r = gan_step(want_losses=at_cadence) if gan_step else bbh.gan_train_step(nets, bank, ev_dev, args.gan_batch, predict_batch=args.predict_batch)
+        if at_cadence:
             rec = score(it)
             rec.update(sg_loss=float(r[0]), sg_acc=float(r[1]), sd_loss=float(r[2]), sd_acc=float(r[3]), seconds=time.time() - t0)
             traj.append(rec)
@@ -194,7 +199,9 @@ def main():
     t_gan = time.time() - t0
     final = score(it)
     out['gan'] = {'iterations': it, 'batch': args.gan_batch, 'waveforms': it * args.gan_batch, 'seconds': t_gan, 'iterations_per_s': it / t_gan,
-                  'final': final, 'best_beta': max([r.get('beta', 0.0) for r in traj + [final]]), 'trajectory': traj}
+                  'final': final, 'best_beta': max([r.get('beta', 0.0) for r in traj + [final]]),
+                  'best_beta_iteration': max(traj + [final], key=lambda r: r.get('beta', 0.0))['iteration'],
+                  'best_waveform_overlap': max([r['waveform_overlap_with_clean_event'] for r in traj + [final]]), 'trajectory': traj}
     out['total_seconds'] = time.time() - t_start
     # tolerance statement: the CNN against the reference's yard-stick; the GAN posterior against the exact one
     ex = out['exact_posterior']
