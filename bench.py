@@ -44,7 +44,7 @@ def pmc_traffic_per_launch():
     """Fabric-side bytes per conv_mfma launch from the committed PMC passes of this same command (profiles/r0N_pmc_traffic.json,
     written by scripts/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs; counters cannot be read from
     inside the timed run).  Newest round first; (None, None) when no file is there."""
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             ks = json.load(open(path))['kernels']

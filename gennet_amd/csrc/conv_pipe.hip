@@ -394,23 +394,11 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
     a2.stat_part = nullptr;
     return conv_pipe_try(a2, tall, s, launched);
   }
-  // Tile: the caller's choice (tall 256 x 64 or square 128 x 128) when it fills the chip.  With fewer than two blocks per CU -- the script's own
-  // operating point, batch 8 at n_pix 1024 (bbhMahoGANy.py:84-89): M = 251 rows per batch element is ONE tall tile, 128 blocks for 256 CUs --
-  // the same kernel runs with 2 waves (128 x 64) or 1 wave (64 x 64) per block: 2-4x the blocks, each a half / a quarter of the work.
-  int wm = tall ? 4 : 2, wn = tall ? 1 : 2;
-  auto blocks_of = [&](int tm, int tn) { return (size_t)a.B * (size_t)((a.M + tm - 1) / tm) * (size_t)(a.Cout / tn); };
-  static const bool no_small = getenv("GN_CONV_NOSMALL") != nullptr;            // A/B switch
-  if (!no_small && a.Cout % 64 == 0 && blocks_of(wm * 64, wn * 64) < 512) {
-    wn = 1;
-    wm = blocks_of(128, 64) >= 512 ? 2 : 1;
-  }
-#define GN_PIPE(NT_, IS_)                                              \
-  do {                                                                 \
-    if (wn == 2) return launch_conv_pipe<2, 2, NT_, IS_>(a, s);        \
-    if (wm == 4) return launch_conv_pipe<4, 1, NT_, IS_>(a, s);        \
-    if (wm == 2) return launch_conv_pipe<2, 1, NT_, IS_>(a, s);        \
-    return launch_conv_pipe<1, 1, NT_, IS_>(a, s);                     \
-  } while (0)
+  // (Smaller tiles for under-filled grids -- 128 x 64 with 2 waves, 64 x 64 with 1 wave per block, at the script's own batch 8 / n_pix 1024
+  // where e.g. the q-branch's last data gradient is 128 blocks for 256 CUs -- were measured in round 3: CNN step 2.34 -> 2.31 ms, GAN iteration
+  // 4.85 -> 5.36 ms.  The number of 64 x 64 WAVE tiles is what it is (509 for that launch, for 1024 SIMDs): cutting blocks into fewer
+  // waves fills more CUs but the same number of SIMDs.  More parallelism there needs split-K or a smaller wave tile, not a smaller block.)
+#define GN_PIPE(NT_, IS_) return tall ? launch_conv_pipe<4, 1, NT_, IS_>(a, s) : launch_conv_pipe<2, 2, NT_, IS_>(a, s)
   // (4-channel chunks for the stride-2 forward -- 27 instead of 53 KiB of LDS, a fourth block per CU, but a barrier per 40 MFMAs -- were
   // measured: 140.3 -> 135.5 TFLOP/s.  Eight channels per chunk is the optimum in both directions.)
   if (a.t.in_stride == 2) { GN_PIPE(5, 2); }

@@ -73,7 +73,7 @@ def moments(s):
             'corr': float(np.corrcoef(s[0], s[1])[0, 1]) if np.std(s[0]) > 0 and np.std(s[1]) > 0 else None}
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--n-pix', type=int, default=1024)
     ap.add_argument('--bank', type=int, default=50000)
@@ -93,8 +93,11 @@ def main():
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--graph', action='store_true', help='run the train steps as captured hipGraphs (engine.GraphedStep)')
     ap.add_argument('--out', default='gpurun_out/posterior_validation.json')
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def run(args):
+    """The whole validation for one configuration; returns the result dictionary (and writes it to args.out when that is set)."""
     import random
     import torch
     from gennet_amd import bbh, engine, ops, posterior, templates as T
@@ -211,11 +214,13 @@ def main():
         'gan_width_ratio [mc, q]': [final['mc_std'] / ex['mc_std'], final['q_std'] / ex['q_std']],
         'beta_final': final.get('beta'), 'beta_of_two_exact_sample_sets': ex['self_overlap_beta']}
     print('verdict: %s' % json.dumps(out['verdict']), flush=True)
-    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
-    with open(args.out, 'w') as fh:
-        json.dump(out, fh, indent=1)
-    print('wrote', args.out)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, 'w') as fh:
+            json.dump(out, fh, indent=1)
+        print('wrote', args.out)
+    return out
 
 
 if __name__ == '__main__':
-    main()
+    run(parse())
