@@ -68,10 +68,10 @@ def host_cores():
     return n
 
 
-def cpu_baseline(n_pix, seconds_budget=30.0):
+def cpu_baseline(n_pix, cnn_batch=256, gan_batch_max=512, seconds_budget=30.0):
     """The torch-CPU port of the same two steps (oracle/torch_ref.py) on this box's host cores.  Protocol of BASELINE.md section 2 / SURVEY 8d:
     same batch as the GPU line where the budget allows, >= 3 warm-up + >= 5 timed iterations, MEDIAN.
-      CNN leg: train_on_batch at the benchmark's batch 256 (3 + 5 steps; ~4 s each on 16 cores).
+      CNN leg: train_on_batch at the workload's own CNN batch (256 on the headline: 3 + 5 steps, ~4 s each on 16 cores).
       GAN leg: a batch-512 iteration is ~40 TFLOP (minutes on the host), so the leg runs at the largest power-of-two batch whose 3 + 5
                iterations fit `seconds_budget`, chosen from one probe iteration at batch 8; the batch is a field of the object.
     value = 1 / (t_CNN + t_GAN) per waveform, the CPU counterpart of the GPU line's B / (t_CNN + t_GAN)."""
@@ -89,7 +89,7 @@ def cpu_baseline(n_pix, seconds_budget=30.0):
             t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
         return float(np.median(ts)), ts
 
-    bc = 256
+    bc = cnn_batch
     pe = T.PENet(n_pix)
     x, ymc, yq = torch.randn(bc, n_pix, 1), torch.rand(bc) * 15 + 20, torch.rand(bc) * 0.5 + 0.5
     t_cnn_batch, cnn_ts = median_time(lambda: pe.train_on_batch(x, ymc, yq))
@@ -100,7 +100,7 @@ def cpu_baseline(n_pix, seconds_budget=30.0):
     gan.iteration(probe, 8)                                        # first call: allocations, oneDNN primitive creation
     t0 = time.perf_counter(); gan.iteration(probe, 8); per_wave = (time.perf_counter() - t0) / 8
     bg = 8
-    while bg < 512 and (WARM + TIMED) * per_wave * (2 * bg) <= seconds_budget:
+    while bg < gan_batch_max and (WARM + TIMED) * per_wave * (2 * bg) <= seconds_budget:
         bg *= 2
     real = torch.randn(bg, n_pix)
     t_gan_batch, gan_ts = median_time(lambda: gan.iteration(real, bg))
@@ -111,8 +111,8 @@ def cpu_baseline(n_pix, seconds_budget=30.0):
             'protocol': {'warmup': WARM, 'timed': TIMED, 'statistic': 'median'},
             'cnn_batch': bc, 'gan_batch': bg, 'cnn_waveforms_per_s': 1.0 / t_cnn, 'gan_waveforms_per_s': 1.0 / t_gan,
             'cnn_step_seconds': [round(t, 3) for t in cnn_ts], 'gan_iteration_seconds': [round(t, 3) for t in gan_ts],
-            'note': 'the GPU line runs CNN batch 256 and GAN batch 512; the CPU GAN leg runs at batch %d, the largest power of two whose %d iterations '
-                    'fit %.0f s on this host (baseline only)' % (bg, WARM + TIMED, seconds_budget)}
+            'note': 'the GPU line runs CNN batch %d and GAN batch %d; the CPU GAN leg runs at batch %d, the largest power of two (up to the GPU line\'s) whose %d '
+                    'iterations fit %.0f s on this host (baseline only)' % (cnn_batch, gan_batch_max, bg, WARM + TIMED, seconds_budget)}
 
 
 def free_port():
@@ -351,8 +351,15 @@ def main():
             out['config']['conv_math'] = conv_math
             out['roofline']['bf16x3_launches'] = {'launches': x3['launches'], 'avg_launch_ms': x3['ms'] / max(x3['launches'], 1),
                                                   'fp32_equivalent_tflops': x3['flop'] / (x3['ms'] * 1e-3) / 1e12 if x3['ms'] > 0 else 0.0}
+        if graphed:          # HIP events are not part of the captured graph: the per-kernel figures are not measured on this line
+            for k in ('achieved', 'frac', 'traffic', 'avg_launch_ms'):
+                out['roofline'][k] = None
+            out['roofline']['wgrad_mfma_kernel'] = None
+            out['roofline']['mfma_kernel_time_share'] = None
+            out['roofline']['note'] = ('loop bodies replayed as hipGraphs: the launch-stream HIP events of the eager path are not captured, so per-kernel '
+                                       'figures are not measured here; the same command with --no-graph measures them (eager, same losses bit for bit)')
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(N_PIX)
+            out['cpu_baseline'] = cpu_baseline(N_PIX, CNN_BATCH, GAN_BATCH)
         print(json.dumps(out), flush=True)
     if dp:
         torch.distributed.barrier()

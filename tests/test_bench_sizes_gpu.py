@@ -144,3 +144,71 @@ def test_generator_at_batch_512_predict_chunks_and_batchnorm_statistics():
         assert float(((mv - want).abs() - 1.2e-7).clamp_min(0).div(want).max()) <= 2e-5, (bn.name, n)
     del cap
     assert all(torch.equal(a_, p.data) for a_, p in zip(d_before, nets.signal_discriminator._train_params))      # D frozen in the G step
+
+
+def test_largest_conv_launches_of_the_bench_against_their_chunks():
+    """The generator's 512 -> 1024 convolution at the bench's B = 512, L = 2048: 2^30 output elements, 65 536 blocks in the XCD patch order
+    (the oracle-parity cases of test_kernels_gpu stop at 720 blocks).  Rows of a convolution do not know their batch: the forward (with the
+    BatchNormalization statistics out of its epilogue) and the data gradient at B = 512 must equal the SAME kernels run on 8 chunks of 64
+    rows -- whose grids are small, differently ordered, and covered by the oracle tests -- bit for bit; the weight gradient, a sum over
+    (b, m), equals the sum of the chunks' to 1e-5 of its largest entry; the epilogue statistics equal fp64 sums of the output."""
+    from gennet_amd import ops
+    from gennet_amd.engine import device
+    B, L, Cin, Cout, k = 512, 2048, 512, 1024, 5
+    x = ops.fill_normal((B, L, Cin), 0.0, 1.0, 31, 0, device())
+    w = ops.fill_uniform((k, Cin, Cout), -0.02, 0.02, 32, 0, device())
+    b = ops.fill_uniform((Cout,), -0.1, 0.1, 33, 0, device())
+    y, sums = ops.conv1d_fwd_stats(x, w, b, 1, 2, L)
+    assert y.shape == (B, L, Cout) and y.numel() == 1 << 30
+    for s in range(0, B, CHUNK):
+        yc = ops.conv1d_fwd(x[s:s + CHUNK], w, b, 1, 2, L)
+        assert torch.equal(y[s:s + CHUNK], yc), s
+    del yc
+    n = B * L
+    s1 = torch.zeros(Cout, dtype=torch.float64, device=device()); s2 = torch.zeros(Cout, dtype=torch.float64, device=device())
+    for s in range(0, B, CHUNK):                                  # fp64 sums of the output, chunked to bound the fp64 temporary
+        yd = y[s:s + CHUNK].double().reshape(-1, Cout)
+        s1 += yd.sum(0); s2 += (yd * yd).sum(0)
+    del yd
+    assert float(((sums[:Cout] - s1).abs() / (s2.sqrt() * np.sqrt(n))).max()) < 1e-9          # sum y against sqrt(n sum y^2): its natural scale
+    assert float(((sums[Cout:] - s2).abs() / s2).max()) < 1e-9
+    # data gradient (transposed weights): dy := y
+    wt = ops.conv1d_transpose_w(w)
+    dx = ops.conv1d_dgrad(y, wt, L, 1, 2)
+    for s in range(0, B, CHUNK):
+        assert torch.equal(dx[s:s + CHUNK], ops.conv1d_dgrad(y[s:s + CHUNK], wt, L, 1, 2)), s
+    del dx
+    # weight gradient: sum over the chunks
+    dw, db = ops.conv1d_wgrad(x, y, k, 1, 2)
+    dw_acc = torch.zeros_like(dw, dtype=torch.float64); db_acc = torch.zeros_like(db, dtype=torch.float64)
+    for s in range(0, B, CHUNK):
+        dwc, dbc = ops.conv1d_wgrad(x[s:s + CHUNK], y[s:s + CHUNK], k, 1, 2)
+        dw_acc += dwc.double(); db_acc += dbc.double()
+    assert float((dw.double() - dw_acc).abs().max() / dw_acc.abs().max()) < 1e-5
+    assert float((db.double() - db_acc).abs().max() / db_acc.abs().max()) < 1e-5
+
+
+def test_stride2_discriminator_launch_of_the_bench_against_its_chunks():
+    """The discriminator's folded second convolution at the bench's 2B = 1024 rows (512 -> 1024 channels, 5 taps, stride 2, L 1024 -> 512) with
+    LeakyReLU + injected dropout in the epilogue, and its two-phase data gradient through the producer's LeakyReLU + dropout: bit-identical to
+    64-row chunks."""
+    from gennet_amd import ops
+    from gennet_amd.engine import device
+    B, L, Cin, Cout, k = 1024, 1024, 512, 1024, 5
+    Lout, pad = 512, 1                                            # 'same' with stride 2: pad_total = 3, pad_left = 1
+    x = ops.fill_normal((B, L, Cin), 0.0, 1.0, 41, 0, device())
+    w = ops.fill_uniform((k, Cin, Cout), -0.02, 0.02, 42, 0, device())
+    b = ops.fill_uniform((Cout,), -0.1, 0.1, 43, 0, device())
+    mask = ops.dropout_mask((B, Lout, Cout), 0.4, 44, 0, device())
+    y = ops.conv1d_fwd_dropout(x, w, b, mask, 2, pad, Lout, 'leaky', 0.2, 0.4)
+    for s in range(0, B, CHUNK):
+        assert torch.equal(y[s:s + CHUNK], ops.conv1d_fwd_dropout(x[s:s + CHUNK], w, b, mask[s:s + CHUNK], 2, pad, Lout, 'leaky', 0.2, 0.4)), s
+    assert 0.55 < float((y != 0).float().mean()) < 0.65
+    # data gradient of that layer fused with the PRODUCER's LeakyReLU + dropout derivative (prev = (its output, act, param, its mask, rate))
+    wt = ops.conv1d_transpose_w(w)
+    pmask = ops.dropout_mask((B, L, Cin), 0.4, 45, 0, device())
+    xprev = torch.where(pmask.bool(), x, torch.zeros_like(x))    # a producer output consistent with its mask
+    dx = ops.conv1d_dgrad(y, wt, L, 2, pad, prev=(xprev, 'leaky', 0.2, pmask, 0.4))
+    for s in range(0, B, CHUNK):
+        dxc = ops.conv1d_dgrad(y[s:s + CHUNK], wt, L, 2, pad, prev=(xprev[s:s + CHUNK], 'leaky', 0.2, pmask[s:s + CHUNK], 0.4))
+        assert torch.equal(dx[s:s + CHUNK], dxc), s
