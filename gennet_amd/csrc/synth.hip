@@ -13,6 +13,7 @@ namespace gn {
 struct ChirpCoeffs {
   double piM, f_merg, f_ring, sigma, f_cut, amp0, t0, wnorm;
   double psi[6];
+  double iv_merg;          // 1 / cbrt(piM f_merg): cbrt(f / f_merg) = cbrt(piM f) * iv_merg
 };
 
 __constant__ double kF[4][3] = {{2.9740e-1, 4.4810e-2, 9.5560e-2}, {5.9411e-1, 8.9794e-2, 1.9111e-1}, {5.0801e-1, 7.7515e-2, 2.2369e-2}, {8.4845e-1, 1.2848e-1, 2.7299e-1}};
@@ -39,6 +40,7 @@ __device__ ChirpCoeffs chirp_coeffs(double m1, double m2, double dist_mpc) {
   for (int i = 0; i < 6; ++i) dsum += c.psi[i] * ((kOrd[i] - 5) / 3.0) * pow(v, (double)(kOrd[i] - 5)) / c.f_ring;
   c.t0 = -dsum / (2.0 * kPi);
   c.wnorm = (kPi * c.sigma / 2.0) * pow(c.f_ring / c.f_merg, -2.0 / 3.0);
+  c.iv_merg = 1.0 / cbrt(c.piM * c.f_merg);
   return c;
 }
 
@@ -60,8 +62,10 @@ __global__ __launch_bounds__(256) void chirp_fd_kernel(const double* __restrict_
     for (int i = 0; i < 6; ++i) phase = phase + c.psi[i] * pw[i];
     const double r = f / c.f_merg;
     double shape;
-    if (f < c.f_merg) shape = pow(r, -7.0 / 6.0);
-    else if (f < c.f_ring) shape = pow(r, -2.0 / 3.0);
+    // r^(-7/6) and r^(-2/3) through cr = cbrt(r) = v * iv_merg (v is there for the phase): no pow per bin
+    const double cr = v * c.iv_merg;
+    if (f < c.f_merg) shape = 1.0 / (r * sqrt(cr));
+    else if (f < c.f_ring) shape = 1.0 / (cr * cr);
     else shape = c.wnorm * ((1.0 / (2.0 * kPi)) * c.sigma / ((f - c.f_ring) * (f - c.f_ring) + 0.25 * c.sigma * c.sigma));
     const double amp = c.amp0 * shape;
     double sn, cs;

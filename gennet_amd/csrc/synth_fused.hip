@@ -25,6 +25,7 @@ struct ChirpCoeffsF {
   double piM, f_merg, f_ring, sigma, f_cut, amp0, t0, wnorm;
   double psi[6];
   double nyq_re, nyq_im;
+  double iv_merg;         // 1 / cbrt(piM f_merg)
   double m1, m2;          // the template's masses (given, or drawn from the prior by the block itself)
   int idx, pad_;
 };
@@ -79,6 +80,7 @@ __device__ void chirp_coeffs_f(double m1, double m2, double dist_mpc, ChirpCoeff
   for (int i = 0; i < 6; ++i) dsum += c->psi[i] * ((kOrdf[i] - 5) / 3.0) * pow(v, (double)(kOrdf[i] - 5)) / c->f_ring;
   c->t0 = -dsum / (2.0 * kPiF);
   c->wnorm = (kPiF * c->sigma / 2.0) * pow(c->f_ring / c->f_merg, -2.0 / 3.0);
+  c->iv_merg = 1.0 / cbrt(c->piM * c->f_merg);
 }
 
 // S[k] = h~(k df) * scale[k]  (complex; zero outside [f_low, f_cut) and at k = 0)
@@ -94,8 +96,10 @@ __device__ __forceinline__ double2 chirp_bin(const ChirpCoeffsF& c, int k, doubl
   for (int i = 0; i < 6; ++i) phase = phase + c.psi[i] * pw[i];
   const double r = f / c.f_merg;
   double shape;
-  if (f < c.f_merg) shape = pow(r, -7.0 / 6.0);
-  else if (f < c.f_ring) shape = pow(r, -2.0 / 3.0);
+  // r^(-7/6) and r^(-2/3) through cr = cbrt(r) = v * iv_merg (v is there for the phase): no pow per bin (same expressions as chirp_fd_kernel)
+  const double cr = v * c.iv_merg;
+  if (f < c.f_merg) shape = 1.0 / (r * sqrt(cr));
+  else if (f < c.f_ring) shape = 1.0 / (cr * cr);
   else shape = c.wnorm * ((1.0 / (2.0 * kPiF)) * c.sigma / ((f - c.f_ring) * (f - c.f_ring) + 0.25 * c.sigma * c.sigma));
   const double amp = c.amp0 * shape;
   double sn, cs;
