@@ -63,6 +63,42 @@ __device__ __forceinline__ void pipe_first(float& na0, float& na1, float& nb0, f
       : "memory");
 }
 
+// Narrow wave tile (64 rows x 32 columns per wave: two accumulator tiles, three operand reads per two MFMAs).  Twice the waves for the same
+// block tile -- for launches whose 64 x 64 wave tiles do not fill the chip's 1024 SIMDs (the script's own batch 8, bbhMahoGANy.py:84-89).
+template <int OA0, int OA1, int OB0>
+__device__ __forceinline__ void pipe_group_n(f32x16& c00, f32x16& c10, float a0, float a1, float b0, float& na0, float& na1, float& nb0, unsigned addr_a,
+                                             unsigned addr_b) {
+  asm volatile(
+      "ds_read_b32 %2, %8 offset:%10\n\t"
+      "ds_read_b32 %3, %8 offset:%11\n\t"
+      "ds_read_b32 %4, %9 offset:%12\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %5, %7, %0\n\t"
+      "v_mfma_f32_32x32x2_f32 %1, %6, %7, %1"
+      : "+v"(c00), "+v"(c10), "=&v"(na0), "=&v"(na1), "=&v"(nb0)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(addr_a), "v"(addr_b), "i"(OA0), "i"(OA1), "i"(OB0)
+      : "memory");
+}
+__device__ __forceinline__ void pipe_last_n(f32x16& c00, f32x16& c10, float a0, float a1, float b0) {
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %2, %4, %0\n\t"
+      "v_mfma_f32_32x32x2_f32 %1, %3, %4, %1"
+      : "+v"(c00), "+v"(c10)
+      : "v"(a0), "v"(a1), "v"(b0)
+      : "memory");
+}
+template <int OA0, int OA1, int OB0>
+__device__ __forceinline__ void pipe_first_n(float& na0, float& na1, float& nb0, unsigned addr_a, unsigned addr_b) {
+  asm volatile(
+      "ds_read_b32 %0, %3 offset:%5\n\t"
+      "ds_read_b32 %1, %3 offset:%6\n\t"
+      "ds_read_b32 %2, %4 offset:%7"
+      : "=&v"(na0), "=&v"(na1), "=&v"(nb0)
+      : "v"(addr_a), "v"(addr_b), "i"(OA0), "i"(OA1), "i"(OB0)
+      : "memory");
+}
+
 template <int TN, int KC, int NTAPS, int STAGE_BYTES, int STAGE>
 struct PipeChunk {
   static constexpr int SLOTS = NTAPS * (KC / 2);
@@ -86,6 +122,23 @@ struct PipeChunk {
     pipe_first<oa(0), oa(0) + 32 * KC * 4, ob(0), ob(0) + 128>(s0[0], s0[1], s0[2], s0[3], addr_a[0], addr_b);
     run<0>(acc, s0, s1, addr_a, addr_b);
   }
+  // narrow wave tile: acc[2][1]
+  template <int G>
+  static __device__ __forceinline__ void run_n(f32x16 (&acc)[2][1], float (&s0)[3], float (&s1)[3], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
+    float(&cur)[3] = (G & 1) ? s1 : s0;
+    float(&nxt)[3] = (G & 1) ? s0 : s1;
+    if constexpr (G + 1 < SLOTS) {
+      pipe_group_n<oa(G + 1), oa(G + 1) + 32 * KC * 4, ob(G + 1)>(acc[0][0], acc[1][0], cur[0], cur[1], cur[2], nxt[0], nxt[1], nxt[2], addr_a[(G + 1) / (KC / 2)], addr_b);
+      run_n<G + 1>(acc, s0, s1, addr_a, addr_b);
+    } else {
+      pipe_last_n(acc[0][0], acc[1][0], cur[0], cur[1], cur[2]);
+    }
+  }
+  static __device__ __forceinline__ void chunk(f32x16 (&acc)[2][1], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
+    float s0[3], s1[3];
+    pipe_first_n<oa(0), oa(0) + 32 * KC * 4, ob(0)>(s0[0], s0[1], s0[2], addr_a[0], addr_b);
+    run_n<0>(acc, s0, s1, addr_a, addr_b);
+  }
 };
 
 // Epilogue of the pipelined kernel.  The activation kind and the fused variants are dispatched ONCE per wave (template parameters), so
@@ -96,8 +149,8 @@ struct PipeChunk {
 // dropped by the hardware bounds check (out row = out_stride*m + out_off >= Ly exactly when m >= M).
 // MODE 0: y = act(acc + bias);  MODE 1: ... then the fused Dropout keep-mask;  MODE 2: data gradient times the producer's act'(gy);
 // MODE 3: MODE 2 through the producer's dropout.
-template <int ACT, int MODE, int GACT>
-__device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&acc)[2][2], int b, int m_base, int n_base, int i32, int h) {
+template <int ACT, int MODE, int GACT, int WN>
+__device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&acc)[2][WN], int b, int m_base, int n_base, int i32, int h) {
   const uintptr_t yp = (uintptr_t)(a.y + (size_t)b * a.Ly * a.Cout);
   const unsigned ylo = __builtin_amdgcn_readfirstlane((unsigned)yp), yhi = __builtin_amdgcn_readfirstlane((unsigned)(yp >> 32));
   const int ybytes = __builtin_amdgcn_readfirstlane(a.Ly * a.Cout * 4);
@@ -116,7 +169,7 @@ __device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&
   const int rowstride = a.t.out_stride * a.Cout;           // elements between consecutive m
   const float ginv = (MODE == 3) ? 1.0f / a.gscale : 1.0f;
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
+  for (int nt = 0; nt < WN; ++nt) {
     const int n = n_base + nt * 32 + i32;
     const float bias = a.bias ? a.bias[n] : 0.f;
     const int voff = rowstride * (4 * h) + a.t.out_off * a.Cout + n;               // element offset of (row 4h, column n)
@@ -151,10 +204,10 @@ __device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&
   }
 }
 
-template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_pipe_kernel(ConvArgs a, int m_tiles, int n_tiles, int patch) {
+template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8, int WN = 2>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 256 ? 1 : 2)) void conv_mfma_pipe_kernel(ConvArgs a, int m_tiles, int n_tiles, int patch) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int WM = 2, WN = 2;
+  constexpr int WM = 2;
   constexpr int TM = WAVES_M * WM * 32;
   constexpr int TN = WAVES_N * WN * 32;
   constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -271,14 +324,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_pipe_kern
     }
   }
   // MFMA results written inside asm: the compiler inserts no wait states for its own readers of acc
-  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+  if constexpr (WN == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+  else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]));
 
   const int m_base = m0 + __builtin_amdgcn_readfirstlane(wm) * WM * 32, n_base = n0 + wn * WN * 32;
   // uniform dispatch, decided once; every case is straight-line code.  Specialised: the forms the three networks run (forward
   // linear / relu / LeakyReLU / tanh, LeakyReLU + dropout, data gradient through relu, through LeakyReLU + dropout); the rest take
   // the variants that decide the activation per element.
   const int mode = a.gy ? (a.gmask ? 3 : 2) : (a.mask ? 1 : 0);
-#define GN_EPI(A_, M_, G_) pipe_epilogue<A_, M_, G_>(a, acc, b, m_base, n_base, i32, h)
+#define GN_EPI(A_, M_, G_) pipe_epilogue<A_, M_, G_, WN>(a, acc, b, m_base, n_base, i32, h)
   if (mode == 0) {
     switch (a.act) {
       case GN_ACT_LINEAR: GN_EPI(GN_ACT_LINEAR, 0, -1); break;
@@ -338,16 +392,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_pipe_kern
 #endif
 }
 
-template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8>
+template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8, int WN = 2>
 static int launch_conv_pipe(const ConvArgs& a, hipStream_t s) {
-  constexpr int TM = WAVES_M * 64, TN = WAVES_N * 64;
+  constexpr int TM = WAVES_M * 64, TN = WAVES_N * WN * 32;
   constexpr int R = IS * (TM - 1) + NTAPS, RPER = (R + IS - 1) / IS;
   constexpr size_t lds = 2 * sizeof(float) * ((size_t)IS * RPER * KC + (size_t)NTAPS * KC * TN);
   static_assert(lds <= 160 * 1024, "stage too large");
   static_assert(lds / 2 + (NTAPS * KC + 8) * TN * 4 < 65536, "ds_read offsets must fit 16 bits");
   if (lds > 64 * 1024) {
     static unsigned long long lds_done = 0;
-    allow_big_lds((const void*)conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS, KC>, &lds_done);
+    allow_big_lds((const void*)conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS, KC, WN>, &lds_done);
   }
   const int m_tiles = (a.M + TM - 1) / TM, n_tiles = a.Cout / TN;
   const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
@@ -363,7 +417,7 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t s) {
     if (!no_patch && pn >= 0 && ng <= 8 && (ng & (ng - 1)) == 0) patch = __builtin_ctz(ng) | (pn << 8);
   }
   prof_begin(s);
-  hipLaunchKernelGGL((conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS, KC>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles,
+  hipLaunchKernelGGL((conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS, KC, WN>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles,
                      patch);
   prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0, 4.0 * ((double)a.B * a.Lin * a.Cin + (double)a.t.ntaps * a.Cin * a.Cout + (double)a.B * a.M * a.Cout));
   int rc = check_launch("conv_mfma_pipe");
@@ -394,11 +448,31 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
     a2.stat_part = nullptr;
     return conv_pipe_try(a2, tall, s, launched);
   }
-  // (Smaller tiles for under-filled grids -- 128 x 64 with 2 waves, 64 x 64 with 1 wave per block, at the script's own batch 8 / n_pix 1024
-  // where e.g. the q-branch's last data gradient is 128 blocks for 256 CUs -- were measured in round 3: CNN step 2.34 -> 2.31 ms, GAN iteration
-  // 4.85 -> 5.36 ms.  The number of 64 x 64 WAVE tiles is what it is (509 for that launch, for 1024 SIMDs): cutting blocks into fewer
-  // waves fills more CUs but the same number of SIMDs.  More parallelism there needs split-K or a smaller wave tile, not a smaller block.)
-#define GN_PIPE(NT_, IS_) return tall ? launch_conv_pipe<4, 1, NT_, IS_>(a, s) : launch_conv_pipe<2, 2, NT_, IS_>(a, s)
+  // Under-filled grids (the script's own batch 8 / n_pix 1024: the q-branch's last convolution is 128 tall blocks for 256 CUs), measured in
+  // round 3 at batch 8 (CNN step / GAN iteration, ms; baseline 2.34 / 4.85): smaller BLOCKS of full 64 x 64 waves (128 x 64 with 2 waves,
+  // 64 x 64 with 1) 2.31 / 5.36 -- more CUs but the same number of SIMDs; narrow WAVES (64 x 32) in the unchanged block tile 2.30 / 4.89 --
+  // more waves on the same CUs; narrow waves with 16-channel chunks 3.06 / 6.34.
+  // What fills the chip is both at once: NARROW waves (64 x 32 each, pipe_group_n) in SMALLER blocks of 64 columns -- 8, 4 or 2 waves for 256,
+  // 128 or 64 rows -- so that a launch with fewer than two 64 x 64 wave tiles per SIMD gets at least two blocks per CU where it can, and
+  // every block still spreads over the CU's SIMDs.
+  static const bool no_narrow = getenv("GN_CONV_NONARROW") != nullptr;          // A/B switch
+  static const int narrow_below = getenv("GN_CONV_NARROW_BELOW") ? atoi(getenv("GN_CONV_NARROW_BELOW")) : 2048;
+  const size_t wave_tiles = (size_t)a.B * (size_t)((a.M + 63) / 64) * (size_t)(a.Cout / 64);
+  const bool narrow_wave = !no_narrow && a.Cout % 64 == 0 && wave_tiles < (size_t)narrow_below;
+  int nwm = 4;
+  if (narrow_wave) {
+    auto blocks_of = [&](int wm_) { return (size_t)a.B * (size_t)((a.M + 64 * wm_ - 1) / (64 * wm_)) * (size_t)(a.Cout / 64); };
+    while (nwm > 1 && blocks_of(nwm) < 512) nwm >>= 1;
+  }
+#define GN_PIPE(NT_, IS_)                                                                    \
+  do {                                                                                       \
+    if (narrow_wave) {                                                                       \
+      if (nwm == 4) return launch_conv_pipe<4, 2, NT_, IS_, 8, 1>(a, s);                     \
+      if (nwm == 2) return launch_conv_pipe<2, 2, NT_, IS_, 8, 1>(a, s);                     \
+      return launch_conv_pipe<1, 2, NT_, IS_, 8, 1>(a, s);                                   \
+    }                                                                                        \
+    return tall ? launch_conv_pipe<4, 1, NT_, IS_>(a, s) : launch_conv_pipe<2, 2, NT_, IS_>(a, s);                       \
+  } while (0)
   // (4-channel chunks for the stride-2 forward -- 27 instead of 53 KiB of LDS, a fourth block per CU, but a barrier per 40 MFMAs -- were
   // measured: 140.3 -> 135.5 TFLOP/s.  Eight channels per chunk is the optimum in both directions.)
   if (a.t.in_stride == 2) { GN_PIPE(5, 2); }
