@@ -296,11 +296,11 @@ def main():
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'last_losses': last_losses,
-            'config': {'workload': ('BASELINE %s; per GPU and step: 2 x CNN point-estimator train_on_batch(batch=%d) + 1 GAN iteration(batch=%d) '
+            'config': {'workload': ('BASELINE %s; per GPU and step: %d x CNN point-estimator train_on_batch(batch=%d) + 1 GAN iteration(batch=%d) '
                                     '(G.predict, D step on 2B, G step through frozen D); n_pix=%d; %s')
                                    % ('configs[4] (cfg5)' if wl['online'] else ('-- NOT a BASELINE config: the reference script\'s own defaults (bbhMahoGANy.py:84-89), loop bodies %s'
                                                                                  % ('replayed as captured hipGraphs' if graphed else 'run eagerly')
-                                                                                 if args.config == 'refdefaults' else 'configs[1]+[2]'), CNN_BATCH, GAN_BATCH, N_PIX,
+                                                                                 if args.config == 'refdefaults' else 'configs[1]+[2]'), WAVES // CNN_BATCH, CNN_BATCH, GAN_BATCH, N_PIX,
                                       'every batch synthesised on the GPU inside the step: CNN rows = template + PSD-coloured noise whitened with the same PSD, one launch (prior -> chirp -> irFFT -> align -> crop -> gen_noise -> whiten_data(td) -> add); GAN real images = [noise-free template | coloured whitened noise], two launches' if wl['online']
                                       else '%d whitened BBH templates synthesised on the GPU into an HBM-resident bank before the timed region' % bank_n),
                        'name': args.config, 'n_pix': N_PIX, 'cnn_batch': CNN_BATCH, 'gan_batch': GAN_BATCH, 'predict_batch': predict_batch,

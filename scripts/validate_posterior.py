@@ -82,6 +82,8 @@ def parse(argv=None):
     ap.add_argument('--pe-batch', type=int, default=256)
     ap.add_argument('--pe-iter', type=int, default=16000, help='500 000 x 8 waveforms of the reference (bbhMahoGANy.py:86-89) = 15 625 steps of 256')
     ap.add_argument('--cnn-seconds', type=float, default=300.0)
+    ap.add_argument('--pe-settle-steps', type=int, default=0, help='DIAGNOSTIC, not in the reference: after the CNN loop, this many more steps at lr / 10, '
+                                                                     'and the held-out error again -- separates the optimiser\'s last-iterate noise from what the net has learnt')
     ap.add_argument('--gan-batch', type=int, default=32)
     ap.add_argument('--gan-iter', type=int, default=125000, help='500 000 x 8 waveforms of the reference = 125 000 iterations of 32')
     ap.add_argument('--gan-seconds', type=float, default=600.0)
@@ -90,6 +92,9 @@ def parse(argv=None):
     ap.add_argument('--fine-cadence', type=int, default=500)
     ap.add_argument('--predict-batch', type=int, default=32, help='chunk of generator.predict inside the GAN iteration')
     ap.add_argument('--lr', type=float, default=9e-5)
+    ap.add_argument('--chi-loss', action='store_true', help='chi_loss (bbhMahoGANy.py:97, :1106-1109): the generator trains on chisquare_Loss instead of binary cross-entropy')
+    ap.add_argument('--save-pe', default='', help='write the trained CNN to this .h5 file (Keras layout)')
+    ap.add_argument('--load-pe', default='', help='skip the CNN loop and load the CNN from this .h5 file')
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--graph', action='store_true', help='run the train steps as captured hipGraphs (engine.GraphedStep)')
     ap.add_argument('--out', default='gpurun_out/posterior_validation.json')
@@ -126,7 +131,7 @@ def run(args):
     noise = np.random.RandomState(100 + args.seed).randn(fs)
     event = (ev_raw.cpu().numpy()[0] * g + noise).astype(np.float32)                    # d = g h + n
     truth = [float((36.0 * 29.0) ** 0.6 / 65.0 ** 0.2), 29.0 / 36.0]
-    out = {'config': {k: getattr(args, k) for k in ('n_pix', 'bank', 'pe_batch', 'pe_iter', 'gan_batch', 'gan_iter', 'cadence', 'lr', 'seed', 'graph')},
+    out = {'config': {k: getattr(args, k) for k in ('n_pix', 'bank', 'pe_batch', 'pe_iter', 'gan_batch', 'gan_iter', 'cadence', 'lr', 'seed', 'graph', 'chi_loss', 'load_pe')},
            'event': {'m1': 36.0, 'm2': 29.0, 'idx': N // 2, 'mc': truth[0], 'q': truth[1], 'optimal_snr': snr, 'template_scale_g': g,
                      'noise': 'N(0,1), RandomState(%d)' % (100 + args.seed)},
            'reference_yardstick_pe_std': PE_STD_REFERENCE}
@@ -144,7 +149,7 @@ def run(args):
     print('exact posterior: %s (%.1f s)' % (json.dumps(out['exact_posterior']), time.time() - t0), flush=True)
 
     # ---- networks
-    nets = bbh.build_and_compile(event.reshape(fs, 1), fs, lr=args.lr)
+    nets = bbh.build_and_compile(event.reshape(fs, 1), fs, lr=args.lr, chi_loss=args.chi_loss)
     ev_dev = engine.to_device(event)
     pe_step = gan_step = None
     if args.graph:
@@ -155,6 +160,9 @@ def run(args):
     t0 = time.time()
     hist = []
     i = 0
+    if args.load_pe:
+        nets.signal_pe.load_weights(args.load_pe)
+        args.pe_iter = 0
     while i < args.pe_iter and time.time() - t0 < args.cnn_seconds:
         r = pe_step(want_losses=(i % 1000 == 0)) if pe_step else bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch)
         if i % 1000 == 0:
@@ -171,6 +179,17 @@ def run(args):
                   'mean_abs_error_heldout [mc, q]': [float(e.mean()) for e in err], 'median_abs_error_heldout [mc, q]': [float(np.median(e)) for e in err],
                   'mean_abs_error_training_4000 [mc, q] (the reference read-out, :1184-1196)': std_tr, 'mse_training_4000 [mc, q]': rms_tr,
                   'prior_std [mc, q]': [float(hy[:, 0].std()), float(hy[:, 1].std())], 'loss_history [step, total, mc, q]': hist}
+    if args.save_pe:
+        nets.signal_pe.save_weights(args.save_pe, True)
+    if args.pe_settle_steps > 0:
+        nets.signal_pe.optimizer.lr = float(np.float32(args.lr / 10.0))
+        for _ in range(args.pe_settle_steps):
+            bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch)
+        p2 = nets.signal_pe.predict_device(held_x.reshape(-1, fs, 1), batch_size=256)
+        err2 = [np.abs(hy[:, k] - p2[k].cpu().numpy().reshape(-1)) for k in range(2)]
+        out['cnn']['diagnostic_after_settling'] = {'extra_steps': args.pe_settle_steps, 'lr': args.lr / 10.0,
+                                                   'mean_abs_error_heldout [mc, q]': [float(e.mean()) for e in err2],
+                                                   'over_reference_pe_std [mc, q]': [float(err2[k].mean()) / PE_STD_REFERENCE[k] for k in range(2)]}
     print('cnn done: %s' % json.dumps({k: v for k, v in out['cnn'].items() if 'history' not in k}), flush=True)
 
     # ---- GAN: the reference's loop body (:1241-1299), scored at every cadence (:1330-1356)
