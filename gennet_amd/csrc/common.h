@@ -69,7 +69,9 @@ struct WgradArgs {
   double* db_part;  // optional [splits][Cout]: per-split column sums of dy (the bias gradient), written by the blocks of Cin-tile 0
   float* db;        // optional: where wgrad_mfma_dispatch puts the bias gradient when the kernel it selects can sum it on the way
   int db_done;      // set by the dispatcher when db has been written
-  int xcd_order;    // wgrad_pipe_kernel: splits % 8 == 0 and every XCD (block i -> XCD i mod 8) takes whole K-splits (see the kernel)
+  int xcd_order;    // wgrad_pipe_kernel: 1 = splits % 8 == 0 and every XCD (block i -> XCD i mod 8) takes whole K-splits; 2 = every XCD takes one patch of
+                    // (Cin tiles / patch_px) x (Cout tiles / (8 / patch_px)) tiles of each split (see the kernel)
+  int patch_px;
 };
 
 struct WgradSmallArgs {

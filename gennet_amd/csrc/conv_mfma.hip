@@ -739,6 +739,20 @@ static int launch_wgrad(WgradArgs& a, float* dw, hipStream_t s) {
       // with private splits every XCD streams its own batch range from HBM.  Off unless GN_WGRAD_XCD is set.
       static const bool xcd = getenv("GN_WGRAD_XCD") != nullptr;
       a.xcd_order = xcd && splits % 8 == 0;
+      // patch order of the tile plane inside every split (GN_WGRAD_PATCH; measured in round 3): needs the tile
+      // plane to split into 8 patches, px x (8 / px) with px | Cin tiles and (8 / px) | Cout tiles, as square as possible
+      static const bool patch = getenv("GN_WGRAD_PATCH") != nullptr;
+      a.patch_px = 0;
+      if (patch && !a.xcd_order) {
+        int best = 0, best_cost = 1 << 30;
+        for (int px = 1; px <= 8; px <<= 1) {
+          const int py = 8 / px;
+          if ((int)grid.x % px || (int)grid.y % py) continue;
+          const int cost = (int)grid.x / px + (int)grid.y / py;       // tiles of x plus tiles of dy an XCD streams per split
+          if (cost < best_cost) { best_cost = cost; best = px; }
+        }
+        if (best) { a.xcd_order = 2; a.patch_px = best; }
+      }
       wgrad_pipe_launch(a, grid, WAVES_C == 2, s);                       // wgrad_pipe.hip
       piped = true;
     }

@@ -106,7 +106,18 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(W
   // tiles (consecutive blocks of an XCD walk the tiles of one split), so each x slab and dy tile of a split is fetched by one XCD only
   // and its L2 serves the Cin-tile x Cout-tile reuse.
   int ct = blockIdx.x, nt_ = blockIdx.y, split = blockIdx.z;
-  if (a.xcd_order) {
+  if (a.xcd_order == 2) {
+    // patch order (round 3): inside every split the 8 XCDs take the 8 patches of a (px x 8/px) partition of the (Cin tile,
+    // Cout tile) plane, so an XCD's L2 serves each x slab tile to pn and each dy tile to pc blocks (4 x 4 tiles on G 512 -> 1024) instead of
+    // owning one Cin tile with ALL the Cout tiles (dy crossing the fabric 8 times)
+    const int gx = gridDim.x, gy = gridDim.y, tiles = gx * gy;
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int r = lin % tiles, k = r & 7, i = r >> 3;
+    const int px = a.patch_px, py = 8 / px, pc = gx / px, pn = gy / py;
+    split = lin / tiles;
+    ct = (k % px) * pc + (i % pc);
+    nt_ = (k / px) * pn + (i / pc);
+  } else if (a.xcd_order) {
     const int tiles = gridDim.x * gridDim.y;
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     const int q = lin >> 3, tile = q % tiles;
