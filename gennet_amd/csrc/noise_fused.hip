@@ -1,5 +1,6 @@
 // gn_noise_whitened: one workgroup per row runs gen_noise -> whiten_data('td') -> crop (noise_chain.h) and writes the crop, optionally
 // added to a template row, as fp64 and / or fp32.  gw_template_maker.py:161-193, :243-286; BASELINE configs[4] ("coloured-Gaussian PSD").
+#include <stdlib.h>
 #include "common.h"
 #include "noise_chain.h"
 
@@ -14,7 +15,7 @@ struct NoiseLaunch {
 };
 
 template <int LOGM, int NT>
-__global__ __launch_bounds__(NT) void noise_whitened_kernel(NoiseLaunch a) {
+__global__ __launch_bounds__(NT, (NT >= 1024 ? 1 : 2)) void noise_whitened_kernel(NoiseLaunch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double2* d = reinterpret_cast<double2*>(smem_raw);
   const int b = blockIdx.x;
@@ -52,12 +53,13 @@ static int launch_noise(const NoiseLaunch& a, hipStream_t s) {
 
 int noise_whitened(const NoiseLaunch& a, int N, hipStream_t s) {
   if (a.nb == 0) return GN_OK;
+  static const bool wide_threads = getenv("GN_SYNTH_WIDE_THREADS") != nullptr;      // A/B switch: 16 values per thread instead of 8
   switch (N) {
     case 1024: return launch_noise<9, 128>(a, s);
     case 2048: return launch_noise<10, 256>(a, s);
     case 4096: return launch_noise<11, 256>(a, s);
     case 8192: return launch_noise<12, 256>(a, s);
-    case 16384: return launch_noise<13, 512>(a, s);
+    case 16384: return wide_threads ? launch_noise<13, 512>(a, s) : launch_noise<13, 1024>(a, s);
     default:
       set_error("noise_whitened: N %d unsupported (1024, 2048, 4096, 8192, 16384)", N);
       return GN_EINVAL;

@@ -15,6 +15,7 @@
 // samples again (emit the even half) -- a third transform is cheaper than a second 64 KiB buffer, which would halve the blocks per CU.
 // ref_idx = argmax(h+^2 + hx^2) over the rolled series (first maximum), slide = ref_idx - idx - peak_off with python slice
 // semantics, zero fill past the end, exactly as align_crop_kernel (synth.hip) does.
+#include <stdlib.h>
 #include "common.h"
 #include "fft_lds.h"
 #include "noise_chain.h"
@@ -109,7 +110,7 @@ __device__ __forceinline__ double2 chirp_bin(const ChirpCoeffsF& c, int k, doubl
 }
 
 template <int LOGM, int NT, bool NOISE>
-__global__ __launch_bounds__(NT, 2) void synth_fused_kernel(SynthArgs a) {
+__global__ __launch_bounds__(NT, (NT >= 1024 ? 1 : 2)) void synth_fused_kernel(SynthArgs a) {
   constexpr int M = 1 << LOGM, N = 2 * M, KPT = M / NT, KC = (KPT + 1) / 2;      // KC crop samples per thread in noise mode (crop_len <= M/2 = N/4)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double2* d = reinterpret_cast<double2*>(smem_raw);                                           // PH(M) padded complex values
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(NT, 2) void synth_fused_kernel(SynthArgs a) {
     cf->nyq_re = nq.x; cf->nyq_im = nq.y;
   }
   __syncthreads();
-  const ChirpCoeffsF c = *cf;
+  const ChirpCoeffsF c = *cf;                  // private copy (reading the coefficients from LDS per bin measured 6 % slower)
 
   double2 S[KPT];
 #pragma unroll
@@ -314,12 +315,16 @@ static int launch_synth(const SynthArgs& a, hipStream_t s) {
 
 int synth_templates(const SynthArgs& a, hipStream_t s) {
   if (a.nb == 0) return GN_OK;
+  static const bool wide_threads = getenv("GN_SYNTH_WIDE_THREADS") != nullptr;
   switch (a.N) {
     case 1024: return launch_synth<9, 128>(a, s);
     case 2048: return launch_synth<10, 256>(a, s);
     case 4096: return launch_synth<11, 256>(a, s);
+    // threads per block measured in round 3 (ms per 16 384 templates; GN_SYNTH_WIDE_THREADS = 16 values per thread at N 16384): N 8192: 256
+    // threads 1.61, 512 threads 2.31 (two blocks per CU either way, the barriers of 8 waves cost more than their latency hiding buys);
+    // N 16384 (one block per CU): 512 threads 8.26 (template + noise), 1024 threads 7.33
     case 8192: return launch_synth<12, 256>(a, s);
-    case 16384: return launch_synth<13, 512>(a, s);
+    case 16384: return wide_threads ? launch_synth<13, 512>(a, s) : launch_synth<13, 1024>(a, s);
     default:
       set_error("synth_templates: N %d unsupported (1024, 2048, 4096, 8192, 16384)", a.N);
       return GN_EINVAL;
