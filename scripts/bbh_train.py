@@ -39,6 +39,8 @@ def main():
     ap.add_argument('--cnn-noise-frac', type=float, default=1.0 / 8.0, help='cnn_noise_frac (:113): fraction of each CNN batch that gets noise added')
     ap.add_argument('--retrain-pe-mod', action='store_true', help='retrain_pe_mod (:104, :1145): load best_models/signal_pe.h5 and keep training it')
     ap.add_argument('--n-noise-real', type=int, default=1, help='noise realisations per sampled template in the GAN loop (:107)')
+    ap.add_argument('--graph', action='store_true', help='replay the two loop bodies as captured hipGraphs (single GPU, n_noise_real 1): the same numbers bit for '
+                                                       'bit, no per-iteration host synchronisation between the read-outs')
     ap.add_argument('--pe-cadence', type=int, default=1000, help='CNN progress read-out every so many iterations (:1176, :1200)')
     ap.add_argument('--old-model', action='store_true', help='do_old_model (:1133-1138): start all four networks from the files of an earlier run in --out')
     ap.add_argument('--only-old-pe-model', action='store_true', help='do_only_old_pe_model (:1141-1142): load best_models/signal_pe.h5 and skip the CNN loop')
@@ -89,8 +91,14 @@ def main():
     # file on disk, or its error raised -- on normal exit AND when a loop dies (KeyboardInterrupt included)
     with hostio.BackgroundWriter() as bg:
         skip_pe = args.only_old_pe_model and not args.retrain_pe_mod                      # :1145
+        graphed = args.graph and dp is None and args.n_noise_real == 1
+        pe_step = bbh.GraphedPEStep(nets.signal_pe, bank, args.pe_batch_size, cnn_noise_frac=args.cnn_noise_frac) if graphed else None
+        gan_step = bbh.GraphedGANStep(nets, bank, event, args.batch_size) if graphed else None
         for i in range(0 if skip_pe else args.pe_iter):                                   # :1153-1173
-            pe_loss = bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch_size, cnn_noise_frac=args.cnn_noise_frac, rank=rank, world=world)
+            if graphed:
+                pe_loss = pe_step(want_losses=(i % args.pe_cadence == 0 or i % 1000 == 0))
+            else:
+                pe_loss = bbh.pe_train_step(nets.signal_pe, bank, args.pe_batch_size, cnn_noise_frac=args.cnn_noise_frac, rank=rank, world=world)
             if i % 5000 == 0 and i > 0 and rank == 0:
                 nets.signal_pe.save(os.path.join(args.out, 'best_models/signal_pe.h5'), True, writer=bg)
             if i % args.pe_cadence == 0 and i > 0:                                        # :1176-1196
@@ -114,7 +122,10 @@ def main():
         print('Completed CNN PE')
 
         for i in range(args.max_iter):                                                    # :1241-1382
-            l = bbh.gan_train_step(nets, bank, event, args.batch_size, rank=rank, world=world, n_noise_real=args.n_noise_real)
+            if graphed:
+                l = gan_step(want_losses=(i % args.cadence == 0))
+            else:
+                l = bbh.gan_train_step(nets, bank, event, args.batch_size, rank=rank, world=world, n_noise_real=args.n_noise_real)
             if i % args.cadence == 0 and i > 0 and rank == 0:
                 print('%d: [sD loss: %f, acc: %f]  [sG loss: %f, acc: %f]' % (i, l[2], l[3], l[0], l[1]), flush=True)
                 pe_samples, waves = bbh.posterior_samples(nets, 4000)                     # :1330-1343

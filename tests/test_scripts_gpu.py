@@ -46,7 +46,7 @@ def test_template_maker_then_trainer_leave_the_reference_files(tmp_path):
     assert 'Completed CNN PE' in out and '[sD loss:' in out and 'RMS:' in out and 'mean |error| (mc, q):' in out
     # do_old_model / do_only_old_pe_model (bbhMahoGANy.py:1133-1142): a second run starts from the files of the first and skips the CNN loop
     out2 = run([os.path.join(ROOT, 'scripts/bbh_train.py'), '--templates', 'templates/', '--training-num', str(n), '--tag', tag, '--n-pix', str(fs),
-                '--batch-size', '4', '--max-iter', '2', '--cadence', '1', '--event-scale', '1.0', '--out', 'run', '--old-model', '--only-old-pe-model'],
+                '--batch-size', '4', '--max-iter', '4', '--cadence', '1', '--event-scale', '1.0', '--out', 'run', '--old-model', '--only-old-pe-model', '--graph'],
                str(tmp_path))
     assert 'Completed CNN PE' in out2 and 'PE loss' not in out2 and '[sD loss:' in out2
     if 'posterior overlap beta' in out:             # scored only once both read-outs vary (bbhMahoGANy.py:1352); a few hundred steps may not get there
