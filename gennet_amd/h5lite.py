@@ -473,9 +473,14 @@ class Writer(object):
         leaves a truncated file under the final name -- the previous checkpoint stays readable."""
         data = self.tobytes()
         tmp = path + '.tmp'
-        with open(tmp, 'wb') as fh:
-            fh.write(data)
-        os.replace(tmp, path)
+        try:
+            with open(tmp, 'wb') as fh:
+                fh.write(data)
+            os.replace(tmp, path)
+        except BaseException:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise
 
     def _alloc(self, blob):
         pad = _pad8(len(self._buf)) - len(self._buf)

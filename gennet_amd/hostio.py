@@ -58,9 +58,14 @@ class BackgroundWriter(object):
         """pickle.dump(obj, open(path, 'wb'), protocol) in the worker; obj must not be mutated by the caller afterwards."""
         def job():
             tmp = path + '.tmp'
-            with open(tmp, 'wb') as f:
-                pickle.dump(obj, f, protocol=protocol)
-            os.replace(tmp, path)
+            try:
+                with open(tmp, 'wb') as f:
+                    pickle.dump(obj, f, protocol=protocol)
+                os.replace(tmp, path)
+            except BaseException:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise
         self.submit(job)
 
     def flush(self):

@@ -348,6 +348,7 @@ def test_interrupted_writes_never_truncate_the_previous_file(tmp_path):
             bg.pickle([lambda: 0], path)                         # pickling fails after the temporary file was opened
     with open(path, 'rb') as f:
         assert pickle.load(f) == [1, 2, 3]
+    assert not os.path.exists(path + '.tmp')                     # the failed job removed its temporary file
     done = []
     with pytest.raises(KeyboardInterrupt):
         with hostio.BackgroundWriter() as bg:                    # the loop dies: queued jobs are still completed by __exit__
