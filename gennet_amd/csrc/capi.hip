@@ -324,7 +324,7 @@ static int dgrad_impl(const float* dy, const float* wt, float* dx, int B, int L,
 
 size_t gn_conv1d_wgrad_workspace(int B, int L, int Cin, int Cout, int k, int stride, int Lout) {
   (void)L; (void)stride;
-  size_t w = (Cin <= 4 || Cout <= 4) ? wgrad_small_workspace_bytes(B, Lout, Cin, Cout, k) : wgrad_workspace_bytes(B, Cin, Cout, k);
+  size_t w = (Cin <= 4 || Cout <= 4) ? wgrad_small_workspace_bytes(B, Lout, Cin, Cout, k) : wgrad_workspace_bytes(B, Lout, Cin, Cout, k);
   size_t b = bias_grad_ws((size_t)B * Lout, Cout);
   return (w > b ? w : b) + 256;
 }
@@ -387,7 +387,7 @@ int gn_dense_fwd(const float* x, const float* w, const float* bias, float* y, in
 
 size_t gn_dense_bwd_workspace(int B, int in, int out) {
   if (out <= 4) return 256;
-  size_t w = wgrad_workspace_bytes(1, in, out, 1);
+  size_t w = wgrad_workspace_bytes(1, B, in, out, 1);
   size_t b = bias_grad_ws((size_t)B, out);
   return (w > b ? w : b) + (size_t)in * out * sizeof(float) + 256;
 }

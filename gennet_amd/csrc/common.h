@@ -65,7 +65,7 @@ struct WgradArgs {
   int B, Lin, Cin, Cout, M;
   int ntaps, in_stride;
   int off[8];
-  int b_per_split;
+  int chunks_per_split;   // K-chunks (32 rows of one batch element) per split: whole batch elements when the batch fills the chip, parts of one below
   double* db_part;  // optional [splits][Cout]: per-split column sums of dy (the bias gradient), written by the blocks of Cin-tile 0
   float* db;        // optional: where wgrad_mfma_dispatch puts the bias gradient when the kernel it selects can sum it on the way
   int db_done;      // set by the dispatcher when db has been written
@@ -113,7 +113,7 @@ struct ColRedArgs {
 
 // conv_mfma.hip
 int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s);
-size_t wgrad_workspace_bytes(int B, int Cin, int Cout, int ntaps);
+size_t wgrad_workspace_bytes(int B, int M, int Cin, int Cout, int ntaps);
 int wgrad_mfma_dispatch(WgradArgs& a, float* dw, size_t ws_bytes, hipStream_t s);
 // conv_pipe.hip / wgrad_pipe.hip (hand-scheduled variants selected by the two dispatchers above)
 int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched);

@@ -582,9 +582,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N) void wgrad_mfma_kernel(Wgra
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][u][r] = 0.f;
 
-  const int b_lo = split * a.b_per_split, b_hi = min(a.B, b_lo + a.b_per_split);
   const int cpb = (a.M + KT - 1) / KT;                     // K-chunks per batch element
-  const int n_chunks = (b_hi - b_lo) * cpb;
+  const int c_lo = split * a.chunks_per_split, c_hi = min(a.B * cpb, c_lo + a.chunks_per_split);
+  const int n_chunks = max(c_hi - c_lo, 0);
 
   // register-staged pipeline over the K-chunks (b, m0): loads of chunk i+1 fly during the MFMA block of chunk i
   constexpr int S_ITEMS = ((2 * (KT - 1) + 5) * (TC / 4) + NT - 1) / NT;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N) void wgrad_mfma_kernel(Wgra
   const int s_count = R * (TC / 4);
 
   auto load_chunk = [&](int ch) {
-    const int b = b_lo + ch / cpb, m0 = (ch % cpb) * KT;
+    const int b = (c_lo + ch) / cpb, m0 = ((c_lo + ch) % cpb) * KT;
     const float* xb = a.x + (size_t)b * a.Lin * a.Cin;
     const float* dyb = a.dy + (size_t)b * a.M * a.Cout;
     const int t_base = is * m0 + minoff;
@@ -686,13 +686,30 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
   reinterpret_cast<float4*>(dw)[i] = s;
 }
 
-static int wgrad_splits(int B, int Cin, int Cout, int TC, int TN) {
+// K-splits of the weight gradient: about 2048 blocks in all.  A split is a range of K-chunks (32 rows of one batch element, KT in the kernels);
+// normally whole batch elements (chunks_per_split a multiple of the chunks per element: the partition of every earlier round).  Only when
+// even one split per batch element leaves the chip idle (tiles * B < 256: the small layers at the script's own batch 8) are the elements cut
+// into ranges of at least 4 chunks, for about 512 blocks.  (Measured at batch 8, us per launch: G 128 -> 256 90 -> 54, PE q 128 -> 256 87 -> 51;
+// cutting layers that already had 256+ blocks was slower -- G 256 -> 512 99 -> 134 -- the extra partial slabs cost more than they buy.)
+static void wgrad_split_plan(int B, int M, int Cin, int Cout, int TC, int TN, int* splits, int* chunks_per_split) {
+  const int cpb = (M + 31) / 32;
   const int tiles = cdiv(Cin, TC) * cdiv(Cout, TN);
   int s = (2048 + tiles - 1) / tiles;
-  if (s > B) s = B;
   if (s < 1) s = 1;
-  const int bps = (B + s - 1) / s;
-  return (B + bps - 1) / bps;
+  static const bool no_sub = getenv("GN_WGRAD_NOSUBSPLIT") != nullptr;       // A/B switch
+  int cps;
+  if (s <= B || no_sub || (long)tiles * B >= 256) {
+    if (s > B) s = B;
+    const int bps = (B + s - 1) / s;
+    cps = bps * cpb;
+  } else {
+    s = (512 + tiles - 1) / tiles;
+    const int per_b = std::min((s + B - 1) / B, std::max(cpb / 4, 1));      // ranges per batch element, each at least 4 chunks
+    cps = (cpb + per_b - 1) / per_b;
+  }
+  const long total = (long)B * cpb;
+  *chunks_per_split = cps;
+  *splits = (int)((total + cps - 1) / cps);
 }
 
 static bool wgrad_square(int Cin, int Cout, int ntaps) {
@@ -705,10 +722,11 @@ static void wgrad_tile(int Cin, int Cout, int ntaps, int* TC, int* TN) {
   if (wgrad_square(Cin, Cout, ntaps)) { *TC = 64; *TN = 64; } else { *TC = 32; *TN = 128; }
 }
 
-size_t wgrad_workspace_bytes(int B, int Cin, int Cout, int ntaps) {
+size_t wgrad_workspace_bytes(int B, int M, int Cin, int Cout, int ntaps) {
   int TC, TN;
   wgrad_tile(Cin, Cout, ntaps, &TC, &TN);
-  const int s = wgrad_splits(B, Cin, Cout, TC, TN);
+  int s, cps;
+  wgrad_split_plan(B, M, Cin, Cout, TC, TN, &s, &cps);
   return (size_t)s * ntaps * Cin * Cout * sizeof(float) + (size_t)s * Cout * sizeof(double);      // dw slabs + per-split bias partials
 }
 
@@ -716,8 +734,8 @@ size_t wgrad_workspace_bytes(int B, int Cin, int Cout, int ntaps) {
 template <int WAVES_C, int WAVES_N, int WNT, int NTAPS>
 static int launch_wgrad(WgradArgs& a, float* dw, hipStream_t s) {
   constexpr int KT = 32, TC = WAVES_C * 32, TN = WAVES_N * WNT * 32;
-  const int splits = wgrad_splits(a.B, a.Cin, a.Cout, TC, TN);
-  a.b_per_split = (a.B + splits - 1) / splits;
+  int splits;
+  wgrad_split_plan(a.B, a.M, a.Cin, a.Cout, TC, TN, &splits, &a.chunks_per_split);
   int minoff = a.off[0], maxoff = a.off[0];
   for (int j = 1; j < NTAPS; ++j) {
     minoff = std::min(minoff, a.off[j]);
@@ -781,7 +799,7 @@ int wgrad_mfma_dispatch(WgradArgs& a, float* dw, size_t ws_bytes, hipStream_t s)
     set_error("wgrad_mfma: in_stride %d unsupported", a.in_stride);
     return GN_EINVAL;
   }
-  if (ws_bytes < wgrad_workspace_bytes(a.B, a.Cin, a.Cout, a.ntaps)) {
+  if (ws_bytes < wgrad_workspace_bytes(a.B, a.M, a.Cin, a.Cout, a.ntaps)) {
     set_error("wgrad_mfma: workspace too small");
     return GN_EWORKSPACE;
   }

@@ -462,7 +462,8 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
   int nwm = 4;
   if (narrow_wave) {
     auto blocks_of = [&](int wm_) { return (size_t)a.B * (size_t)((a.M + 64 * wm_ - 1) / (64 * wm_)) * (size_t)(a.Cout / 64); };
-    while (nwm > 1 && blocks_of(nwm) < 512) nwm >>= 1;
+    static const int min_blocks = getenv("GN_CONV_NARROW_BLOCKS") ? atoi(getenv("GN_CONV_NARROW_BLOCKS")) : 256;      // A/B switch
+    while (nwm > 1 && blocks_of(nwm) < (size_t)min_blocks) nwm >>= 1;
   }
 #define GN_PIPE(NT_, IS_)                                                                    \
   do {                                                                                       \

@@ -138,9 +138,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(W
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  const int b_lo = split * a.b_per_split, b_hi = min(a.B, b_lo + a.b_per_split);
   const int cpb = (a.M + KT - 1) / KT;
-  const int n_chunks = (b_hi - b_lo) * cpb;
+  const int c_lo = split * a.chunks_per_split, c_hi = min(a.B * cpb, c_lo + a.chunks_per_split);
+  const int n_chunks = max(c_hi - c_lo, 0);
 
   // per-lane byte offsets of the DMA granules inside one batch element, for m0 = 0 (chunk-invariant); the chunk adds m0 rows
   constexpr int S_COUNT = R * (TC / 4);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(W
   }
   const int xbytes = __builtin_amdgcn_readfirstlane(a.Lin * a.Cin * 4), dybytes = __builtin_amdgcn_readfirstlane(a.M * a.Cout * 4);
   auto dma_chunk = [&](int ch, float* stage) {
-    const int b = __builtin_amdgcn_readfirstlane(b_lo + ch / cpb), m0 = __builtin_amdgcn_readfirstlane((ch % cpb) * KT);
+    const int b = __builtin_amdgcn_readfirstlane((c_lo + ch) / cpb), m0 = __builtin_amdgcn_readfirstlane(((c_lo + ch) % cpb) * KT);
     const uintptr_t xp = (uintptr_t)(a.x + (size_t)b * a.Lin * a.Cin), dp = (uintptr_t)(a.dy + (size_t)b * a.M * a.Cout);
     // (unsigned halves: readfirstlane returns int, and a sign-extended low half would corrupt the high one)
     const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xp), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xp >> 32));

@@ -1,53 +1,56 @@
 #!/usr/bin/env python
-"""Micro-benchmark of the MFMA convolution kernels on one layer shape (default: the dominant generator layer
-Conv1D(512 -> 1024, k5, same) on (B, 2048, 512)); prints achieved TFLOP/s from HIP events.  Used under rocprofv3 --pmc.
-
-  python scripts/conv_microbench.py [--B 64] [--L 2048] [--cin 512] [--cout 1024] [--stride 1] [--padding same] [--iters 10] [--what fwd|dgrad|wgrad|all]
-"""
-import argparse
+"""Time single conv launches (forward, data gradient, weight gradient) at given shapes: us per launch and TFLOP/s.  The kernel-selection
+switches of csrc/conv_pipe.hip are read once per process from the environment (GN_CONV_NONARROW, GN_CONV_NARROW_BELOW, GN_CONV_NARROW_BLOCKS),
+so run the script once per setting.
+  python scripts/conv_microbench.py                       # the MFMA layers of the three nets at batch 8, n_pix 1024
+  python scripts/conv_microbench.py B L Cin Cout k stride  # one shape"""
 import os
 import sys
+import time
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gennet_amd import ops  # noqa: E402
+from gennet_amd.engine import device  # noqa: E402
+
+# (name, B, L, Cin, Cout, k, stride, pad_left, Lout) at batch 8, n_pix 1024
+SHAPES = [
+    ('G conv 128->256', 8, 1024, 128, 256, 5, 1, 2, 1024), ('G conv 256->512', 8, 1024, 256, 512, 5, 1, 2, 1024), ('G conv 512->1024', 8, 1024, 512, 1024, 5, 1, 2, 1024),
+    ('D conv2 folded (2B)', 16, 512, 512, 1024, 5, 2, 1, 256), ('PE q 128->256', 8, 1020, 128, 256, 5, 1, 0, 1016), ('PE q 256->512 s2', 8, 1016, 256, 512, 5, 2, 0, 506),
+    ('PE q 512->1024 s2', 8, 506, 512, 1024, 5, 2, 0, 251), ('PE mc 256->512 s2', 8, 125, 256, 512, 5, 2, 0, 61),
+]
+
+
+def timeit(fn, reps=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--B', type=int, default=64)
-    ap.add_argument('--L', type=int, default=2048)
-    ap.add_argument('--cin', type=int, default=512)
-    ap.add_argument('--cout', type=int, default=1024)
-    ap.add_argument('--stride', type=int, default=1)
-    ap.add_argument('--padding', default='same')
-    ap.add_argument('--iters', type=int, default=10)
-    ap.add_argument('--what', default='all')
-    a = ap.parse_args()
-    from gennet_amd import ops
-    dev = torch.device('cuda:0')
-    x = torch.randn(a.B, a.L, a.cin, device=dev)
-    w = torch.randn(5, a.cin, a.cout, device=dev) * 0.02
-    b = torch.zeros(a.cout, device=dev)
-    Lout, pl = ops.conv_geometry(a.L, 5, a.stride, a.padding)
-    dy = torch.randn(a.B, Lout, a.cout, device=dev)
-    wt = ops.conv1d_transpose_w(w)
-    flop = 2.0 * a.B * Lout * 5 * a.cin * a.cout
-    runs = {'fwd': lambda: ops.conv1d_fwd(x, w, b, a.stride, pl, Lout, 'relu'),
-            'dgrad': lambda: ops.conv1d_dgrad(dy, wt, a.L, a.stride, pl),
-            'wgrad': lambda: ops.conv1d_wgrad(x, dy, 5, a.stride, pl)}
-    for name, fn in runs.items():
-        if a.what not in ('all', name):
-            continue
-        fn(); fn()
-        torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.iters):
-            fn()
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / a.iters
-        print('%-6s B=%d L=%d %d->%d s=%d: %.3f ms  %.1f TFLOP/s' % (name, a.B, a.L, a.cin, a.cout, a.stride, ms, flop / ms / 1e9), flush=True)
+    shapes = SHAPES
+    if len(sys.argv) == 7:
+        B, L, Cin, Cout, k, s = [int(v) for v in sys.argv[1:]]
+        shapes = [('arg', B, L, Cin, Cout, k, s, 0, (L - k) // s + 1)]
+    dev = device()
+    print('%-24s %10s %10s %10s   (us per launch | TFLOP/s)' % ('layer', 'fwd', 'dgrad', 'wgrad'))
+    for name, B, L, Cin, Cout, k, stride, pl, Lout in shapes:
+        x = ops.fill_normal((B, L, Cin), 0.0, 1.0, 1, 0, dev)
+        w = ops.fill_uniform((k, Cin, Cout), -0.05, 0.05, 2, 0, dev)
+        b = torch.zeros(Cout, device=dev)
+        y = ops.conv1d_fwd(x, w, b, stride, pl, Lout)
+        wt = ops.conv1d_transpose_w(w)
+        flop = 2.0 * B * Lout * k * Cin * Cout
+        tf = timeit(lambda: ops.conv1d_fwd(x, w, b, stride, pl, Lout, 'relu'))
+        td = timeit(lambda: ops.conv1d_dgrad(y, wt, L, stride, pl))
+        tw = timeit(lambda: ops.conv1d_wgrad(x, y, k, stride, pl))
+        print('%-24s %5.0f|%5.1f %5.0f|%5.1f %5.0f|%5.1f' % (name, tf * 1e6, flop / tf / 1e12, td * 1e6, flop / td / 1e12, tw * 1e6, flop / tw / 1e12), flush=True)
 
 
 if __name__ == '__main__':
