@@ -453,8 +453,8 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
   // 64 x 64 with 1) 2.31 / 5.36 -- more CUs but the same number of SIMDs; narrow WAVES (64 x 32) in the unchanged block tile 2.30 / 4.89 --
   // more waves on the same CUs; narrow waves with 16-channel chunks 3.06 / 6.34.
   // What fills the chip is both at once: NARROW waves (64 x 32 each, pipe_group_n) in SMALLER blocks of 64 columns -- 8, 4 or 2 waves for 256,
-  // 128 or 64 rows -- so that a launch with fewer than two 64 x 64 wave tiles per SIMD gets at least two blocks per CU where it can, and
-  // every block still spreads over the CU's SIMDs.
+  // 128 or 64 rows -- so that a launch with fewer than two 64 x 64 wave tiles per SIMD gets at least one block per CU (256 blocks: 1.62 /
+  // 4.28; requiring two, 512 blocks, 1.71 / 4.54; 128 blocks 1.78 / 4.67), and every block still spreads over the CU's SIMDs.
   static const bool no_narrow = getenv("GN_CONV_NONARROW") != nullptr;          // A/B switch
   static const int narrow_below = getenv("GN_CONV_NARROW_BELOW") ? atoi(getenv("GN_CONV_NARROW_BELOW")) : 2048;
   const size_t wave_tiles = (size_t)a.B * (size_t)((a.M + 63) / 64) * (size_t)(a.Cout / 64);
