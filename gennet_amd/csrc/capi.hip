@@ -297,6 +297,27 @@ static int dgrad_impl(const float* dy, const float* wt, float* dx, int B, int L,
   if (B == 0) return GN_OK;
   // dx[b, tau, ci] = sum_{k', co} dy[b, t, co] * wt[k', co, ci]  with  stride*t + k' - pad_left == tau.
   // Output phase p = tau mod stride uses the taps with (p + pad_left - k') divisible by stride, at dy row m + (p+pad_left-k')/stride.
+  if (stride == 2 && k == 5 && L >= 2 && Cin > 4 && Cout > 4 && g_conv_math == 0) {
+    // both output phases in one launch where the pipelined kernel takes it (conv_pipe_try_merged): tap kk belongs to phase (kk + pad_left) & 1
+    ConvArgs a = {};
+    a.x = dy; a.w = wt; a.bias = nullptr; a.y = dx;
+    a.B = B; a.Lin = Lout; a.Cin = Cout; a.Cout = Cin;
+    a.M = (L + 1) / 2; a.Ly = L;
+    a.t.in_stride = 1; a.t.out_stride = 2; a.t.ntaps = 5;
+    for (int kk = 0; kk < 5; ++kk) {
+      const int p = (kk + pad_left) & 1;
+      const int d = p + pad_left - kk;                       // even by construction
+      a.t.off[kk] = (d >= 0) ? d / 2 : -((-d) / 2);
+      a.t.widx[kk] = kk;
+    }
+    a.t.out_off = pad_left & 1;                              // phase of the even taps (kk = 0, 2, 4)
+    a.t.out_off_odd = 1 - (pad_left & 1);
+    a.act = GN_ACT_LINEAR;
+    a.gy = gy; a.gmask = gmask; a.gact = gact; a.gparam = gparam; a.gscale = 1.0f / (1.0f - grate);
+    bool launched = false;
+    int rc = conv_pipe_try_merged(a, (hipStream_t)stream, &launched);
+    if (rc || launched) return rc;
+  }
   for (int p = 0; p < stride; ++p) {
     if (p >= L) break;
     ConvArgs a = {};

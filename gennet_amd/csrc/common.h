@@ -29,6 +29,9 @@ struct ConvTaps {
   int off[8];
   int widx[8];
   int out_stride, out_off;
+  // merged two-phase launch (stride-2 data gradient, conv_pipe_try_merged): taps with even index j accumulate the output rows
+  // out_stride*m + out_off, taps with odd j the rows out_stride*m + out_off_odd
+  int out_off_odd;
 };
 
 struct ConvArgs {
@@ -117,6 +120,7 @@ size_t wgrad_workspace_bytes(int B, int M, int Cin, int Cout, int ntaps);
 int wgrad_mfma_dispatch(WgradArgs& a, float* dw, size_t ws_bytes, hipStream_t s);
 // conv_pipe.hip / wgrad_pipe.hip (hand-scheduled variants selected by the two dispatchers above)
 int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched);
+int conv_pipe_try_merged(const ConvArgs& a, hipStream_t s, bool* launched);
 void wgrad_pipe_launch(const WgradArgs& a, dim3 grid, bool narrow, hipStream_t s);
 // conv_bf16x3.hip (experimental bf16 x 3 operand-split convolution, opt-in)
 size_t conv_bf16x3_workspace_bytes(int B, int Lin, int Cin, int Cout, int w_taps);

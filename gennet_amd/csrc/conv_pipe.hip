@@ -139,6 +139,26 @@ struct PipeChunk {
     pipe_first_n<oa(0), oa(0) + 32 * KC * 4, ob(0)>(s0[0], s0[1], s0[2], addr_a[0], addr_b);
     run_n<0>(acc, s0, s1, addr_a, addr_b);
   }
+  // merged two-phase launch: taps with even index feed accumulator set A, taps with odd index set B (both narrow, [2][1])
+  template <int G>
+  static __device__ __forceinline__ void run_m(f32x16 (&accA)[2][1], f32x16 (&accB)[2][1], float (&s0)[3], float (&s1)[3], const unsigned (&addr_a)[NTAPS],
+                                               unsigned addr_b) {
+    float(&cur)[3] = (G & 1) ? s1 : s0;
+    float(&nxt)[3] = (G & 1) ? s0 : s1;
+    constexpr bool odd_tap = ((G / (KC / 2)) & 1) != 0;
+    f32x16(&acc)[2][1] = odd_tap ? accB : accA;
+    if constexpr (G + 1 < SLOTS) {
+      pipe_group_n<oa(G + 1), oa(G + 1) + 32 * KC * 4, ob(G + 1)>(acc[0][0], acc[1][0], cur[0], cur[1], cur[2], nxt[0], nxt[1], nxt[2], addr_a[(G + 1) / (KC / 2)], addr_b);
+      run_m<G + 1>(accA, accB, s0, s1, addr_a, addr_b);
+    } else {
+      pipe_last_n(acc[0][0], acc[1][0], cur[0], cur[1], cur[2]);
+    }
+  }
+  static __device__ __forceinline__ void chunk_m(f32x16 (&accA)[2][1], f32x16 (&accB)[2][1], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
+    float s0[3], s1[3];
+    pipe_first_n<oa(0), oa(0) + 32 * KC * 4, ob(0)>(s0[0], s0[1], s0[2], addr_a[0], addr_b);
+    run_m<0>(accA, accB, s0, s1, addr_a, addr_b);
+  }
 };
 
 // Epilogue of the pipelined kernel.  The activation kind and the fused variants are dispatched ONCE per wave (template parameters), so
@@ -150,7 +170,7 @@ struct PipeChunk {
 // MODE 0: y = act(acc + bias);  MODE 1: ... then the fused Dropout keep-mask;  MODE 2: data gradient times the producer's act'(gy);
 // MODE 3: MODE 2 through the producer's dropout.
 template <int ACT, int MODE, int GACT, int WN>
-__device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&acc)[2][WN], int b, int m_base, int n_base, int i32, int h) {
+__device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&acc)[2][WN], int b, int m_base, int n_base, int i32, int h, int out_off) {
   const uintptr_t yp = (uintptr_t)(a.y + (size_t)b * a.Ly * a.Cout);
   const unsigned ylo = __builtin_amdgcn_readfirstlane((unsigned)yp), yhi = __builtin_amdgcn_readfirstlane((unsigned)(yp >> 32));
   const int ybytes = __builtin_amdgcn_readfirstlane(a.Ly * a.Cout * 4);
@@ -172,7 +192,7 @@ __device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&
   for (int nt = 0; nt < WN; ++nt) {
     const int n = n_base + nt * 32 + i32;
     const float bias = a.bias ? a.bias[n] : 0.f;
-    const int voff = rowstride * (4 * h) + a.t.out_off * a.Cout + n;               // element offset of (row 4h, column n)
+    const int voff = rowstride * (4 * h) + out_off * a.Cout + n;                   // element offset of (row 4h, column n)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -204,14 +224,45 @@ __device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&
   }
 }
 
-template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8, int WN = 2>
+// uniform dispatch, decided once per wave; every case is straight-line code.  Specialised: the forms the three networks run (forward
+// linear / relu / LeakyReLU / tanh, LeakyReLU + dropout, data gradient through relu, through LeakyReLU + dropout); the rest take the
+// variants that decide the activation per element.
+template <int WN>
+__device__ __forceinline__ void pipe_epilogue_dispatch(const ConvArgs& a, const f32x16 (&acc)[2][WN], int b, int m_base, int n_base, int i32, int h, int out_off,
+                                                       int mode) {
+#define GN_EPI(A_, M_, G_) pipe_epilogue<A_, M_, G_, WN>(a, acc, b, m_base, n_base, i32, h, out_off)
+  if (mode == 0) {
+    switch (a.act) {
+      case GN_ACT_LINEAR: GN_EPI(GN_ACT_LINEAR, 0, -1); break;
+      case GN_ACT_RELU: GN_EPI(GN_ACT_RELU, 0, -1); break;
+      case GN_ACT_LEAKY: GN_EPI(GN_ACT_LEAKY, 0, -1); break;
+      case GN_ACT_TANH: GN_EPI(GN_ACT_TANH, 0, -1); break;
+      default: GN_EPI(-1, 0, -1); break;
+    }
+  } else if (mode == 1) {
+    if (a.act == GN_ACT_LEAKY) GN_EPI(GN_ACT_LEAKY, 1, -1);
+    else GN_EPI(-1, 1, -1);
+  } else if (mode == 2) {
+    if (a.act == GN_ACT_LINEAR && a.gact == GN_ACT_RELU) GN_EPI(GN_ACT_LINEAR, 2, GN_ACT_RELU);
+    else GN_EPI(-1, 2, -1);
+  } else {
+    if (a.act == GN_ACT_LINEAR && a.gact == GN_ACT_LEAKY) GN_EPI(GN_ACT_LINEAR, 3, GN_ACT_LEAKY);
+    else GN_EPI(-1, 3, -1);
+  }
+#undef GN_EPI
+}
+
+// SPAN = consecutive input rows the taps cover (= NTAPS, except in the merged two-phase launch where five taps cover three rows);
+// MERGE: taps of even / odd index accumulate two output phases (accumulator sets A / B; narrow waves only).
+template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8, int WN = 2, int SPAN = NTAPS, bool MERGE = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 256 ? 1 : 2)) void conv_mfma_pipe_kernel(ConvArgs a, int m_tiles, int n_tiles, int patch) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(!MERGE || WN == 1, "the merged launch runs on narrow waves");
   constexpr int WM = 2;
   constexpr int TM = WAVES_M * WM * 32;
   constexpr int TN = WAVES_N * WN * 32;
   constexpr int NT = 64 * WAVES_M * WAVES_N;
-  constexpr int R = IS * (TM - 1) + NTAPS;                 // staged input rows: the launcher checks that the taps are consecutive
+  constexpr int R = IS * (TM - 1) + SPAN;                  // staged input rows: the launcher checks that the taps are consecutive
   constexpr int RPER = (R + IS - 1) / IS;
   constexpr int SLAB = IS * RPER * KC;                     // floats
   constexpr int BUF = SLAB + NTAPS * KC * TN;
@@ -250,12 +301,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
   for (int j = 1; j < NTAPS; ++j) minoff = min(minoff, a.t.off[j]);
 
   f32x16 acc[WM][WN];
+  f32x16 accB[WM][MERGE ? 1 : 0 + 1];                      // second accumulator set of the merged launch (unused, and optimised away, otherwise)
 #pragma unroll
   for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  if constexpr (MERGE) {
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accB[mt][0][r] = 0.f;
+  }
 
   const int t_base = IS * m0 + minoff;
   // descriptor inputs made PROVABLY wave-uniform (pointer halves and byte count through readfirstlane): otherwise hipcc wraps every
@@ -315,43 +373,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
 
   for (int ch = 0; ch < n_chunks; ch += 2) {
     dma_chunk(min(ch + 1, n_chunks - 1) * KC, smem + BUF);                        // chunk ch+1 flies during this chunk's MFMAs
-    PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::chunk(acc, addr_a, addr_b);
+    if constexpr (MERGE) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::chunk_m(acc, accB, addr_a, addr_b);
+    else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::chunk(acc, addr_a, addr_b);
     __syncthreads();
     if (ch + 1 < n_chunks) {
       dma_chunk(min(ch + 2, n_chunks - 1) * KC, smem);
-      PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::chunk(acc, addr_a, addr_b);
+      if constexpr (MERGE) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::chunk_m(acc, accB, addr_a, addr_b);
+      else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::chunk(acc, addr_a, addr_b);
       __syncthreads();
     }
   }
   // MFMA results written inside asm: the compiler inserts no wait states for its own readers of acc
   if constexpr (WN == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+  else if constexpr (MERGE) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(accB[0][0]), "+v"(accB[1][0]));
   else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]));
 
   const int m_base = m0 + __builtin_amdgcn_readfirstlane(wm) * WM * 32, n_base = n0 + wn * WN * 32;
-  // uniform dispatch, decided once; every case is straight-line code.  Specialised: the forms the three networks run (forward
-  // linear / relu / LeakyReLU / tanh, LeakyReLU + dropout, data gradient through relu, through LeakyReLU + dropout); the rest take
-  // the variants that decide the activation per element.
   const int mode = a.gy ? (a.gmask ? 3 : 2) : (a.mask ? 1 : 0);
-#define GN_EPI(A_, M_, G_) pipe_epilogue<A_, M_, G_, WN>(a, acc, b, m_base, n_base, i32, h)
-  if (mode == 0) {
-    switch (a.act) {
-      case GN_ACT_LINEAR: GN_EPI(GN_ACT_LINEAR, 0, -1); break;
-      case GN_ACT_RELU: GN_EPI(GN_ACT_RELU, 0, -1); break;
-      case GN_ACT_LEAKY: GN_EPI(GN_ACT_LEAKY, 0, -1); break;
-      case GN_ACT_TANH: GN_EPI(GN_ACT_TANH, 0, -1); break;
-      default: GN_EPI(-1, 0, -1); break;
-    }
-  } else if (mode == 1) {
-    if (a.act == GN_ACT_LEAKY) GN_EPI(GN_ACT_LEAKY, 1, -1);
-    else GN_EPI(-1, 1, -1);
-  } else if (mode == 2) {
-    if (a.act == GN_ACT_LINEAR && a.gact == GN_ACT_RELU) GN_EPI(GN_ACT_LINEAR, 2, GN_ACT_RELU);
-    else GN_EPI(-1, 2, -1);
-  } else {
-    if (a.act == GN_ACT_LINEAR && a.gact == GN_ACT_LEAKY) GN_EPI(GN_ACT_LINEAR, 3, GN_ACT_LEAKY);
-    else GN_EPI(-1, 3, -1);
-  }
-#undef GN_EPI
+  pipe_epilogue_dispatch<WN>(a, acc, b, m_base, n_base, i32, h, a.t.out_off, mode);
+  if constexpr (MERGE) pipe_epilogue_dispatch<1>(a, accB, b, m_base, n_base, i32, h, a.t.out_off_odd, mode);
 
   // BatchNorm statistics of the output on the way (the conv -> BatchNormalization layers of the generator): every lane sums its 32
   // values of each column in fp64 (rows past M excluded), the two lane halves and the waves stacked in M combine through a shuffle
@@ -392,16 +432,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
 #endif
 }
 
-template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8, int WN = 2>
+template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8, int WN = 2, int SPAN = NTAPS, bool MERGE = false>
 static int launch_conv_pipe(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WAVES_M * 64, TN = WAVES_N * WN * 32;
-  constexpr int R = IS * (TM - 1) + NTAPS, RPER = (R + IS - 1) / IS;
+  constexpr int R = IS * (TM - 1) + SPAN, RPER = (R + IS - 1) / IS;
   constexpr size_t lds = 2 * sizeof(float) * ((size_t)IS * RPER * KC + (size_t)NTAPS * KC * TN);
   static_assert(lds <= 160 * 1024, "stage too large");
   static_assert(lds / 2 + (NTAPS * KC + 8) * TN * 4 < 65536, "ds_read offsets must fit 16 bits");
   if (lds > 64 * 1024) {
     static unsigned long long lds_done = 0;
-    allow_big_lds((const void*)conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS, KC, WN>, &lds_done);
+    allow_big_lds((const void*)conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS, KC, WN, SPAN, MERGE>, &lds_done);
   }
   const int m_tiles = (a.M + TM - 1) / TM, n_tiles = a.Cout / TN;
   const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
@@ -417,7 +457,7 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t s) {
     if (!no_patch && pn >= 0 && ng <= 8 && (ng & (ng - 1)) == 0) patch = __builtin_ctz(ng) | (pn << 8);
   }
   prof_begin(s);
-  hipLaunchKernelGGL((conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS, KC, WN>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles,
+  hipLaunchKernelGGL((conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS, KC, WN, SPAN, MERGE>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles,
                      patch);
   prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0, 4.0 * ((double)a.B * a.Lin * a.Cin + (double)a.t.ntaps * a.Cin * a.Cout + (double)a.B * a.M * a.Cout));
   int rc = check_launch("conv_mfma_pipe");
@@ -486,6 +526,33 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
     default: GN_PIPE(5, 1);
   }
 #undef GN_PIPE
+}
+
+// Both output phases of a stride-2, 5-tap data gradient in ONE launch (round 3).  The two phases read the same three dy rows per output pair
+// (phase of tap kk alternates with kk), so the block stages the slab once and every K-chunk carries all five taps: narrow waves with two
+// accumulator sets chosen by tap parity (PipeChunk::run_m), two epilogues.  Two separate launches of 3 and 2 taps each walk every channel
+// chunk; at the script's own batch 8 that made the data gradient of a stride-2 layer twice as slow as its forward.
+// a.t: ntaps 5 in kernel-tap order (even index <-> rows out_stride*m + out_off, odd index <-> out_off_odd), offsets spanning 3 rows.
+int conv_pipe_try_merged(const ConvArgs& a, hipStream_t s, bool* launched) {
+  static const bool off = getenv("GN_CONV_NOMERGE") != nullptr;        // A/B switch
+  static const int merge_below = getenv("GN_CONV_MERGE_BELOW") ? atoi(getenv("GN_CONV_MERGE_BELOW")) : 2048;
+  *launched = false;
+  if (off || a.t.ntaps != 5 || a.t.in_stride != 1 || a.t.out_stride != 2 || a.stat_part || a.mask || a.bias) return GN_OK;
+  int minoff = a.t.off[0], maxoff = a.t.off[0];
+  for (int j = 1; j < 5; ++j) {
+    minoff = std::min(minoff, a.t.off[j]);
+    maxoff = std::max(maxoff, a.t.off[j]);
+  }
+  if (maxoff - minoff + 1 > 3 || a.Cin % 8 || a.Cout % 64 || (size_t)a.Ly * a.Cout * 4 >= 0x40000000ull || (size_t)a.Lin * a.Cin * 4 >= 0x40000000ull) return GN_OK;
+  const size_t wave_tiles = (size_t)a.B * (size_t)((a.M + 63) / 64) * (size_t)(a.Cout / 64) * 2;       // 64 x 64 tiles of both phases
+  if (wave_tiles >= (size_t)merge_below) return GN_OK;
+  auto blocks_of = [&](int wm_) { return (size_t)a.B * (size_t)((a.M + 64 * wm_ - 1) / (64 * wm_)) * (size_t)(a.Cout / 64); };
+  int nwm = 4;
+  while (nwm > 1 && blocks_of(nwm) < 256) nwm >>= 1;
+  *launched = true;
+  if (nwm == 4) return launch_conv_pipe<4, 2, 5, 1, 8, 1, 3, true>(a, s);
+  if (nwm == 2) return launch_conv_pipe<2, 2, 5, 1, 8, 1, 3, true>(a, s);
+  return launch_conv_pipe<1, 2, 5, 1, 8, 1, 3, true>(a, s);
 }
 
 }  // namespace gn
