@@ -236,12 +236,17 @@ class StepGraph(object):
         self.graph = torch.cuda.CUDAGraph()
         _CAPTURE = self
         ops.set_rng_base(base.ptr)
+        prof = ops.prof_enabled()          # the launch-stream HIP events of the profiling hooks must not be recorded into the graph
+        if prof:
+            ops.prof_enable(False)
         try:
             with torch.cuda.graph(self.graph):
                 self.outputs = fn()
         finally:
             ops.set_rng_base(None)
             _CAPTURE = None
+            if prof:
+                ops.prof_enable(True)
         self.rng_taken = rng.offset - self.rng_start
         rng.offset = self.rng_start
         return self.outputs

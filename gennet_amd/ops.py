@@ -542,8 +542,17 @@ def set_rng_base(ptr):
 
 
 # ---------------------------------------------------------------------------------------------- profiling hooks
+_PROF_ON = False
+
+
 def prof_enable(on=True):
+    global _PROF_ON
+    _PROF_ON = bool(on)
     _lib.call('gn_prof_enable', 1 if on else 0)
+
+
+def prof_enabled():
+    return _PROF_ON
 
 
 def prof_reset():

@@ -80,3 +80,22 @@ def test_two_graphs_share_the_device_random_stream():
     for _ in range(4):
         got.append(pe()); got.append(gan())
     assert got == eager
+
+
+def test_capture_while_the_launch_profiler_is_on():
+    """bench.py switches the HIP-event launch profiler on around its timed region; a graph captured inside that region (--warmup < 2) must not
+    record those events: StepGraph.capture suspends the profiler, and the replayed losses still equal the eager ones."""
+    from gennet_amd import bbh, ops
+    n_pix, B = 128, 4
+    nets, bank, _ = _setup(n_pix, 11)
+    eager = [bbh.pe_train_step(nets.signal_pe, bank, B) for _ in range(4)]
+    nets, bank, _ = _setup(n_pix, 11)
+    step = bbh.GraphedPEStep(nets.signal_pe, bank, B)
+    ops.prof_enable(True); ops.prof_reset()
+    try:
+        got = [step() for _ in range(4)]
+        assert ops.prof_enabled()
+    finally:
+        ops.prof_enable(False)
+    assert got == eager
+    assert ops.prof_collect(0)['launches'] > 0          # the eager first call was profiled; the capture was not (it would have failed)
