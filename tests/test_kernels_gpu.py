@@ -56,6 +56,16 @@ CONV_CASES = [
     (3, 66, 32, 64, 4, 2, 'same'),        # 4 taps, stride 2
     (9, 2100, 16, 512, 5, 1, 'same'),     # 648 blocks of the tall tile: 512 in XCD patch order (8 slabs x 8 column tiles) + a plain-order tail
     (20, 1100, 16, 512, 3, 1, 'same'),    # 720 blocks of the square tile, 4 column tiles: 16 x 4 patches + tail
+    # round 3: the narrow-wave forms for launches with fewer than two wave tiles per SIMD (conv_pipe_try), every block height
+    (8, 512, 16, 1024, 5, 1, 'same'),     # forward: 256 blocks of 8 narrow waves (256 x 64); data gradient (Cout 16) on the plain path
+    (8, 250, 16, 1024, 5, 1, 'same'),     # forward: 128 x 64 blocks of 4 narrow waves, ragged rows (250 = 128 + 122)
+    (8, 1000, 16, 512, 5, 2, 'valid'),    # stride-2 forward on narrow waves (M = 498)
+    (8, 513, 1024, 16, 5, 2, 'same'),     # data gradient merged over both phases, odd length (257 output pairs, the last without its odd row),
+                                          # 256-row blocks of 8 narrow waves with two accumulator sets; 'same' padding: even taps -> odd rows
+    (7, 700, 1024, 16, 5, 2, 'valid'),    # ... 128-row blocks, 'valid' padding: even taps -> even rows
+    (2, 131, 128, 24, 5, 2, 'same'),      # ... 64-row blocks, ragged rows
+    (3, 700, 64, 128, 5, 1, 'same'),      # weight gradient K-splits INSIDE batch elements (14 ranges of 5 chunks over 3 x 22 chunks, ragged last chunk)
+    (5, 333, 64, 64, 5, 2, 'valid'),      # ... stride 2
 ]
 
 
