@@ -154,6 +154,30 @@ struct PipeChunk {
       pipe_last_n(acc[0][0], acc[1][0], cur[0], cur[1], cur[2]);
     }
   }
+  // phase-split form of the merged launch: a wave owns ONE output phase and runs only the taps of its parity PAR (3 or 2 of the 5); the
+  // I-th group of the subset is group G(I) of the full numbering
+  template <int PAR>
+  static constexpr int gsub(int i) { return (2 * (i / (KC / 2)) + PAR) * (KC / 2) + i % (KC / 2); }
+  template <int PAR, int I>
+  static __device__ __forceinline__ void run_p(f32x16 (&acc)[2][1], float (&s0)[3], float (&s1)[3], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
+    constexpr int NSUB = ((NTAPS + 1 - PAR) / 2) * (KC / 2);
+    float(&cur)[3] = (I & 1) ? s1 : s0;
+    float(&nxt)[3] = (I & 1) ? s0 : s1;
+    if constexpr (I + 1 < NSUB) {
+      constexpr int G1 = gsub<PAR>(I + 1);
+      pipe_group_n<oa(G1), oa(G1) + 32 * KC * 4, ob(G1)>(acc[0][0], acc[1][0], cur[0], cur[1], cur[2], nxt[0], nxt[1], nxt[2], addr_a[G1 / (KC / 2)], addr_b);
+      run_p<PAR, I + 1>(acc, s0, s1, addr_a, addr_b);
+    } else {
+      pipe_last_n(acc[0][0], acc[1][0], cur[0], cur[1], cur[2]);
+    }
+  }
+  template <int PAR>
+  static __device__ __forceinline__ void chunk_p(f32x16 (&acc)[2][1], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
+    float s0[3], s1[3];
+    constexpr int G0 = gsub<PAR>(0);
+    pipe_first_n<oa(G0), oa(G0) + 32 * KC * 4, ob(G0)>(s0[0], s0[1], s0[2], addr_a[G0 / (KC / 2)], addr_b);
+    run_p<PAR, 0>(acc, s0, s1, addr_a, addr_b);
+  }
   static __device__ __forceinline__ void chunk_m(f32x16 (&accA)[2][1], f32x16 (&accB)[2][1], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
     float s0[3], s1[3];
     pipe_first_n<oa(0), oa(0) + 32 * KC * 4, ob(0)>(s0[0], s0[1], s0[2], addr_a[0], addr_b);
@@ -253,15 +277,16 @@ __device__ __forceinline__ void pipe_epilogue_dispatch(const ConvArgs& a, const 
 }
 
 // SPAN = consecutive input rows the taps cover (= NTAPS, except in the merged two-phase launch where five taps cover three rows);
-// MERGE: taps of even / odd index accumulate two output phases (accumulator sets A / B; narrow waves only).
-template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8, int WN = 2, int SPAN = NTAPS, bool MERGE = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 256 ? 1 : 2)) void conv_mfma_pipe_kernel(ConvArgs a, int m_tiles, int n_tiles, int patch) {
+// MERGE (narrow waves only): taps of even / odd index accumulate two output phases.  1: every wave keeps two accumulator sets (A / B) and runs
+// all five taps; 2: twice the waves, each owning ONE phase and running only the taps of its parity.
+template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8, int WN = 2, int SPAN = NTAPS, int MERGE = 0>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * (MERGE == 2 ? 2 : 1), (64 * WAVES_M * WAVES_N * (MERGE == 2 ? 2 : 1) > 256 ? 1 : 2)) void conv_mfma_pipe_kernel(ConvArgs a, int m_tiles, int n_tiles, int patch) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(!MERGE || WN == 1, "the merged launch runs on narrow waves");
   constexpr int WM = 2;
   constexpr int TM = WAVES_M * WM * 32;
   constexpr int TN = WAVES_N * WN * 32;
-  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int NT = 64 * WAVES_M * WAVES_N * (MERGE == 2 ? 2 : 1);
   constexpr int R = IS * (TM - 1) + SPAN;                  // staged input rows: the launcher checks that the taps are consecutive
   constexpr int RPER = (R + IS - 1) / IS;
   constexpr int SLAB = IS * RPER * KC;                     // floats
@@ -271,7 +296,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+  const int ph = MERGE == 2 ? wave_all / (WAVES_M * WAVES_N) : 0;              // phase-split merged launch: the wave's output phase
+  const int wave = MERGE == 2 ? wave_all % (WAVES_M * WAVES_N) : wave_all;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int i32 = lane & 31, h = lane >> 5;
   // block -> tile.  Plain order is (slab, column tile) with the column tile fastest: block i runs on XCD i mod 8, so every XCD meets
@@ -301,14 +328,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
   for (int j = 1; j < NTAPS; ++j) minoff = min(minoff, a.t.off[j]);
 
   f32x16 acc[WM][WN];
-  f32x16 accB[WM][MERGE ? 1 : 0 + 1];                      // second accumulator set of the merged launch (unused, and optimised away, otherwise)
+  f32x16 accB[WM][1];                      // second accumulator set of the merged launch (unused, and optimised away, otherwise)
 #pragma unroll
   for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-  if constexpr (MERGE) {
+  if constexpr (MERGE == 1) {
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
@@ -373,25 +400,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
 
   for (int ch = 0; ch < n_chunks; ch += 2) {
     dma_chunk(min(ch + 1, n_chunks - 1) * KC, smem + BUF);                        // chunk ch+1 flies during this chunk's MFMAs
-    if constexpr (MERGE) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::chunk_m(acc, accB, addr_a, addr_b);
-    else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::chunk(acc, addr_a, addr_b);
+    if constexpr (MERGE == 1) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::chunk_m(acc, accB, addr_a, addr_b);
+    else if constexpr (MERGE == 2) {
+      if (ph) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::template chunk_p<1>(acc, addr_a, addr_b);
+      else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::template chunk_p<0>(acc, addr_a, addr_b);
+    } else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::chunk(acc, addr_a, addr_b);
     __syncthreads();
     if (ch + 1 < n_chunks) {
       dma_chunk(min(ch + 2, n_chunks - 1) * KC, smem);
-      if constexpr (MERGE) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::chunk_m(acc, accB, addr_a, addr_b);
-      else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::chunk(acc, addr_a, addr_b);
+      if constexpr (MERGE == 1) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::chunk_m(acc, accB, addr_a, addr_b);
+      else if constexpr (MERGE == 2) {
+        if (ph) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::template chunk_p<1>(acc, addr_a, addr_b);
+        else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::template chunk_p<0>(acc, addr_a, addr_b);
+      } else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::chunk(acc, addr_a, addr_b);
       __syncthreads();
     }
   }
   // MFMA results written inside asm: the compiler inserts no wait states for its own readers of acc
   if constexpr (WN == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
-  else if constexpr (MERGE) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(accB[0][0]), "+v"(accB[1][0]));
+  else if constexpr (MERGE == 1) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(accB[0][0]), "+v"(accB[1][0]));
   else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]));
 
   const int m_base = m0 + __builtin_amdgcn_readfirstlane(wm) * WM * 32, n_base = n0 + wn * WN * 32;
   const int mode = a.gy ? (a.gmask ? 3 : 2) : (a.mask ? 1 : 0);
-  pipe_epilogue_dispatch<WN>(a, acc, b, m_base, n_base, i32, h, a.t.out_off, mode);
-  if constexpr (MERGE) pipe_epilogue_dispatch<1>(a, accB, b, m_base, n_base, i32, h, a.t.out_off_odd, mode);
+  pipe_epilogue_dispatch<WN>(a, acc, b, m_base, n_base, i32, h, (MERGE == 2 && ph) ? a.t.out_off_odd : a.t.out_off, mode);
+  if constexpr (MERGE == 1) pipe_epilogue_dispatch<1>(a, accB, b, m_base, n_base, i32, h, a.t.out_off_odd, mode);
 
   // BatchNorm statistics of the output on the way (the conv -> BatchNormalization layers of the generator): every lane sums its 32
   // values of each column in fp64 (rows past M excluded), the two lane halves and the waves stacked in M combine through a shuffle
@@ -432,7 +465,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
 #endif
 }
 
-template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8, int WN = 2, int SPAN = NTAPS, bool MERGE = false>
+template <int WAVES_M, int WAVES_N, int NTAPS, int IS, int KC = 8, int WN = 2, int SPAN = NTAPS, int MERGE = 0>
 static int launch_conv_pipe(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WAVES_M * 64, TN = WAVES_N * WN * 32;
   constexpr int R = IS * (TM - 1) + SPAN, RPER = (R + IS - 1) / IS;
@@ -457,7 +490,7 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t s) {
     if (!no_patch && pn >= 0 && ng <= 8 && (ng & (ng - 1)) == 0) patch = __builtin_ctz(ng) | (pn << 8);
   }
   prof_begin(s);
-  hipLaunchKernelGGL((conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS, KC, WN, SPAN, MERGE>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, m_tiles, n_tiles,
+  hipLaunchKernelGGL((conv_mfma_pipe_kernel<WAVES_M, WAVES_N, NTAPS, IS, KC, WN, SPAN, MERGE>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N * (MERGE == 2 ? 2 : 1)), lds, s, a, m_tiles, n_tiles,
                      patch);
   prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 0, 4.0 * ((double)a.B * a.Lin * a.Cin + (double)a.t.ntaps * a.Cin * a.Cout + (double)a.B * a.M * a.Cout));
   int rc = check_launch("conv_mfma_pipe");
@@ -530,7 +563,7 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
 
 // Both output phases of a stride-2, 5-tap data gradient in ONE launch (round 3).  The two phases read the same three dy rows per output pair
 // (phase of tap kk alternates with kk), so the block stages the slab once and every K-chunk carries all five taps: narrow waves with two
-// accumulator sets chosen by tap parity (PipeChunk::run_m), two epilogues.  Two separate launches of 3 and 2 taps each walk every channel
+// accumulator sets chosen by tap parity (PipeChunk::run_m, two epilogues), or twice the waves with one phase each (PipeChunk::run_p).  Two separate launches of 3 and 2 taps each walk every channel
 // chunk; at the script's own batch 8 that made the data gradient of a stride-2 layer twice as slow as its forward.
 // a.t: ntaps 5 in kernel-tap order (even index <-> rows out_stride*m + out_off, odd index <-> out_off_odd), offsets spanning 3 rows.
 int conv_pipe_try_merged(const ConvArgs& a, hipStream_t s, bool* launched) {
@@ -550,9 +583,13 @@ int conv_pipe_try_merged(const ConvArgs& a, hipStream_t s, bool* launched) {
   int nwm = 4;
   while (nwm > 1 && blocks_of(nwm) < 256) nwm >>= 1;
   *launched = true;
-  if (nwm == 4) return launch_conv_pipe<4, 2, 5, 1, 8, 1, 3, true>(a, s);
-  if (nwm == 2) return launch_conv_pipe<2, 2, 5, 1, 8, 1, 3, true>(a, s);
-  return launch_conv_pipe<1, 2, 5, 1, 8, 1, 3, true>(a, s);
+  // 256-row blocks: 8 narrow waves, each both phases (two accumulator sets); smaller blocks: twice the waves, each ONE phase and only the taps
+  // of its parity -- the merged wave is a 64 x 64 x 2-phase tile, which left half the SIMDs idle at batch 8.  Measured at batch 8 (us per
+  // launch, both-phase waves -> phase-split waves): PE q 512 -> 1024 data gradient 162 -> 111 (its forward: 94), PE q 256 -> 512 84 -> 58,
+  // CNN step 1.47 -> 1.32 ms; the discriminator's 256-row launch 180 -> 186, so it keeps the two-set form.
+  if (nwm == 4) return launch_conv_pipe<4, 2, 5, 1, 8, 1, 3, 1>(a, s);
+  if (nwm == 2) return launch_conv_pipe<2, 2, 5, 1, 8, 1, 3, 2>(a, s);
+  return launch_conv_pipe<1, 2, 5, 1, 8, 1, 3, 2>(a, s);
 }
 
 }  // namespace gn
