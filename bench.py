@@ -268,6 +268,20 @@ def main():
         return (time.perf_counter() - t) / reps
     t_cnn = timed(cnn_step, 4)
     t_gan = timed(gan_step, 2)
+    # N > 1: the exchange step measured, not estimated -- one more step with every all-reduce bracketed by HIP events on the launch stream
+    coll = None
+    if dp:
+        dp.reset_counters(); dp.timing = True
+        barrier()
+        t = time.perf_counter()
+        step()
+        barrier()
+        t_coll_step = time.perf_counter() - t
+        dp.timing = False
+        coll = dp.collect()
+        coll.update(step_ms=1e3 * t_coll_step, share_of_step=(coll['ms'] * 1e-3 / t_coll_step) if coll['ms'] is not None else None,
+                    note='all-reduces of ONE step on rank 0 (flat gradient buffers of the CNN x2, D, G; SyncBN sums; loss scalars), event-bracketed on the '
+                         'launch stream; they are not overlapped with compute, so ms is their whole cost to the step (it includes waiting for the slowest rank)')
     # metric iii: rows/s of the fused synthesiser, kernel time from HIP events on the launch stream.  default: templates only (prior -> chirp ->
     # whiten -> both inverse FFTs -> arg-max -> slide -> crop, one kernel); cfg5: the launch the CNN loop makes -- the same plus gen_noise ->
     # whiten_data('td') -> crop -> add in the same workgroup.  Priced twice: fp64 VALU operations (what bounds it) and SURVEY 8d's byte figure.
@@ -296,6 +310,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'last_losses': last_losses,
+            'collectives': coll,
             'config': {'workload': ('BASELINE %s; per GPU and step: %d x CNN point-estimator train_on_batch(batch=%d) + 1 GAN iteration(batch=%d) '
                                     '(G.predict, D step on 2B, G step through frozen D); n_pix=%d; %s')
                                    % ('configs[4] (cfg5)' if wl['online'] else ('-- NOT a BASELINE config: the reference script\'s own defaults (bbhMahoGANy.py:84-89), loop bodies %s'

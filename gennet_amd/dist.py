@@ -24,11 +24,38 @@ class DataParallel(object):
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.always = always               # issue the collectives even in a one-rank group (init(allow_single=True))
+        # accounting of the exchange step: calls and bytes always; with `timing` every all-reduce is bracketed by HIP events on the launch
+        # stream (the collective itself runs on RCCL's stream, which the launch stream waits for), read by collect()
+        self.calls = 0
+        self.bytes = 0
+        self.timing = False
+        self._events = []
+
+    def reset_counters(self):
+        self.calls, self.bytes, self._events = 0, 0, []
 
     def all_reduce_sum(self, t):
         if self.world_size > 1 or self.always:
+            self.calls += 1
+            self.bytes += t.numel() * t.element_size()
+            timed = self.timing and t.is_cuda
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if timed:
+                e1.record()
+                self._events.append((e0, e1))
         return t
+
+    def collect(self):
+        """{'calls', 'bytes', 'ms'}: all-reduces since reset_counters(); ms = summed event-bracketed time on the launch stream (None unless
+        `timing` was on) -- the exchange is not overlapped with compute, so this is its whole cost to the step."""
+        ms = None
+        if self._events:
+            torch.cuda.synchronize()
+            ms = float(sum(a.elapsed_time(b) for a, b in self._events))
+        return {'calls': self.calls, 'bytes': self.bytes, 'ms': ms}
 
     def broadcast(self, t, src=0):
         if self.world_size > 1 or self.always:
