@@ -1,6 +1,7 @@
 // Hand-scheduled, software-pipelined implicit-GEMM Conv1D (forward + data gradient) for gfx950; selected by conv_mfma_dispatch.
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 #ifndef GN_STORE_AUX
 #define GN_STORE_AUX 0      // cache policy of the output stores.  2 (nt, streaming) was measured: conv +0.5 %, but the weight gradient that reads
@@ -23,21 +24,49 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // The layout is compile-time: IS (input stride) is a template parameter and the slab holds IS*(TM-1)+NTAPS rows (consecutive taps).
 // Descriptor and tile indices go through readfirstlane so that the buffer_load ... lds of the slab are not wrapped in waterfall loops.
 // ---------------------------------------------------------------------------------------------
-template <int OA0, int OA1, int OB0, int OB1>
-__device__ __forceinline__ void pipe_group(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, float a0, float a1, float b0, float b1, float& na0, float& na1,
-                                           float& nb0, float& nb1, unsigned addr_a, unsigned addr_b) {
+// LDS layout and operand reads (round 3, after `--pmc SQ_LDS_BANK_CONFLICT`: 0.78 of the kernel's LDS cycles were conflict replays).  The slab
+// holds rows of KC = 8 channels (32 B).  Read with ds_read_b32 at one dword per lane, the 32 lanes of a half-wave sit 32 B apart: 4 banks of
+// the 32 that instruction sees, 8 addresses each -- 16 LDS cycles per read instead of 2, the LDS array about half busy under 16 waves.  Now
+// every lane fetches FOUR channels of its row with one ds_read_b128 (lane half h takes channels 4h..4h+3: k-step s of a tap multiplies
+// channel s in the lower half-wave and channel 4+s in the upper one; the weight rows follow suit) and the two 16-byte granules of a row are
+// swapped in rows 8..15 mod 16, so that the 16 lanes the hardware serves per LDS cycle (rows distinct mod 16) fall on 16 distinct 16-byte
+// slots of the 256-byte bank row: conflict-free, 4 cycles per instruction, 10 input reads per chunk instead of 40.  The swap is applied by the
+// DMA (which granule a lane fetches from global memory -- the two lanes of a row still read its 32 contiguous bytes) and by the per-tap read
+// address.  Schedule per tap: the group of k-step 0 issues the next group's weight reads and then the NEXT tap's two input reads; lgkmcnt
+// retires in order, so the counted waits over a tap's four groups are 4, 4, 2, 2 (2 throughout on the last tap, which issues no input read).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int OB0, int OB1, int WAIT>
+__device__ __forceinline__ void pipe_group(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, float a0, float a1, float b0, float b1, float& nb0, float& nb1,
+                                           unsigned addr_b) {
   asm volatile(
-      "ds_read_b32 %4, %12 offset:%14\n\t"
-      "ds_read_b32 %5, %12 offset:%15\n\t"
-      "ds_read_b32 %6, %13 offset:%16\n\t"
-      "ds_read_b32 %7, %13 offset:%17\n\t"
-      "s_waitcnt lgkmcnt(4)\n\t"
+      "ds_read_b32 %4, %10 offset:%11\n\t"
+      "ds_read_b32 %5, %10 offset:%12\n\t"
+      "s_waitcnt lgkmcnt(%13)\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %6, %8, %0\n\t"
+      "v_mfma_f32_32x32x2_f32 %1, %6, %9, %1\n\t"
+      "v_mfma_f32_32x32x2_f32 %2, %7, %8, %2\n\t"
+      "v_mfma_f32_32x32x2_f32 %3, %7, %9, %3"
+      : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11), "=&v"(nb0), "=&v"(nb1)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(addr_b), "i"(OB0), "i"(OB1), "i"(WAIT)
+      : "memory");
+}
+// ... the same, and the next tap's input rows for both row tiles (issued after the weight reads)
+template <int OA0, int OA1, int OB0, int OB1, int WAIT>
+__device__ __forceinline__ void pipe_group_a(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, float a0, float a1, float b0, float b1, float& nb0, float& nb1,
+                                             f32x4& na0, f32x4& na1, unsigned addr_a, unsigned addr_b) {
+  asm volatile(
+      "ds_read_b32 %4, %13 offset:%16\n\t"
+      "ds_read_b32 %5, %13 offset:%17\n\t"
+      "ds_read_b128 %6, %12 offset:%14\n\t"
+      "ds_read_b128 %7, %12 offset:%15\n\t"
+      "s_waitcnt lgkmcnt(%18)\n\t"
       "v_mfma_f32_32x32x2_f32 %0, %8, %10, %0\n\t"
       "v_mfma_f32_32x32x2_f32 %1, %8, %11, %1\n\t"
       "v_mfma_f32_32x32x2_f32 %2, %9, %10, %2\n\t"
       "v_mfma_f32_32x32x2_f32 %3, %9, %11, %3"
-      : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11), "=&v"(na0), "=&v"(na1), "=&v"(nb0), "=&v"(nb1)
-      : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(addr_a), "v"(addr_b), "i"(OA0), "i"(OA1), "i"(OB0), "i"(OB1)
+      : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11), "=&v"(nb0), "=&v"(nb1), "=&v"(na0), "=&v"(na1)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(addr_a), "v"(addr_b), "i"(OA0), "i"(OA1), "i"(OB0), "i"(OB1), "i"(WAIT)
       : "memory");
 }
 __device__ __forceinline__ void pipe_last(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, float a0, float a1, float b0, float b1) {
@@ -52,10 +81,10 @@ __device__ __forceinline__ void pipe_last(f32x16& c00, f32x16& c01, f32x16& c10,
       : "memory");
 }
 template <int OA0, int OA1, int OB0, int OB1>
-__device__ __forceinline__ void pipe_first(float& na0, float& na1, float& nb0, float& nb1, unsigned addr_a, unsigned addr_b) {
+__device__ __forceinline__ void pipe_first(f32x4& na0, f32x4& na1, float& nb0, float& nb1, unsigned addr_a, unsigned addr_b) {
   asm volatile(
-      "ds_read_b32 %0, %4 offset:%6\n\t"
-      "ds_read_b32 %1, %4 offset:%7\n\t"
+      "ds_read_b128 %0, %4 offset:%6\n\t"
+      "ds_read_b128 %1, %4 offset:%7\n\t"
       "ds_read_b32 %2, %5 offset:%8\n\t"
       "ds_read_b32 %3, %5 offset:%9"
       : "=&v"(na0), "=&v"(na1), "=&v"(nb0), "=&v"(nb1)
@@ -63,20 +92,31 @@ __device__ __forceinline__ void pipe_first(float& na0, float& na1, float& nb0, f
       : "memory");
 }
 
-// Narrow wave tile (64 rows x 32 columns per wave: two accumulator tiles, three operand reads per two MFMAs).  Twice the waves for the same
+// Narrow wave tile (64 rows x 32 columns per wave: two accumulator tiles, one weight read per two MFMAs).  Twice the waves for the same
 // block tile -- for launches whose 64 x 64 wave tiles do not fill the chip's 1024 SIMDs (the script's own batch 8, bbhMahoGANy.py:84-89).
-template <int OA0, int OA1, int OB0>
-__device__ __forceinline__ void pipe_group_n(f32x16& c00, f32x16& c10, float a0, float a1, float b0, float& na0, float& na1, float& nb0, unsigned addr_a,
-                                             unsigned addr_b) {
+template <int OB0, int WAIT>
+__device__ __forceinline__ void pipe_group_n(f32x16& c00, f32x16& c10, float a0, float a1, float b0, float& nb0, unsigned addr_b) {
   asm volatile(
-      "ds_read_b32 %2, %8 offset:%10\n\t"
-      "ds_read_b32 %3, %8 offset:%11\n\t"
-      "ds_read_b32 %4, %9 offset:%12\n\t"
-      "s_waitcnt lgkmcnt(3)\n\t"
+      "ds_read_b32 %2, %6 offset:%7\n\t"
+      "s_waitcnt lgkmcnt(%8)\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %3, %5, %0\n\t"
+      "v_mfma_f32_32x32x2_f32 %1, %4, %5, %1"
+      : "+v"(c00), "+v"(c10), "=&v"(nb0)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(addr_b), "i"(OB0), "i"(WAIT)
+      : "memory");
+}
+template <int OA0, int OA1, int OB0, int WAIT>
+__device__ __forceinline__ void pipe_group_na(f32x16& c00, f32x16& c10, float a0, float a1, float b0, float& nb0, f32x4& na0, f32x4& na1, unsigned addr_a,
+                                              unsigned addr_b) {
+  asm volatile(
+      "ds_read_b32 %2, %9 offset:%12\n\t"
+      "ds_read_b128 %3, %8 offset:%10\n\t"
+      "ds_read_b128 %4, %8 offset:%11\n\t"
+      "s_waitcnt lgkmcnt(%13)\n\t"
       "v_mfma_f32_32x32x2_f32 %0, %5, %7, %0\n\t"
       "v_mfma_f32_32x32x2_f32 %1, %6, %7, %1"
-      : "+v"(c00), "+v"(c10), "=&v"(na0), "=&v"(na1), "=&v"(nb0)
-      : "v"(a0), "v"(a1), "v"(b0), "v"(addr_a), "v"(addr_b), "i"(OA0), "i"(OA1), "i"(OB0)
+      : "+v"(c00), "+v"(c10), "=&v"(nb0), "=&v"(na0), "=&v"(na1)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(addr_a), "v"(addr_b), "i"(OA0), "i"(OA1), "i"(OB0), "i"(WAIT)
       : "memory");
 }
 __device__ __forceinline__ void pipe_last_n(f32x16& c00, f32x16& c10, float a0, float a1, float b0) {
@@ -89,99 +129,114 @@ __device__ __forceinline__ void pipe_last_n(f32x16& c00, f32x16& c10, float a0, 
       : "memory");
 }
 template <int OA0, int OA1, int OB0>
-__device__ __forceinline__ void pipe_first_n(float& na0, float& na1, float& nb0, unsigned addr_a, unsigned addr_b) {
+__device__ __forceinline__ void pipe_first_n(f32x4& na0, f32x4& na1, float& nb0, unsigned addr_a, unsigned addr_b) {
   asm volatile(
-      "ds_read_b32 %0, %3 offset:%5\n\t"
-      "ds_read_b32 %1, %3 offset:%6\n\t"
+      "ds_read_b128 %0, %3 offset:%5\n\t"
+      "ds_read_b128 %1, %3 offset:%6\n\t"
       "ds_read_b32 %2, %4 offset:%7"
       : "=&v"(na0), "=&v"(na1), "=&v"(nb0)
       : "v"(addr_a), "v"(addr_b), "i"(OA0), "i"(OA1), "i"(OB0)
       : "memory");
 }
 
+// One K-chunk (KC = 8 channels x NTAPS taps) of a wave, on stage STAGE.  A group = one k-step (two channels: s and 4+s of the chunk) of one
+// tap: 4 MFMAs on the 64 x 64 wave tile, 2 on the narrow one.  Input operands are double-buffered per TAP (A[tap parity][row tile], four
+// k-steps per register quad), weight operands per GROUP (B[step parity][column tile]).
 template <int TN, int KC, int NTAPS, int STAGE_BYTES, int STAGE>
 struct PipeChunk {
-  static constexpr int SLOTS = NTAPS * (KC / 2);
-  static constexpr int oa(int g) { return STAGE * STAGE_BYTES + 8 * (g % (KC / 2)); }                                   // + the tap's address register
-  static constexpr int ob(int g) { return STAGE * STAGE_BYTES + ((g / (KC / 2)) * KC + 2 * (g % (KC / 2))) * TN * 4; }
-  // groups G..SLOTS-1; operand set P (= G & 1) is current, the other one receives group G+1
-  template <int G>
-  static __device__ __forceinline__ void run(f32x16 (&acc)[2][2], float (&s0)[4], float (&s1)[4], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
-    float(&cur)[4] = (G & 1) ? s1 : s0;
-    float(&nxt)[4] = (G & 1) ? s0 : s1;
-    if constexpr (G + 1 < SLOTS) {
-      pipe_group<oa(G + 1), oa(G + 1) + 32 * KC * 4, ob(G + 1), ob(G + 1) + 128>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], cur[0], cur[1], cur[2], cur[3], nxt[0], nxt[1],
-                                                                                   nxt[2], nxt[3], addr_a[(G + 1) / (KC / 2)], addr_b);
-      run<G + 1>(acc, s0, s1, addr_a, addr_b);
-    } else {
-      pipe_last(acc[0][0], acc[0][1], acc[1][0], acc[1][1], cur[0], cur[1], cur[2], cur[3]);
+  static_assert(KC == 8, "two 16-byte granules per slab row: lane half h reads channels 4h..4h+3");
+  static constexpr int SB = STAGE * STAGE_BYTES;
+  static constexpr int OA1 = 32 * KC * 4;                                                  // second row tile: 32 slab rows further
+  static constexpr int ob(int t, int s) { return SB + (t * KC + s) * TN * 4; }             // + 4h rows of the weight stage in the address register
+  // staging of the NEXT chunk (into the other stage), spread over this chunk's groups: piece K of NP goes in front of group K * GSPAN / NP,
+  // GSPAN = the first three quarters of the chunk's GTOTAL groups (the last pieces still have a quarter of the chunk to land before the barrier)
+  template <int G, int GTOTAL, int NP, int K = 0, class D>
+  static __device__ __forceinline__ void issue(D& dma) {
+    if constexpr (K < NP) {
+      constexpr int GSPAN = (GTOTAL * 3 + 3) / 4;
+      if constexpr ((K * GSPAN) / NP == G) dma(std::integral_constant<int, K>{}, std::integral_constant<int, 1 - STAGE>{});
+      issue<G, GTOTAL, NP, K + 1>(dma);
     }
   }
-  static __device__ __forceinline__ void chunk(f32x16 (&acc)[2][2], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
-    float s0[4], s1[4];
-    pipe_first<oa(0), oa(0) + 32 * KC * 4, ob(0), ob(0) + 128>(s0[0], s0[1], s0[2], s0[3], addr_a[0], addr_b);
-    run<0>(acc, s0, s1, addr_a, addr_b);
-  }
-  // narrow wave tile: acc[2][1]
-  template <int G>
-  static __device__ __forceinline__ void run_n(f32x16 (&acc)[2][1], float (&s0)[3], float (&s1)[3], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
-    float(&cur)[3] = (G & 1) ? s1 : s0;
-    float(&nxt)[3] = (G & 1) ? s0 : s1;
-    if constexpr (G + 1 < SLOTS) {
-      pipe_group_n<oa(G + 1), oa(G + 1) + 32 * KC * 4, ob(G + 1)>(acc[0][0], acc[1][0], cur[0], cur[1], cur[2], nxt[0], nxt[1], nxt[2], addr_a[(G + 1) / (KC / 2)], addr_b);
-      run_n<G + 1>(acc, s0, s1, addr_a, addr_b);
-    } else {
-      pipe_last_n(acc[0][0], acc[1][0], cur[0], cur[1], cur[2]);
+  template <int NP, int K = 0, class D>
+  static __device__ __forceinline__ void issue_all(D& dma) {
+    if constexpr (K < NP) {
+      dma(std::integral_constant<int, K>{}, std::integral_constant<int, 1 - STAGE>{});
+      issue_all<NP, K + 1>(dma);
     }
   }
-  static __device__ __forceinline__ void chunk(f32x16 (&acc)[2][1], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
-    float s0[3], s1[3];
-    pipe_first_n<oa(0), oa(0) + 32 * KC * 4, ob(0)>(s0[0], s0[1], s0[2], addr_a[0], addr_b);
-    run_n<0>(acc, s0, s1, addr_a, addr_b);
-  }
-  // merged two-phase launch: taps with even index feed accumulator set A, taps with odd index set B (both narrow, [2][1])
-  template <int G>
-  static __device__ __forceinline__ void run_m(f32x16 (&accA)[2][1], f32x16 (&accB)[2][1], float (&s0)[3], float (&s1)[3], const unsigned (&addr_a)[NTAPS],
-                                               unsigned addr_b) {
-    float(&cur)[3] = (G & 1) ? s1 : s0;
-    float(&nxt)[3] = (G & 1) ? s0 : s1;
-    constexpr bool odd_tap = ((G / (KC / 2)) & 1) != 0;
-    f32x16(&acc)[2][1] = odd_tap ? accB : accA;
-    if constexpr (G + 1 < SLOTS) {
-      pipe_group_n<oa(G + 1), oa(G + 1) + 32 * KC * 4, ob(G + 1)>(acc[0][0], acc[1][0], cur[0], cur[1], cur[2], nxt[0], nxt[1], nxt[2], addr_a[(G + 1) / (KC / 2)], addr_b);
-      run_m<G + 1>(accA, accB, s0, s1, addr_a, addr_b);
+  // ---- 64 x 64 wave tile ----
+  template <int NP, int I, int S, class D>
+  static __device__ __forceinline__ void run(f32x16 (&acc)[2][2], f32x4 (&A)[2][2], float (&B)[2][2], const unsigned (&addr_a)[NTAPS], unsigned addr_b, D& dma) {
+    issue<I * 4 + S, NTAPS * 4, NP>(dma);
+    f32x4(&ac)[2] = A[I & 1];
+    f32x4(&an)[2] = A[(I + 1) & 1];
+    float(&bc)[2] = B[S & 1];
+    float(&bn)[2] = B[(S + 1) & 1];
+    constexpr bool last_tap = I + 1 == NTAPS;
+    if constexpr (last_tap && S == 3) {
+      pipe_last(acc[0][0], acc[0][1], acc[1][0], acc[1][1], ac[0][3], ac[1][3], bc[0], bc[1]);
     } else {
-      pipe_last_n(acc[0][0], acc[1][0], cur[0], cur[1], cur[2]);
+      constexpr int NI = S == 3 ? I + 1 : I, NS = (S + 1) & 3;
+      if constexpr (S == 0 && !last_tap)
+        pipe_group_a<SB, SB + OA1, ob(NI, NS), ob(NI, NS) + 128, 4>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], ac[0][S], ac[1][S], bc[0], bc[1], bn[0], bn[1], an[0],
+                                                                     an[1], addr_a[last_tap ? I : I + 1], addr_b);
+      else
+        pipe_group<ob(NI, NS), ob(NI, NS) + 128, (S == 1 && !last_tap) ? 4 : 2>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], ac[0][S], ac[1][S], bc[0], bc[1], bn[0],
+                                                                                 bn[1], addr_b);
+      run<NP, NI, NS>(acc, A, B, addr_a, addr_b, dma);
     }
   }
-  // phase-split form of the merged launch: a wave owns ONE output phase and runs only the taps of its parity PAR (3 or 2 of the 5); the
-  // I-th group of the subset is group G(I) of the full numbering
-  template <int PAR>
-  static constexpr int gsub(int i) { return (2 * (i / (KC / 2)) + PAR) * (KC / 2) + i % (KC / 2); }
-  template <int PAR, int I>
-  static __device__ __forceinline__ void run_p(f32x16 (&acc)[2][1], float (&s0)[3], float (&s1)[3], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
-    constexpr int NSUB = ((NTAPS + 1 - PAR) / 2) * (KC / 2);
-    float(&cur)[3] = (I & 1) ? s1 : s0;
-    float(&nxt)[3] = (I & 1) ? s0 : s1;
-    if constexpr (I + 1 < NSUB) {
-      constexpr int G1 = gsub<PAR>(I + 1);
-      pipe_group_n<oa(G1), oa(G1) + 32 * KC * 4, ob(G1)>(acc[0][0], acc[1][0], cur[0], cur[1], cur[2], nxt[0], nxt[1], nxt[2], addr_a[G1 / (KC / 2)], addr_b);
-      run_p<PAR, I + 1>(acc, s0, s1, addr_a, addr_b);
+  template <int NP, class D>
+  static __device__ __forceinline__ void chunk(f32x16 (&acc)[2][2], const unsigned (&addr_a)[NTAPS], unsigned addr_b, D& dma) {
+    f32x4 A[2][2];
+    float B[2][2];
+    pipe_first<SB, SB + OA1, ob(0, 0), ob(0, 0) + 128>(A[0][0], A[0][1], B[0][0], B[0][1], addr_a[0], addr_b);
+    run<NP, 0, 0>(acc, A, B, addr_a, addr_b, dma);
+  }
+  // ---- narrow wave tile (acc[2][1]).  The taps visited are FIRST, FIRST + STEP, ... (NSEQ of them); with ALT the taps of odd index
+  // accumulate into the second set (the merged two-phase launch) ----
+  template <int NP, int FIRST, int STEP, int NSEQ, bool ALT, int I, int S, class D>
+  static __device__ __forceinline__ void run_n(f32x16 (&accA)[2][1], f32x16 (&accB)[2][1], f32x4 (&A)[2][2], float (&B)[2], const unsigned (&addr_a)[NTAPS],
+                                               unsigned addr_b, D& dma) {
+    issue<I * 4 + S, NSEQ * 4, NP>(dma);
+    constexpr int T = FIRST + I * STEP;
+    f32x16(&acc)[2][1] = (ALT && (T & 1)) ? accB : accA;
+    f32x4(&ac)[2] = A[I & 1];
+    f32x4(&an)[2] = A[(I + 1) & 1];
+    constexpr bool last_tap = I + 1 == NSEQ;
+    if constexpr (last_tap && S == 3) {
+      pipe_last_n(acc[0][0], acc[1][0], ac[0][3], ac[1][3], B[S & 1]);
     } else {
-      pipe_last_n(acc[0][0], acc[1][0], cur[0], cur[1], cur[2]);
+      constexpr int NI = S == 3 ? I + 1 : I, NS = (S + 1) & 3, NT_ = FIRST + NI * STEP;
+      if constexpr (S == 0 && !last_tap)
+        pipe_group_na<SB, SB + OA1, ob(NT_, NS), 3>(acc[0][0], acc[1][0], ac[0][S], ac[1][S], B[S & 1], B[(S + 1) & 1], an[0], an[1],
+                                                    addr_a[last_tap ? T : T + STEP], addr_b);
+      else
+        pipe_group_n<ob(NT_, NS), (S == 1 && !last_tap) ? 3 : 1>(acc[0][0], acc[1][0], ac[0][S], ac[1][S], B[S & 1], B[(S + 1) & 1], addr_b);
+      run_n<NP, FIRST, STEP, NSEQ, ALT, NI, NS>(accA, accB, A, B, addr_a, addr_b, dma);
     }
   }
-  template <int PAR>
-  static __device__ __forceinline__ void chunk_p(f32x16 (&acc)[2][1], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
-    float s0[3], s1[3];
-    constexpr int G0 = gsub<PAR>(0);
-    pipe_first_n<oa(G0), oa(G0) + 32 * KC * 4, ob(G0)>(s0[0], s0[1], s0[2], addr_a[G0 / (KC / 2)], addr_b);
-    run_p<PAR, 0>(acc, s0, s1, addr_a, addr_b);
+  template <int NP, int FIRST, int STEP, int NSEQ, bool ALT, class D>
+  static __device__ __forceinline__ void chunk_seq(f32x16 (&accA)[2][1], f32x16 (&accB)[2][1], const unsigned (&addr_a)[NTAPS], unsigned addr_b, D& dma) {
+    f32x4 A[2][2];
+    float B[2];
+    pipe_first_n<SB, SB + OA1, ob(FIRST, 0)>(A[0][0], A[0][1], B[0], addr_a[FIRST], addr_b);
+    run_n<NP, FIRST, STEP, NSEQ, ALT, 0, 0>(accA, accB, A, B, addr_a, addr_b, dma);
   }
-  static __device__ __forceinline__ void chunk_m(f32x16 (&accA)[2][1], f32x16 (&accB)[2][1], const unsigned (&addr_a)[NTAPS], unsigned addr_b) {
-    float s0[3], s1[3];
-    pipe_first_n<oa(0), oa(0) + 32 * KC * 4, ob(0)>(s0[0], s0[1], s0[2], addr_a[0], addr_b);
-    run_m<0>(accA, accB, s0, s1, addr_a, addr_b);
+  template <int NP, class D>
+  static __device__ __forceinline__ void chunk(f32x16 (&acc)[2][1], const unsigned (&addr_a)[NTAPS], unsigned addr_b, D& dma) {
+    chunk_seq<NP, 0, 1, NTAPS, false>(acc, acc, addr_a, addr_b, dma);
+  }
+  // merged two-phase launch: taps with even index feed accumulator set A, taps with odd index set B
+  template <int NP, class D>
+  static __device__ __forceinline__ void chunk_m(f32x16 (&accA)[2][1], f32x16 (&accB)[2][1], const unsigned (&addr_a)[NTAPS], unsigned addr_b, D& dma) {
+    chunk_seq<NP, 0, 1, NTAPS, true>(accA, accB, addr_a, addr_b, dma);
+  }
+  // phase-split form of the merged launch: a wave owns ONE output phase and runs only the taps of its parity PAR (3 or 2 of the 5)
+  template <int PAR, int NP, class D>
+  static __device__ __forceinline__ void chunk_p(f32x16 (&acc)[2][1], const unsigned (&addr_a)[NTAPS], unsigned addr_b, D& dma) {
+    chunk_seq<NP, PAR, 2, (NTAPS + 1 - PAR) / 2, false>(acc, acc, addr_a, addr_b, dma);
   }
 };
 
@@ -358,29 +413,46 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * (MERGE == 2 ? 2 : 1), (64 
 #pragma unroll
   for (int it = 0; it < S_ITEMS; ++it) {
     const int id = tid + it * NT;
-    const int lr = id / (KC / 4), c4 = id % (KC / 4);
+    const int lr = id / (KC / 4), c4 = (id % (KC / 4)) ^ ((lr >> 3) & 1);            // the row's two granules swapped in rows 8..15 mod 16 (PipeChunk)
     const int r = (IS == 1) ? lr : (lr < RPER ? 2 * lr : 2 * (lr - RPER) + 1);
     soff[it] = (id < S_COUNT && r < R) ? ((t_base + r) * a.Cin + 4 * c4) * 4 : 0x40000000;   // out of range -> the descriptor returns 0
   }
-  const float* wp[W_ITEMS];
+  // weights through a buffer descriptor too (round 3): a 32-bit lane offset and the chunk's offset in an SGPR instead of a 64-bit pointer per
+  // lane advanced by VALU adds every chunk -- scripts/mfma_peak.hip: six global_load_lds per chunk cost the matrix pipe 1.9 %, six
+  // buffer_load ... lds 0.9 %
+  int maxw = a.t.widx[0];
+#pragma unroll
+  for (int j = 1; j < NTAPS; ++j) maxw = max(maxw, a.t.widx[j]);
+  const uintptr_t wbp = (uintptr_t)a.w;
+  const unsigned wb_lo = __builtin_amdgcn_readfirstlane((unsigned)wbp), wb_hi = __builtin_amdgcn_readfirstlane((unsigned)(wbp >> 32));
+  const int wbytes = __builtin_amdgcn_readfirstlane((maxw + 1) * a.Cin * a.Cout * 4);
+  const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)wb_hi << 32) | wb_lo), 0, wbytes, 0x00020000);
+  int woff[W_ITEMS];
 #pragma unroll
   for (int it = 0; it < W_ITEMS; ++it) {
     const int id = min(tid + it * NT, W_TOTAL - 1);
     const int n4 = id % (TN / 4);
     const int kk = (id / (TN / 4)) % KC;
     const int j = id / ((TN / 4) * KC);
-    wp[it] = a.w + ((size_t)a.t.widx[j] * a.Cin + kk) * a.Cout + n0 + 4 * n4;
+    woff[it] = ((a.t.widx[j] * a.Cin + kk) * a.Cout + n0 + 4 * n4) * 4;
   }
-  auto dma_chunk = [&](int c0, float* stage) {
-#pragma unroll
-    for (int it = 0; it < S_ITEMS; ++it) {
-      if ((it + 1) * NT <= S_COUNT || tid + it * NT < S_COUNT)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stage + (it * NT + (tid & ~63)) * 4), 16, soff[it] + c0 * 4, 0, 0, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < W_ITEMS; ++it)
+  // One staging piece = one wave-wide 16-byte LDS-DMA of every wave of the block: pieces 0 .. S_ITEMS-1 the input slab, the rest the weight
+  // tile, of the chunk at channel c0_next, into stage STG.  The chunk loop does not issue them in one burst after the barrier but one every
+  // few MFMA groups (PipeChunk::issue): in scripts/mfma_peak.hip the burst costs the matrix pipe 0.9 % at four blocks per CU (5 % at one),
+  // the spread issue 0.1 %.
+  constexpr int NPIECES = S_ITEMS + W_ITEMS;
+  int c0_next = 0;
+  auto dma_piece = [&](auto kc, auto stg) {
+    constexpr int k = decltype(kc)::value;
+    float* stage = smem + decltype(stg)::value * BUF;
+    if constexpr (k < S_ITEMS) {
+      if ((k + 1) * NT <= S_COUNT || tid + k * NT < S_COUNT)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stage + (k * NT + (tid & ~63)) * 4), 16, soff[k], c0_next * 4, 0, 0);
+    } else {
+      constexpr int it = k - S_ITEMS;
       if ((it + 1) * NT <= W_TOTAL || (tid & ~63) + it * NT < W_TOTAL)
-        __builtin_amdgcn_global_load_lds((gptr_t)(wp[it] + (size_t)c0 * a.Cout), (lptr_t)(stage + SLAB + (it * NT + (tid & ~63)) * 4), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(stage + SLAB + (it * NT + (tid & ~63)) * 4), 16, woff[it], c0_next * a.Cout * 4, 0, 0);
+    }
   };
 
   // chunk-invariant LDS byte addresses of this lane's operands in stage 0
@@ -390,29 +462,30 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * (MERGE == 2 ? 2 : 1), (64 
   for (int j = 0; j < NTAPS; ++j) {
     const int d = a.t.off[j] - minoff;
     const int rowbase = (IS == 1) ? d : ((d & 1) * RPER + (d >> 1));
-    addr_a[j] = lds0 + ((rowbase + wm * WM * 32 + i32) * KC + h) * 4;
+    const int row = rowbase + wm * WM * 32 + i32;
+    addr_a[j] = lds0 + (row * 2 + (h ^ ((row >> 3) & 1))) * 16;                        // granule h of the row: channels 4h .. 4h+3
   }
-  const unsigned addr_b = lds0 + (SLAB + h * TN + wn * WN * 32 + i32) * 4;
+  const unsigned addr_b = lds0 + (SLAB + 4 * h * TN + wn * WN * 32 + i32) * 4;         // weight rows 4h + s of the tap, s = k-step
 
   const int n_chunks = a.Cin / KC;
-  dma_chunk(0, smem);
+  PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::template issue_all<NPIECES>(dma_piece);       // chunk 0 into stage 0, in one burst
   __syncthreads();                                         // drains the LDS-DMA (vmcnt(0)) in front of the barrier
 
   for (int ch = 0; ch < n_chunks; ch += 2) {
-    dma_chunk(min(ch + 1, n_chunks - 1) * KC, smem + BUF);                        // chunk ch+1 flies during this chunk's MFMAs
-    if constexpr (MERGE == 1) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::chunk_m(acc, accB, addr_a, addr_b);
+    c0_next = min(ch + 1, n_chunks - 1) * KC;                                     // chunk ch+1 flies during this chunk's MFMAs
+    if constexpr (MERGE == 1) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::template chunk_m<NPIECES>(acc, accB, addr_a, addr_b, dma_piece);
     else if constexpr (MERGE == 2) {
-      if (ph) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::template chunk_p<1>(acc, addr_a, addr_b);
-      else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::template chunk_p<0>(acc, addr_a, addr_b);
-    } else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::chunk(acc, addr_a, addr_b);
+      if (ph) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::template chunk_p<1, NPIECES>(acc, addr_a, addr_b, dma_piece);
+      else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::template chunk_p<0, NPIECES>(acc, addr_a, addr_b, dma_piece);
+    } else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 0>::template chunk<NPIECES>(acc, addr_a, addr_b, dma_piece);
     __syncthreads();
     if (ch + 1 < n_chunks) {
-      dma_chunk(min(ch + 2, n_chunks - 1) * KC, smem);
-      if constexpr (MERGE == 1) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::chunk_m(acc, accB, addr_a, addr_b);
+      c0_next = min(ch + 2, n_chunks - 1) * KC;
+      if constexpr (MERGE == 1) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::template chunk_m<NPIECES>(acc, accB, addr_a, addr_b, dma_piece);
       else if constexpr (MERGE == 2) {
-        if (ph) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::template chunk_p<1>(acc, addr_a, addr_b);
-        else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::template chunk_p<0>(acc, addr_a, addr_b);
-      } else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::chunk(acc, addr_a, addr_b);
+        if (ph) PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::template chunk_p<1, NPIECES>(acc, addr_a, addr_b, dma_piece);
+        else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::template chunk_p<0, NPIECES>(acc, addr_a, addr_b, dma_piece);
+      } else PipeChunk<TN, KC, NTAPS, STAGE_BYTES, 1>::template chunk<NPIECES>(acc, addr_a, addr_b, dma_piece);
       __syncthreads();
     }
   }
@@ -545,8 +618,14 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
       if (nwm == 2) return launch_conv_pipe<2, 2, NT_, IS_, 8, 1>(a, s);                     \
       return launch_conv_pipe<1, 2, NT_, IS_, 8, 1>(a, s);                                   \
     }                                                                                        \
+    if constexpr (IS_ == 2)                                                                  \
+      if (tall && wide8 && a.Cout % 128 == 0) return launch_conv_pipe<4, 2, 5, 2>(a, s);     \
     return tall ? launch_conv_pipe<4, 1, NT_, IS_>(a, s) : launch_conv_pipe<2, 2, NT_, IS_>(a, s);                       \
   } while (0)
+  // (256 x 128 blocks of 8 waves for the stride-2 forward -- 74 KiB of LDS, two blocks per CU = a fourth wave per SIMD -- measured in round 3:
+  // -2.5 to -4 % per launch in the layer sweep, nothing on the step (1420.0 / 1420.6 against 1420.8 / 1419.1 waveforms/s); the same blocks on the
+  // stride-1 5-tap launches and on the 2- / 3-tap phases LOSE 0.3 % of the step.  Opt-in.)
+  static const bool wide8 = getenv("GN_CONV_WIDE8") != nullptr;
   // (4-channel chunks for the stride-2 forward -- 27 instead of 53 KiB of LDS, a fourth block per CU, but a barrier per 40 MFMAs -- were
   // measured: 140.3 -> 135.5 TFLOP/s.  Eight channels per chunk is the optimum in both directions.)
   if (a.t.in_stride == 2) { GN_PIPE(5, 2); }
