@@ -1,6 +1,7 @@
 // Hand-scheduled, LDS-DMA weight-gradient kernel for gfx950; selected by wgrad_mfma_dispatch (conv_mfma.hip).
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 
 namespace gn {
@@ -67,22 +68,41 @@ struct WgChunk {
   static constexpr int QS = KT / 2;
   static constexpr int oa(int q, int j) { return STAGE * STAGE_BYTES + (IS * 2 * q + j) * TC * 4; }       // + lane part (h * IS rows, channel)
   static constexpr int ob(int q) { return STAGE * STAGE_BYTES + 2 * q * TN * 4; }
-  template <int Q>
-  static __device__ __forceinline__ void run(f32x16 (&acc)[5], float (&s0)[6], float (&s1)[6], unsigned addr_a, unsigned addr_b) {
+  // staging of the NEXT chunk spread over this chunk's groups, as in conv_pipe.hip (PipeChunk::issue): piece K of NP in front of group
+  // K * GSPAN / NP, GSPAN = the first three quarters of the chunk's QS groups
+  template <int G, int NP, int K = 0, class D>
+  static __device__ __forceinline__ void issue(D& dma) {
+    if constexpr (K < NP) {
+      constexpr int GSPAN = (QS * 3 + 3) / 4;
+      if constexpr ((K * GSPAN) / NP == G) dma(std::integral_constant<int, K>{}, std::integral_constant<int, 1 - STAGE>{});
+      issue<G, NP, K + 1>(dma);
+    }
+  }
+  template <int NP, int K = 0, class D>
+  static __device__ __forceinline__ void issue_all(D& dma) {
+    if constexpr (K < NP) {
+      dma(std::integral_constant<int, K>{}, std::integral_constant<int, 1 - STAGE>{});
+      issue_all<NP, K + 1>(dma);
+    }
+  }
+  template <int NP, int Q, class D>
+  static __device__ __forceinline__ void run(f32x16 (&acc)[5], float (&s0)[6], float (&s1)[6], unsigned addr_a, unsigned addr_b, D& dma) {
+    issue<Q, NP>(dma);
     float(&cur)[6] = (Q & 1) ? s1 : s0;
     float(&nxt)[6] = (Q & 1) ? s0 : s1;
     if constexpr (Q + 1 < QS) {
       wg_group<oa(Q + 1, 0), oa(Q + 1, 1), oa(Q + 1, 2), oa(Q + 1, 3), oa(Q + 1, 4), ob(Q + 1)>(acc[0], acc[1], acc[2], acc[3], acc[4], cur[0], cur[1], cur[2], cur[3], cur[4],
                                                                                                cur[5], nxt[0], nxt[1], nxt[2], nxt[3], nxt[4], nxt[5], addr_a, addr_b);
-      run<Q + 1>(acc, s0, s1, addr_a, addr_b);
+      run<NP, Q + 1>(acc, s0, s1, addr_a, addr_b, dma);
     } else {
       wg_last(acc[0], acc[1], acc[2], acc[3], acc[4], cur[0], cur[1], cur[2], cur[3], cur[4], cur[5]);
     }
   }
-  static __device__ __forceinline__ void chunk(f32x16 (&acc)[5], unsigned addr_a, unsigned addr_b) {
+  template <int NP, class D>
+  static __device__ __forceinline__ void chunk(f32x16 (&acc)[5], unsigned addr_a, unsigned addr_b, D& dma) {
     float s0[6], s1[6];
     wg_first<oa(0, 0), oa(0, 1), oa(0, 2), oa(0, 3), oa(0, 4), ob(0)>(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], addr_a, addr_b);
-    run<0>(acc, s0, s1, addr_a, addr_b);
+    run<NP, 0>(acc, s0, s1, addr_a, addr_b, dma);
   }
 };
 
@@ -162,23 +182,35 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(W
     doff[it] = (r * a.Cout + n0 + 4 * n4) * 4;
   }
   const int xbytes = __builtin_amdgcn_readfirstlane(a.Lin * a.Cin * 4), dybytes = __builtin_amdgcn_readfirstlane(a.M * a.Cout * 4);
-  auto dma_chunk = [&](int ch, float* stage) {
+  // staging of one K-chunk: dma_setup builds the chunk's descriptors and row offsets (scalar work), dma_piece issues ONE wave-wide 16-byte
+  // LDS-DMA of every wave (pieces 0 .. S_ITEMS-1 the x slab, the rest the dy tile) into stage STG.  The chunk loop spreads the pieces over the
+  // MFMA groups instead of issuing them in one burst after the barrier (scripts/mfma_peak.hip: the burst costs the matrix pipe 0.9 %, the
+  // spread issue 0.1 %).  The row offsets stay VALU adds: in an SGPR offset they would escape the descriptor's range check, which is what
+  // turns rows outside [0, Lin) and dy rows >= M into zeros.
+  constexpr int NPIECES = S_ITEMS + D_ITEMS;
+  __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0, 0x00020000), ds = xs;
+  int xrow = 0, drow = 0;
+  auto dma_setup = [&](int ch) {
     const int b = __builtin_amdgcn_readfirstlane((c_lo + ch) / cpb), m0 = __builtin_amdgcn_readfirstlane(((c_lo + ch) % cpb) * KT);
     const uintptr_t xp = (uintptr_t)(a.x + (size_t)b * a.Lin * a.Cin), dp = (uintptr_t)(a.dy + (size_t)b * a.M * a.Cout);
     // (unsigned halves: readfirstlane returns int, and a sign-extended low half would corrupt the high one)
     const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xp), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xp >> 32));
     const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)dp), dhi = __builtin_amdgcn_readfirstlane((unsigned)(dp >> 32));
-    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)xhi << 32) | xlo), 0, xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ds = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)dhi << 32) | dlo), 0, dybytes, 0x00020000);
-    const int xrow = IS * m0 * a.Cin * 4, drow = m0 * a.Cout * 4;
-#pragma unroll
-    for (int it = 0; it < S_ITEMS; ++it) {
-      if ((it + 1) * NT <= S_COUNT || tid + it * NT < S_COUNT)          // x rows before 0 give a negative (= huge unsigned) offset: out of range -> 0
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lptr_t)(stage + (it * NT + (tid & ~63)) * 4), 16, soff[it] + xrow, 0, 0, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < D_ITEMS; ++it)
+    xs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)xhi << 32) | xlo), 0, xbytes, 0x00020000);
+    ds = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)dhi << 32) | dlo), 0, dybytes, 0x00020000);
+    xrow = IS * m0 * a.Cin * 4;
+    drow = m0 * a.Cout * 4;
+  };
+  auto dma_piece = [&](auto kc, auto stg) {
+    constexpr int k = decltype(kc)::value;
+    float* stage = smem + decltype(stg)::value * BUF;
+    if constexpr (k < S_ITEMS) {
+      if ((k + 1) * NT <= S_COUNT || tid + k * NT < S_COUNT)            // x rows before 0 give a negative (= huge unsigned) offset: out of range -> 0
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lptr_t)(stage + (k * NT + (tid & ~63)) * 4), 16, soff[k] + xrow, 0, 0, 0);
+    } else {
+      constexpr int it = k - S_ITEMS;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ds, (lptr_t)(stage + SLAB + (it * NT + (tid & ~63)) * 4), 16, doff[it] + drow, 0, 0, 0);
+    }
   };
 
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
@@ -196,17 +228,20 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(W
     for (int r = 0; r < RPG; ++r) bsum += (double)col[r * TN];
   };
 
-  if (n_chunks > 0) dma_chunk(0, smem);
+  if (n_chunks > 0) {
+    dma_setup(0);
+    WgChunk<TC, TN, KT, IS, STAGE_BYTES, 1>::template issue_all<NPIECES>(dma_piece);      // chunk 0 into stage 0, in one burst
+  }
   __syncthreads();
   for (int ch = 0; ch < n_chunks; ch += 2) {
-    dma_chunk(min(ch + 1, n_chunks - 1), smem + BUF);
+    dma_setup(min(ch + 1, n_chunks - 1));
     if (do_bias) bias_chunk(smem);
-    WgChunk<TC, TN, KT, IS, STAGE_BYTES, 0>::chunk(acc, addr_a, addr_b);
+    WgChunk<TC, TN, KT, IS, STAGE_BYTES, 0>::template chunk<NPIECES>(acc, addr_a, addr_b, dma_piece);
     __syncthreads();
     if (ch + 1 < n_chunks) {
-      dma_chunk(min(ch + 2, n_chunks - 1), smem);
+      dma_setup(min(ch + 2, n_chunks - 1));
       if (do_bias) bias_chunk(smem + BUF);
-      WgChunk<TC, TN, KT, IS, STAGE_BYTES, 1>::chunk(acc, addr_a, addr_b);
+      WgChunk<TC, TN, KT, IS, STAGE_BYTES, 1>::template chunk<NPIECES>(acc, addr_a, addr_b, dma_piece);
       __syncthreads();
     }
   }
