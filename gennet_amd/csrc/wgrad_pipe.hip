@@ -4,6 +4,11 @@
 #include <type_traits>
 #include "common.h"
 
+#ifndef GN_DMA_SPAN_NUM
+#define GN_DMA_SPAN_NUM 3      // the staging pieces of a chunk are issued over the first NUM / DEN of its MFMA groups
+#define GN_DMA_SPAN_DEN 4
+#endif
+
 namespace gn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -73,7 +78,7 @@ struct WgChunk {
   template <int G, int NP, int K = 0, class D>
   static __device__ __forceinline__ void issue(D& dma) {
     if constexpr (K < NP) {
-      constexpr int GSPAN = (QS * 3 + 3) / 4;
+      constexpr int GSPAN = (QS * GN_DMA_SPAN_NUM + GN_DMA_SPAN_DEN - 1) / GN_DMA_SPAN_DEN;
       if constexpr ((K * GSPAN) / NP == G) dma(std::integral_constant<int, K>{}, std::integral_constant<int, 1 - STAGE>{});
       issue<G, NP, K + 1>(dma);
     }

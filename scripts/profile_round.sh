@@ -16,6 +16,9 @@ find gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write -name "*counter_col
 rocprofv3 --kernel-trace --pmc MfmaUtil GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${TAG}_pmc_mfma -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_pmc_mfma.log 2>&1
 python scripts/pmc_mfma_util.py gpurun_out/${TAG}_pmc_mfma gpurun_out/${TAG}_pmc_mfma_util.json > gpurun_out/${TAG}_pmc_mfma_summary.log 2>&1
 find gpurun_out/${TAG}_pmc_mfma -name "*.csv" -delete
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${TAG}_pmc_lds -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_pmc_lds.log 2>&1
+python scripts/pmc_lds.py gpurun_out/${TAG}_pmc_lds gpurun_out/${TAG}_pmc_lds.json > gpurun_out/${TAG}_pmc_lds_summary.log 2>&1
+find gpurun_out/${TAG}_pmc_lds -name "*.csv" -delete
 find gpurun_out/${TAG}_prof -name "*kernel_trace.csv" -delete
 cp gpurun_out/${TAG}_prof/*/*kernel_stats.csv gpurun_out/${TAG}_bench_kernel_stats.csv
 echo profiled
