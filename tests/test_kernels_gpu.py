@@ -468,3 +468,32 @@ def test_full_size_layers_spot_checked_against_the_definition(L, Cin, Cout, s, p
         acc = sum(x64[bb, src[ok], ci] @ dy64[bb, ts_[ok], co] for bb in range(B))
         assert abs(dw[kk, ci, co] - acc) <= 5e-5 * dws
     assert np.abs(db - dy64.sum(axis=(0, 1))).max() <= 5e-5 * np.abs(db).max()
+
+
+def test_optin_eight_wave_stride2_tile_is_bit_identical_to_the_default():
+    """GN_CONV_WIDE8 (256 x 128 blocks of eight waves for the stride-2 forward: measured, not the default -- DESIGN section 6) is read once per
+    process, so the variant runs in a child process; both kernels walk channels, taps and k-steps in the same order: bit-identical output."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from gennet_amd import ops
+    B, L, Cin, Cout, k, s = 16, 1018, 16, 1024, 5, 2                # 16 x 8 x 16 = 2048 wave tiles: the wide-wave (not the narrow) path
+    rng = np.random.RandomState(7)
+    x = rng.randn(B, L, Cin).astype(np.float32); w = (rng.randn(k, Cin, Cout) / np.sqrt(k * Cin)).astype(np.float32); b = rng.randn(Cout).astype(np.float32)
+    Lout, pl = ops.conv_geometry(L, k, s, 'valid')
+    y = ops.conv1d_fwd(g(x), g(w), g(b), s, pl, Lout).cpu().numpy()
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, 'in.npz'), x=x, w=w, b=b)
+        code = ("import numpy as np, torch\nfrom gennet_amd import ops\nd = np.load(r'%s')\nt = lambda a: torch.tensor(a, device='cuda:0')\n"
+                "y = ops.conv1d_fwd(t(d['x']), t(d['w']), t(d['b']), %d, %d, %d).cpu().numpy()\nnp.save(r'%s', y)\n"
+                % (os.path.join(td, 'in.npz'), s, pl, Lout, os.path.join(td, 'out.npy')))
+        env = dict(os.environ, GN_CONV_WIDE8='1')
+        subprocess.run([sys.executable, '-c', code], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+        y8 = np.load(os.path.join(td, 'out.npy'))
+    assert y.shape == y8.shape and np.array_equal(y, y8)
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    for _ in range(50):
+        bb, t, co = rng.randint(B), rng.randint(Lout), rng.randint(Cout)
+        acc = float(b[co]) + sum(x64[bb, s * t + kk - pl] @ w64[kk, :, co] for kk in range(k))
+        assert abs(y8[bb, t, co] - acc) <= 2e-5 * np.abs(y).max()
