@@ -694,7 +694,10 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
 static void wgrad_split_plan(int B, int M, int Cin, int Cout, int TC, int TN, int* splits, int* chunks_per_split) {
   const int cpb = (M + 31) / 32;
   const int tiles = cdiv(Cin, TC) * cdiv(Cout, TN);
-  int s = (2048 + tiles - 1) / tiles;
+  // blocks per launch the K-splits aim at: two full rounds of the chip's 1024 block slots.  Measured (round 3, step in waveforms/s): 2048: 1437,
+  // 1024 (one round, half the partial slabs to write and reduce): 1436 -- the kernel loses what the reduce gains; 1536 / 3072: 1429 (ragged rounds)
+  static const int target_blocks = getenv("GN_WGRAD_BLOCKS") ? atoi(getenv("GN_WGRAD_BLOCKS")) : 2048;      // A/B switch
+  int s = (target_blocks + tiles - 1) / tiles;
   if (s < 1) s = 1;
   static const bool no_sub = getenv("GN_WGRAD_NOSUBSPLIT") != nullptr;       // A/B switch
   int cps;
