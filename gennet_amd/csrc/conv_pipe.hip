@@ -22,10 +22,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // the same epilogue, but the MFMA block of a chunk is HAND-SCHEDULED.  hipcc turns the source-level operand double buffering of
 // conv_mfma_dma_kernel into "ds_read, s_waitcnt lgkmcnt(0), 2-4 MFMAs" (reads sunk next to their use, every wait a full drain), so a
 // wave exposes one LDS latency per 128-256 cycles of matrix work and the pipe only stays busy through the other waves of the SIMD.
-// Here each group of four MFMAs is one asm statement: the four ds_read_b32 of the NEXT group are issued first, a counted
-// s_waitcnt lgkmcnt(4) retires exactly the CURRENT group's operands (issued one group = 256 matrix cycles earlier), then the four
+// Here each group of four MFMAs is one asm statement: the operand reads of the NEXT group are issued first, a counted s_waitcnt
+// lgkmcnt retires exactly the CURRENT group's operands (issued one group = 256 matrix cycles earlier), then the four
 // v_mfma_f32_32x32x2_f32 issue back to back.  All LDS addresses are chunk-invariant VGPRs (one per tap for the input slab, one for
-// the weight tile) plus compile-time 16-bit offsets (stage, channel pair, tile), so the block has no address arithmetic at all.
+// the weight tile) plus compile-time 16-bit offsets (stage, tap, k-step, tile), so the block has no address arithmetic at all.
 // The layout is compile-time: IS (input stride) is a template parameter and the slab holds IS*(TM-1)+NTAPS rows (consecutive taps).
 // Descriptor and tile indices go through readfirstlane so that the buffer_load ... lds of the slab are not wrapped in waterfall loops.
 // ---------------------------------------------------------------------------------------------
