@@ -138,6 +138,107 @@ __global__ __launch_bounds__(256) void chunk_loop_kernel(float* out, int iters, 
 #endif
 }
 
+// Block turnover: the chunk loop above (operand reads + six spread buffer_load ... lds per chunk) as TILES of 64 chunks, as the dominant layer
+// runs them (Cin 512).  MODE_T 0: one launch of rounds x 1024 blocks, one tile each, no output (block exit + dispatch of the next one +
+// its first staging burst per tile); 1: the same with the tile's epilogue, 64 buffer_store_dword per lane; 2: PERSISTENT blocks, 1024 of them,
+// each looping over its tiles with the same epilogue and the next tile's first staging burst issued before it.
+template <int MODE_T>
+__global__ __launch_bounds__(256) void tile_loop_kernel(float* out, int tiles_per_block, const float* src, unsigned src_mask, float* sink) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(16))) float lds[9216];
+  const int lane = threadIdx.x & 63, i32 = lane & 31, h = lane >> 5, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = wave * 64 + i32;
+  const unsigned lds0 = (unsigned)(uintptr_t)lds;
+  const unsigned addr_a = lds0 + (row * 2 + (h ^ ((row >> 3) & 1))) * 16;
+  const unsigned addr_b = lds0 + (2112 + 4 * h * 64 + i32) * 4;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x40000000, 0x00020000);
+  const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc((void*)sink, 0, 0x40000000, 0x00020000);
+  int voff[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) voff[k] = (wave * 6 + k) * 1024 + lane * 16;
+  auto dma = [&](unsigned chunk_id, int k) {
+    float* dst = lds + 3072 + ((wave * 6 + k) * 256) % 6144;
+    const unsigned chunk_bytes = (chunk_id * 24576u) & 0x3ff00000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)dst, 16, voff[k], (int)chunk_bytes, 0, 0);
+  };
+  for (int i = threadIdx.x; i < 3072; i += 256) lds[i] = 1.0f / 1024.0f;
+  for (int t = 0; t < tiles_per_block; ++t) {
+    const unsigned tile = blockIdx.x + (unsigned)t * gridDim.x;
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    f32x4 a0 = {0.125f, 0.25f, 0.5f, 1.f}, a1 = a0;
+    float b0 = 1.0f / 1024.0f, b1 = b0;
+    if (MODE_T != 2 || t == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dma(tile * 64u, k);          // the tile's first chunk: a burst, and nothing to overlap it with
+    }
+    __syncthreads();
+    for (int i = 0; i < 64; ++i) {
+#pragma unroll
+      for (int tp = 0; tp < 5; ++tp) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          if ((tp * 4 + st) % 2 == 0 && (tp * 4 + st) / 2 < 6) dma(tile * 64u + i + 1, (tp * 4 + st) / 2);
+          if (st == 0)
+            asm volatile("ds_read_b32 %0, %5 offset:0\n\tds_read_b32 %1, %5 offset:128\n\tds_read_b128 %2, %4 offset:0\n\tds_read_b128 %3, %4 offset:1024\n\ts_waitcnt lgkmcnt(4)"
+                         : "=&v"(b0), "=&v"(b1), "=&v"(a0), "=&v"(a1) : "v"(addr_a), "v"(addr_b) : "memory");
+          else
+            asm volatile("ds_read_b32 %0, %2 offset:256\n\tds_read_b32 %1, %2 offset:384\n\ts_waitcnt lgkmcnt(2)" : "=&v"(b0), "=&v"(b1) : "v"(addr_b) : "memory");
+          asm volatile(
+              "v_mfma_f32_32x32x2_f32 %0, %4, %6, %0\n\t"
+              "v_mfma_f32_32x32x2_f32 %1, %4, %7, %1\n\t"
+              "v_mfma_f32_32x32x2_f32 %2, %5, %6, %2\n\t"
+              "v_mfma_f32_32x32x2_f32 %3, %5, %7, %3"
+              : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+              : "v"(a0[st]), "v"(a1[st]), "v"(b0), "v"(b1));
+        }
+      }
+      __syncthreads();
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    if (MODE_T >= 1) {
+      // epilogue of the tile: 64 dword stores per lane, 128 contiguous bytes per half-wave and row, rows 4 KiB apart (Cout = 1024)
+      const unsigned tile_base = ((tile & 4095u) * 65536u * 4u) & 0x3fc00000u;      // 4-MiB steps: the lane offsets (up to 1 MiB) stay inside the 1-GiB sink
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = wave * 64 + (j >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[j][r] + 1.0f), osrd, (rr * 1024 + (j & 1) * 32 + i32) * 4, (int)tile_base, 0);
+        }
+    } else {
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sacc += acc[j][0] + acc[j][15];
+      if (sacc == 12345.678f) out[threadIdx.x] = sacc;
+    }
+  }
+#endif
+}
+
+static void run_tiles(const char* name, int mode, int cus, float* out, const float* src, unsigned src_mask, float* sink) {
+  const int rounds = 8, slots = cus * 4;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    CHECK(hipEventRecord(e0, 0));
+    if (mode == 0) hipLaunchKernelGGL(tile_loop_kernel<0>, dim3(slots * rounds), dim3(256), 0, 0, out, 1, src, src_mask, sink);
+    else if (mode == 1) hipLaunchKernelGGL(tile_loop_kernel<1>, dim3(slots * rounds), dim3(256), 0, 0, out, 1, src, src_mask, sink);
+    else hipLaunchKernelGGL(tile_loop_kernel<2>, dim3(slots), dim3(256), 0, 0, out, rounds, src, src_mask, sink);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep > 0 && ms < best) best = ms;
+  }
+  const double tf = (double)slots * rounds * 4 * 64 * 80 * 4096.0 / (best * 1e-3) / 1e12;
+  printf("%-60s %8.3f ms  %7.2f TFLOP/s  %.4f of 157.3\n", name, best, tf, tf / 157.3);
+}
+
 template <typename K>
 static void run_chunk(const char* name, K kernel, int cus, int blocks_per_cu, float* out, const float* src, unsigned src_mask) {
   const int blocks = cus * blocks_per_cu;
@@ -215,6 +316,12 @@ int main() {
     run_chunk("  + 6 buffer_load lds x 16 B, spread", chunk_loop_kernel<true, 2, 6, 16, true>, cus, w, out, src, mask);
     run_chunk("  + 6 buffer x 16 B, no operand reads", chunk_loop_kernel<false, 2, 6, 16, false>, cus, w, out, src, mask);
   }
+  float* sink;
+  CHECK(hipMalloc(&sink, (size_t)1 << 30));
+  run_tiles("tiles of 64 chunks, a block per tile, no output", 0, cus, out, src, mask, sink);
+  run_tiles("tiles of 64 chunks, a block per tile, 64 stores per lane", 1, cus, out, src, mask, sink);
+  run_tiles("tiles of 64 chunks, persistent blocks, 64 stores per lane", 2, cus, out, src, mask, sink);
+  CHECK(hipFree(sink));
   CHECK(hipFree(src));
   CHECK(hipFree(out));
   return 0;
