@@ -82,12 +82,20 @@ __global__ void dropout_mask_kernel(uint8_t* __restrict__ mask, size_t n, float 
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t n4 = (n + 3) >> 2;
   if (base) offset += *base;
+  const bool aligned = (reinterpret_cast<uintptr_t>(mask) & 3) == 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const Philox4 r = philox4x32_10(offset + i, seed);
+    if (aligned && 4 * i + 3 < n) {                          // the four bytes as one dword store (byte stores: 4 instructions, a quarter of each sector)
+      unsigned w = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const size_t k = 4 * i + e;
-      if (k < n) mask[k] = u01_24(r.v[e]) >= rate ? 1 : 0;
+      for (int e = 0; e < 4; ++e) w |= (u01_24(r.v[e]) >= rate ? 1u : 0u) << (8 * e);
+      reinterpret_cast<unsigned*>(mask)[i] = w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const size_t k = 4 * i + e;
+        if (k < n) mask[k] = u01_24(r.v[e]) >= rate ? 1 : 0;
+      }
     }
   }
 }
