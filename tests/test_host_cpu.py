@@ -365,3 +365,28 @@ def test_interrupted_writes_never_truncate_the_previous_file(tmp_path):
     with pytest.raises(IOError):
         w2.save(h5)
     assert open(h5, 'rb').read() == first and not os.path.exists(h5 + '.tmp') or open(h5, 'rb').read() == first
+
+
+def test_measurement_tools_build_and_parse(tmp_path):
+    """scripts/mfma_peak.hip (the bare-MFMA-pipe / chunk-loop microbenchmark behind DESIGN section 6) cross-compiles for gfx950, and the counter
+    summariser reads a rocprofv3 counter CSV of the shape it documents."""
+    import json
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, 'scripts', 'mfma_peak.hip')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-c', '--cuda-device-only', src, '-o', str(tmp_path / 'mfma_peak.o')], check=True, timeout=600,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    d = tmp_path / 'pmc' / 'run'
+    d.mkdir(parents=True)
+    rows = ['Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value']
+    for disp in (1, 2):
+        rows += ['%d,k_conv,SQ_LDS_BANK_CONFLICT,%d' % (disp, 780 * disp), '%d,k_conv,SQ_LDS_IDX_ACTIVE,%d' % (disp, 1000 * disp),
+                 '%d,k_conv,GRBM_GUI_ACTIVE,%d' % (disp, 500 * disp)]
+    (d / '1_counter_collection.csv').write_text('\n'.join(rows) + '\n')
+    out = tmp_path / 'lds.json'
+    subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'pmc_lds.py'), str(tmp_path / 'pmc'), str(out), '256'], check=True, timeout=60, stdout=subprocess.DEVNULL)
+    k = json.load(open(out))['kernels']['k_conv']
+    assert k['launches'] == 2 and abs(k['conflict_share_of_lds_cycles'] - 0.78) < 1e-12 and abs(k['lds_busy_share_of_launch'] - 3000.0 / (1500.0 * 256)) < 1e-12
