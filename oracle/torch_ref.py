@@ -56,11 +56,16 @@ def _conv1d(x, w, b, stride, padding):
 
 
 class _BN(object):
-    def __init__(self, C):
+    """moving_average: 'ema' = plain exponential average (tf.keras, TF's zero_debias=False); 'tf_zero_debias' = Keras 2.2.4 on TF 1.12
+    (keras_ref.bn_moving_update_zero_debias: zero-initialised shadow accumulator, moving = biased / (1 - m^t))."""
+
+    def __init__(self, C, moving_average='ema'):
         self.gamma = torch.ones(C, requires_grad=True)
         self.beta = torch.zeros(C, requires_grad=True)
         self.mm = torch.zeros(C)
         self.mv = torch.ones(C)
+        self.moving_average = moving_average
+        self.bm, self.bv, self.t = torch.zeros(C), torch.zeros(C), 0
 
     def __call__(self, x, training, momentum=0.99):
         """x (B, C, L) or (B, C)."""
@@ -70,9 +75,17 @@ class _BN(object):
         n = x.numel() // x.shape[1]
         with torch.no_grad():
             mean = x.mean(dims)
-            var = x.var(dims, unbiased=False)
-            self.mm.mul_(momentum).add_(mean, alpha=1 - momentum)
-            self.mv.mul_(momentum).add_(var * (n / (n - (1.0 + K.BN_EPS))), alpha=1 - momentum)
+            var = x.var(dims, unbiased=False) * (n / (n - (1.0 + K.BN_EPS)))
+            if self.moving_average == 'ema':
+                self.mm.mul_(momentum).add_(mean, alpha=1 - momentum)
+                self.mv.mul_(momentum).add_(var, alpha=1 - momentum)
+            else:
+                self.bm.mul_(momentum).add_(mean, alpha=1 - momentum)
+                self.bv.mul_(momentum).add_(var, alpha=1 - momentum)
+                self.t += 1
+                corr = 1.0 - momentum ** self.t
+                self.mm.copy_(self.bm / corr)
+                self.mv.copy_(self.bv / corr)
         return F.batch_norm(x, None, None, self.gamma, self.beta, True, 0.0, K.BN_EPS)
 
 
@@ -124,17 +137,21 @@ class PENet(object):
 class GAN(object):
     """generator_model (:212-295), signal_discriminator_model (:408-498), MyLayer (:164-188), compile wiring (:1100-1119)."""
 
-    def __init__(self, n_pix, event, seed=2):
+    def __init__(self, n_pix, event, seed=2, lr=9e-5, moving_average='ema', bce_grad='clip'):
+        """bce_grad: 'clip' = Keras 2.2.4's binary cross-entropy from probabilities (clip to [1e-7, 1 - 1e-7]; the clip's gradient is zero
+        outside the interval); 'noclip' = DIAGNOSTIC ONLY (tests/tools/gan_dynamics_cpu.py): the same loss value, gradient taken through the
+        logit as if the clip were not there, i.e. never zeroed."""
         g = torch.Generator().manual_seed(seed)
         self.n_pix = n_pix
+        self.bce_grad = bce_grad
         self.event = torch.as_tensor(event, dtype=torch.float32).reshape(1, n_pix, 1)
         U = 256 * (n_pix // 2)
         self.g_dense = [_glorot((100, U), g).requires_grad_(), torch.zeros(U, requires_grad=True)]
-        self.g_bn0 = _BN(U)
+        self.g_bn0 = _BN(U, moving_average)
         self.g_convs = []
         cin = 256
         for cout, s in ((64, 2), (128, 1), (256, 1), (512, 1), (1024, 1)):
-            self.g_convs.append([_glorot((5, cin, cout), g).requires_grad_(), torch.zeros(cout, requires_grad=True), s, _BN(cout)])
+            self.g_convs.append([_glorot((5, cin, cout), g).requires_grad_(), torch.zeros(cout, requires_grad=True), s, _BN(cout, moving_average)])
             cin = cout
         self.g_out = [_glorot((5, 1024, 1), g).requires_grad_(), torch.zeros(1, requires_grad=True)]
         self.d_convs = []
@@ -148,8 +165,8 @@ class GAN(object):
             self.g_params += [w, b, bn.gamma, bn.beta]
         self.g_params += self.g_out
         self.d_params = [t for l in self.d_convs for t in l] + self.d_dense
-        self.opt_g = KerasAdam(self.g_params)
-        self.opt_d = KerasAdam(self.d_params)
+        self.opt_g = KerasAdam(self.g_params, lr=lr)
+        self.opt_d = KerasAdam(self.d_params, lr=lr)
 
     def G(self, z, training):
         h = z @ self.g_dense[0] + self.g_dense[1]
@@ -161,19 +178,24 @@ class GAN(object):
             h = F.dropout(torch.tanh(bn(_conv1d(h, w, b, s, 'same'), training)), 0.2, training)
         return _conv1d(h, self.g_out[0], self.g_out[1], 1, 'same').permute(0, 2, 1)          # (B, n_pix, 1)
 
-    def D(self, img, training):
-        """img (B, n_pix, 2, 1) channels-last -> (B, 1)."""
+    def D_logit(self, img, training):
+        """img (B, n_pix, 2, 1) channels-last -> pre-sigmoid (B, 1)."""
         h = img.permute(0, 3, 1, 2)
         for w, b in self.d_convs:
             _, pt, pb = K.same_pad(h.shape[2], 5, 2)
             h = F.conv2d(F.pad(h, (2, 2, pt, pb)), w.permute(3, 2, 0, 1), b, stride=(2, 1))
             h = F.dropout(F.leaky_relu(h, 0.2), 0.4, training)
         h = h.permute(0, 2, 3, 1).reshape(h.shape[0], -1)
-        return torch.sigmoid(h @ self.d_dense[0] + self.d_dense[1])
+        return h @ self.d_dense[0] + self.d_dense[1]
 
-    @staticmethod
-    def bce(p, y):
+    def D(self, img, training):
+        return torch.sigmoid(self.D_logit(img, training))
+
+    def bce(self, p, y, logit=None):
         lo, hi = K.CLIP_LO, K.CLIP_HI
+        if self.bce_grad == 'noclip':
+            # diagnostic: same VALUE as the clipped loss wherever the clip is inactive, gradient sigmoid(logit) - y everywhere
+            return F.binary_cross_entropy_with_logits(logit, y)
         return F.binary_cross_entropy(torch.clamp(p, lo, hi), y)
 
     def iteration(self, real, B):
@@ -185,16 +207,21 @@ class GAN(object):
         real2 = torch.cat([real.reshape(B, self.n_pix, 1), torch.randn(B, self.n_pix, 1)], dim=2)
         sX = torch.cat([real2, fake2]).reshape(2 * B, self.n_pix, 2, 1)
         sy = torch.cat([torch.ones(B, 1), torch.zeros(B, 1)])
-        ld = self.bce(self.D(sX, True), sy)
+        lgt = self.D_logit(sX, True)
+        pd = torch.sigmoid(lgt)
+        ld = self.bce(pd, sy, lgt)
         ld.backward()
         self.opt_d.step()
         for p in self.g_params:
             p.grad = None
         x = self.G(torch.rand(B, 100) * 2 - 1, True)
         img = torch.stack([x, self.event - x], dim=2)
-        lg = self.bce(self.D(img, True), torch.ones(B, 1))
+        lgt = self.D_logit(img, True)
+        pg = torch.sigmoid(lgt)
+        lg = self.bce(pg, torch.ones(B, 1), lgt)
         lg.backward()
         for p in self.d_params:
             p.grad = None                                  # D frozen in the combined model
         self.opt_g.step()
+        self.last_acc = [float((pg.detach().round() == 1).float().mean()), float((pd.detach().round() == sy).float().mean())]
         return [float(lg.detach()), float(ld.detach())]

@@ -73,6 +73,53 @@ def moments(s):
             'corr': float(np.corrcoef(s[0], s[1])[0, 1]) if np.std(s[0]) > 0 and np.std(s[1]) > 0 else None}
 
 
+def build_nets(event, fs, lr=9e-5, chi_loss=False, moving_average='tf_zero_debias', bce_on_logit=False, do_pe=True):
+    """bbh.build_and_compile, plus the two DIAGNOSTIC switches of VERDICT r3 item 1c.  Neither is reachable from the product surface:
+      moving_average 'ema'   every BatchNormalization built here uses the plain exponential moving average (tf.keras; layers.BatchNormalization
+                             already offers it per layer) instead of the Keras-2.2.4 default 'tf_zero_debias';
+      bce_on_logit           the discriminator's final sigmoid is made linear and binary cross-entropy is evaluated ON THE LOGIT
+                             (loss = softplus(z) - z y, dL/dz = (sigmoid(z) - y) / B): no clip, and no fp32 sigmoid that rounds to exactly 0 / 1, so
+                             the gradient is never zeroed.  Keras 2.2.4 cannot do this (binary_crossentropy from probabilities, Appendix B.8).  The
+                             arithmetic is a few torch ops on the device, monkey-patched over ops.loss for THIS PROCESS only -- a checker's tool."""
+    import torch
+    from gennet_amd import bbh, layers, ops
+    saved_ma, saved_d = layers.BN_MOVING_AVERAGE, bbh.signal_discriminator_model
+    layers.BN_MOVING_AVERAGE = moving_average
+    if bce_on_logit:
+        def d_linear(n_pix=1024):
+            m = saved_d(n_pix)
+            assert m.layers[-1].act_spec[0] == 'sigmoid'
+            m.layers[-1].act_spec = ('linear', 0.0)
+            return m
+        bbh.signal_discriminator_model = d_linear
+        if not getattr(ops.loss, '_on_logit', False):
+            plain = ops.loss
+
+            def loss_on_logit(kind, p, y, Bglobal=None):
+                if kind != 'binary_crossentropy':
+                    return plain(kind, p, y, Bglobal)
+                B = float(Bglobal or p.shape[0])
+                per = torch.clamp(p, min=0) - p * y + torch.log1p(torch.exp(-p.abs()))
+                return (torch.sigmoid(p) - y) / B, torch.stack([per.sum() / B, ((p > 0).float() == y).float().sum()])
+            loss_on_logit._on_logit = True
+            ops.loss = loss_on_logit
+    try:
+        return bbh.build_and_compile(event, fs, lr=lr, chi_loss=chi_loss, do_pe=do_pe)
+    finally:
+        layers.BN_MOVING_AVERAGE, bbh.signal_discriminator_model = saved_ma, saved_d
+
+
+def rail_report(y_q, p_q, lo=0.0, hi=1.0):
+    """ReLU(max_value=1) on the q head (bbhMahoGANy.py:400): fraction of predictions sitting exactly on a rail, and the mean |error| without them."""
+    y_q, p_q = np.asarray(y_q, np.float64).reshape(-1), np.asarray(p_q, np.float64).reshape(-1)
+    on0, on1 = p_q <= lo, p_q >= hi
+    free = ~(on0 | on1)
+    return {'fraction_at_0': float(on0.mean()), 'fraction_at_1': float(on1.mean()),
+            'mean_abs_error_q_off_rail': float(np.abs(y_q - p_q)[free].mean()) if free.any() else None,
+            'mean_abs_error_q_on_rail': float(np.abs(y_q - p_q)[~free].mean()) if (~free).any() else None,
+            'true_q_mean_of_rows_at_1': float(y_q[on1].mean()) if on1.any() else None}
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--n-pix', type=int, default=1024)
@@ -92,6 +139,8 @@ def parse(argv=None):
     ap.add_argument('--fine-cadence', type=int, default=500)
     ap.add_argument('--predict-batch', type=int, default=32, help='chunk of generator.predict inside the GAN iteration')
     ap.add_argument('--lr', type=float, default=9e-5)
+    ap.add_argument('--moving-average', default='tf_zero_debias', choices=('tf_zero_debias', 'ema'), help='DIAGNOSTIC (build_nets): BatchNormalization moving statistics')
+    ap.add_argument('--bce-on-logit', action='store_true', help='DIAGNOSTIC (build_nets): cross-entropy on the discriminator logit, gradient never zeroed; not a product mode')
     ap.add_argument('--chi-loss', action='store_true', help='chi_loss (bbhMahoGANy.py:97, :1106-1109): the generator trains on chisquare_Loss instead of binary cross-entropy')
     ap.add_argument('--save-pe', default='', help='write the trained CNN to this .h5 file (Keras layout)')
     ap.add_argument('--load-pe', default='', help='skip the CNN loop and load the CNN from this .h5 file')
@@ -131,7 +180,7 @@ def run(args):
     noise = np.random.RandomState(100 + args.seed).randn(fs)
     event = (ev_raw.cpu().numpy()[0] * g + noise).astype(np.float32)                    # d = g h + n
     truth = [float((36.0 * 29.0) ** 0.6 / 65.0 ** 0.2), 29.0 / 36.0]
-    out = {'config': {k: getattr(args, k) for k in ('n_pix', 'bank', 'pe_batch', 'pe_iter', 'gan_batch', 'gan_iter', 'cadence', 'lr', 'seed', 'graph', 'chi_loss', 'load_pe')},
+    out = {'config': {k: getattr(args, k) for k in ('n_pix', 'bank', 'pe_batch', 'pe_iter', 'gan_batch', 'gan_iter', 'cadence', 'lr', 'seed', 'graph', 'chi_loss', 'load_pe', 'moving_average', 'bce_on_logit')},
            'event': {'m1': 36.0, 'm2': 29.0, 'idx': N // 2, 'mc': truth[0], 'q': truth[1], 'optimal_snr': snr, 'template_scale_g': g,
                      'noise': 'N(0,1), RandomState(%d)' % (100 + args.seed)},
            'reference_yardstick_pe_std': PE_STD_REFERENCE}
@@ -149,7 +198,7 @@ def run(args):
     print('exact posterior: %s (%.1f s)' % (json.dumps(out['exact_posterior']), time.time() - t0), flush=True)
 
     # ---- networks
-    nets = bbh.build_and_compile(event.reshape(fs, 1), fs, lr=args.lr, chi_loss=args.chi_loss)
+    nets = build_nets(event.reshape(fs, 1), fs, lr=args.lr, chi_loss=args.chi_loss, moving_average=args.moving_average, bce_on_logit=args.bce_on_logit)
     ev_dev = engine.to_device(event)
     pe_step = gan_step = None
     if args.graph:
@@ -178,7 +227,8 @@ def run(args):
     out['cnn'] = {'steps': i, 'batch': args.pe_batch, 'waveforms': i * args.pe_batch, 'seconds': t_cnn, 'waveforms_per_s': i * args.pe_batch / t_cnn,
                   'mean_abs_error_heldout [mc, q]': [float(e.mean()) for e in err], 'median_abs_error_heldout [mc, q]': [float(np.median(e)) for e in err],
                   'mean_abs_error_training_4000 [mc, q] (the reference read-out, :1184-1196)': std_tr, 'mse_training_4000 [mc, q]': rms_tr,
-                  'prior_std [mc, q]': [float(hy[:, 0].std()), float(hy[:, 1].std())], 'loss_history [step, total, mc, q]': hist}
+                  'prior_std [mc, q]': [float(hy[:, 0].std()), float(hy[:, 1].std())],
+                  'q_head_rails (ReLU(max_value=1), :400)': rail_report(hy[:, 1], p[1].cpu().numpy()), 'loss_history [step, total, mc, q]': hist}
     if args.save_pe:
         nets.signal_pe.save_weights(args.save_pe, True)
     if args.pe_settle_steps > 0:
