@@ -286,7 +286,8 @@ def gan_train_step(nets, bank, event, batch, rng=_pyrandom, rank=0, world=1, pre
 # --------------------------------------------------------------------------------------------------------------
 class _GraphedStep(object):
     """Call 1 runs the step eagerly (binds optimizer state, triggers every lazy initialisation); call 2 captures the step into a
-    hipGraph (engine.StepGraph) and replays it; later calls replay.  The sequence of results is bit-identical to calling the eager step
+    hipGraph (engine.StepGraph) and replays it; later calls replay (under data parallelism every call runs the eager body: the collectives of
+    dist.DataParallel are not captured).  The sequence of results is bit-identical to calling the eager step
     every time: same host index stream, same Philox stream positions, same Adam / BatchNormalization step counts.
     want_losses=False skips the device -> host read of the loss statistics (and with it the per-step synchronisation)."""
 
@@ -294,6 +295,7 @@ class _GraphedStep(object):
         self.bank, self.batch, self.rng, self.rank, self.world = bank, int(batch), rng, rank, world
         self.calls = 0
         self.sg = None
+        self.eager_only = False            # under data parallelism: the collectives are not captured, every call runs the eager body
         self.it = torch.zeros(self.batch, dtype=torch.int64, device=device())
         self.it_host = torch.zeros(self.batch, dtype=torch.int64).pin_memory()
 
@@ -304,13 +306,14 @@ class _GraphedStep(object):
 
     def __call__(self, want_losses=True):
         self.calls += 1
-        if self.calls == 1:
+        if self.calls == 1 or self.eager_only:
             return self._eager()
         if self.sg is None:
-            self.sg = StepGraph()
+            sg = StepGraph()
             self._stage_indices()
             torch.cuda.synchronize()
-            self.sg.capture(self._body)
+            sg.capture(self._body)
+            self.sg = sg                   # only a graph whose capture succeeded is ever replayed
         else:
             self.sg.wait_inputs_consumed()
             self._stage_indices()
@@ -323,8 +326,7 @@ class GraphedPEStep(_GraphedStep):
 
     def __init__(self, signal_pe, bank, batch, cnn_noise_frac=1.0 / 8.0, rng=_pyrandom, nprng=np.random, rank=0, world=1):
         _GraphedStep.__init__(self, bank, batch, rng, rank, world)
-        if signal_pe.data_parallel is not None:
-            raise NotImplementedError('GraphedPEStep under data parallelism (the collectives are not captured)')
+        self.eager_only = signal_pe.data_parallel is not None
         self.model, self.frac, self.nprng = signal_pe, cnn_noise_frac, nprng
 
     def _eager(self):
@@ -351,8 +353,7 @@ class GraphedGANStep(_GraphedStep):
 
     def __init__(self, nets, bank, event, batch, rng=_pyrandom, rank=0, world=1, predict_batch=32):
         _GraphedStep.__init__(self, bank, batch, rng, rank, world)
-        if nets.signal_discriminator.data_parallel is not None:
-            raise NotImplementedError('GraphedGANStep under data parallelism (the collectives are not captured)')
+        self.eager_only = nets.signal_discriminator.data_parallel is not None
         self.nets, self.event, self.predict_batch = nets, event, predict_batch
 
     def _eager(self):

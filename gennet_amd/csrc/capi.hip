@@ -211,7 +211,9 @@ int gn_set_conv_math(int mode, void* workspace, size_t workspace_bytes) { return
 size_t gn_conv1d_bf16x3_workspace(int B, int L, int Cin, int Cout, int k) { return conv_bf16x3_workspace_bytes(B, L, Cin, Cout, k); }
 
 size_t gn_conv1d_fwd_stats_workspace(int B, int Lout, int Cout) {
-  const size_t fused = (size_t)B * (size_t)((Lout + 127) / 128) * 2 * (size_t)Cout * sizeof(double);      // per-block partials (smallest tile: 128 rows)
+  // per-block partials: one row of 2 * Cout doubles per (batch element, row tile); the smallest row tile any launch_conv_pipe instantiation uses
+  // is 64 rows (the narrow-wave blocks with one wave in M, conv_pipe.hip conv_pipe_try: nwm == 1)
+  const size_t fused = (size_t)B * (size_t)((Lout + 63) / 64) * 2 * (size_t)Cout * sizeof(double);
   const size_t plain = colred_workspace_bytes((size_t)B * Lout, Cout);
   return (fused > plain ? fused : plain) + 256;
 }

@@ -651,7 +651,10 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
 // chunk; at the script's own batch 8 that made the data gradient of a stride-2 layer twice as slow as its forward.
 // a.t: ntaps 5 in kernel-tap order (even index <-> rows out_stride*m + out_off, odd index <-> out_off_odd), offsets spanning 3 rows.
 int conv_pipe_try_merged(const ConvArgs& a, hipStream_t s, bool* launched) {
-  static const bool off = getenv("GN_CONV_NOMERGE") != nullptr;        // A/B switch
+  // A/B switches: the merged kernel is a member of the pipelined LDS-DMA family, so every switch that takes that family out (to run and test
+  // the fallback kernels) takes it out too
+  static const bool off = getenv("GN_CONV_NOMERGE") != nullptr || getenv("GN_CONV_NOPIPE") != nullptr || getenv("GN_CONV_NODMA") != nullptr ||
+                          getenv("GN_CONV_NOGLDS") != nullptr;
   static const int merge_below = getenv("GN_CONV_MERGE_BELOW") ? atoi(getenv("GN_CONV_MERGE_BELOW")) : 2048;
   *launched = false;
   if (off || a.t.ntaps != 5 || a.t.in_stride != 1 || a.t.out_stride != 2 || a.stat_part || a.mask || a.bias) return GN_OK;

@@ -68,6 +68,35 @@ class DataParallel(object):
             self.broadcast(p.data)
 
 
+def expected_collectives(nets, cnn_steps=2):
+    """What ONE bench step (cnn_steps x CNN train_on_batch + one GAN iteration, bbh.pe_train_step / gan_train_step) must put through
+    all_reduce_sum, from the models' own shapes -- so that the first real N > 1 run validates itself against DataParallel's counters:
+      * per train_on_batch of a compiled model: its trainable parameters, each padded to the flat buffer's 256-byte granule, fp32 (SUM of
+        the gradients; n_pix 2048: CNN 19.7 MB, D 15.2 MB, G 122 MB) and one (n_outputs, 2) fp32 block of loss / accuracy sums;
+      * per BatchNormalization of the generator inside the combined model: (sum x, sum x^2) forward and (sum g, sum g xhat) backward, 2 C fp64
+        each (SyncBN: the first one reduces over the batch axis only, bbhMahoGANy.py:235).
+    Returns {'calls', 'bytes', 'parts': {...}}."""
+    from .engine import ParamGroup, segments
+    from .layers import BatchNormalization
+    gran = ParamGroup.ALIGN
+
+    def grad_bytes(model):
+        return 4 * sum(-(-p.size // gran) * gran for p in model._train_params)
+    parts, calls = {}, 0
+    for name, model, n in (('cnn', nets.signal_pe, cnn_steps), ('discriminator', nets.signal_discriminator, 1),
+                           ('generator_through_frozen_discriminator', nets.signal_discriminator_on_generator, 1)):
+        if model is None or n == 0:
+            continue
+        parts[name + '_gradients'] = n * grad_bytes(model)
+        parts[name + '_loss_scalars'] = n * len(model.output_ids) * 2 * 4
+        bound = all(getattr(p, 'group', None) is not None for p in model._train_params)       # flat buffers exist after the first device step
+        calls += n * ((len(segments(model._train_params)) if bound else 1) + 1)
+    bns = [l for l in nets.generator.layers if isinstance(l, BatchNormalization)]
+    parts['syncbn_sums'] = sum(2 * (2 * int(l.gamma.size) * 8) for l in bns)
+    calls += 2 * len(bns)
+    return {'calls': calls, 'bytes': int(sum(parts.values())), 'parts': parts}
+
+
 def init(backend=None, allow_single=False):
     """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
     Returns a DataParallel, or None when WORLD_SIZE is 1 or unset (allow_single=True initialises a one-rank group anyway: the

@@ -210,6 +210,7 @@ class StepGraph(object):
         self.copied = torch.cuda.Event()
         self._copied_once = False
         self.outputs = None
+        self.scratch = []                  # every ops.workspace() buffer handed out during capture: the graph holds their addresses
 
     def slot(self, fmt, provider):
         """Reserve one 8-byte slot holding a scalar of struct format `fmt` ('f', 'i', 'Q'); provider() -> value is called before every replay."""
@@ -228,6 +229,10 @@ class StepGraph(object):
         rng = device_rng()
         self.rng_start = rng.offset
 
+        def keep(buf):
+            if not any(b is buf for b in self.scratch):
+                self.scratch.append(buf)
+
         def rng_base():
             base = device_rng().offset - self.rng_start
             device_rng().offset += self.rng_taken
@@ -236,6 +241,7 @@ class StepGraph(object):
         self.graph = torch.cuda.CUDAGraph()
         _CAPTURE = self
         ops.set_rng_base(base.ptr)
+        ops._ws_on_use = keep
         prof = ops.prof_enabled()          # the launch-stream HIP events of the profiling hooks must not be recorded into the graph
         if prof:
             ops.prof_enable(False)
@@ -244,11 +250,12 @@ class StepGraph(object):
                 self.outputs = fn()
         finally:
             ops.set_rng_base(None)
+            ops._ws_on_use = None
             _CAPTURE = None
             if prof:
                 ops.prof_enable(True)
-        self.rng_taken = rng.offset - self.rng_start
-        rng.offset = self.rng_start
+            self.rng_taken = rng.offset - self.rng_start
+            rng.offset = self.rng_start    # also when fn raised: the draws of a failed capture never executed
         return self.outputs
 
     def wait_inputs_consumed(self):

@@ -30,6 +30,10 @@ def _chk(*ts):
             raise ValueError('non-contiguous tensor passed to a gennet_amd op')
 
 
+_ws_on_use = None       # engine.StepGraph.capture installs a callback here: a captured graph keeps the RAW ADDRESS of the scratch buffer it
+                        # was handed, so it must also keep the buffer alive after a larger request has replaced it in _ws
+
+
 def workspace(nbytes, device):
     """Stream-ordered scratch, grown on demand and reused (all ops run on one stream per process)."""
     key = (device.type, device.index)
@@ -37,6 +41,8 @@ def workspace(nbytes, device):
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
         _ws[key] = buf
+    if _ws_on_use is not None:
+        _ws_on_use(buf)
     return buf
 
 

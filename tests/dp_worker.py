@@ -67,9 +67,9 @@ def run_cpu(out):
     ds = dsum.numpy()
     dx = gamma * inv * (dyl - ds[:5] / n - xhat * ds[5:] / n)
     res['bn'] = {'rows': (lo, hi), 'y': gamma * xhat + beta, 'dx': dx, 'mean': mean, 'var': var, 'dgamma_local': local.numpy()[5:], 'dsum': ds}
-    # (3) rank-sliced host sampling
+    # (3) rank-sliced host sampling: BASELINE configs[3]'s global batch of 4096 rows out of a 100 000-template bank, 4096 / world rows per rank
     random.seed(1)
-    res['idx'] = [bbh.sample_indices(1000, 4, random, rank, world) for _ in range(3)]
+    res['idx'] = [bbh.sample_indices(100000, 4096 // world, random, rank, world) for _ in range(3)]
     res['next'] = random.random()
     pickle.dump(res, open('%s.%d' % (out, rank), 'wb'))
     if dp:
@@ -109,6 +109,13 @@ def run_gpu(out, backend='gloo'):
         for l, shp in zip([l for l in D.layers if isinstance(l, Dropout)], ((B, n_pix // 2, 2, 256), (B, n_pix // 4, 2, 512))):
             masks[l.name] = (rng.rand(*shp) >= 0.4).astype(np.uint8)
         res['losses'].append(DG.train_on_batch(z[lo:hi], np.ones(hi - lo), dropout_masks={k: v[lo:hi] for k, v in masks.items()}))
+    # the hipGraph loop body under data parallelism runs its eager body (the collectives are not captured) and still tiles the global batch
+    bank = bbh.DeviceBank(f32(rng.randn(32, n_pix)), np.stack([rng.uniform(20, 35, 32), rng.uniform(0.5, 1, 32)], 1))
+    random.seed(5)
+    step = bbh.GraphedPEStep(PE, bank, B // world, cnn_noise_frac=0.0, rank=rank, world=world)
+    for _ in range(3):
+        res['losses'].append(step())
+    assert step.eager_only == (dp is not None) and (step.sg is None) == (dp is not None)
     res['weights'] = {'G': G.get_weights(), 'D': D.get_weights(), 'PE': PE.get_weights()}
     if dp:
         for m in (G, D, PE):

@@ -39,9 +39,17 @@ def launch(mode, out, world):
     return [pickle.load(open('%s.%d' % (out, k), 'rb')) for k in range(world)]
 
 
-def test_dp_math_over_gloo_cpu(tmp_path):
-    one = launch('cpu', str(tmp_path / 'one'), 1)[0]
-    two = launch('cpu', str(tmp_path / 'two'), 2)
+@pytest.fixture(scope='module')
+def single_process_cpu(tmp_path_factory):
+    return launch('cpu', str(tmp_path_factory.mktemp('dp') / 'one'), 1)[0]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_dp_math_over_gloo_cpu(tmp_path, single_process_cpu, world):
+    """world = 8 is BASELINE configs[3]'s partition (8 x 512 rows of a 4096-row draw); the driver's SCALE run is its first execution over RCCL."""
+    one = single_process_cpu
+    two = launch('cpu', str(tmp_path / 'many'), world)
+    assert len(two) == world and sorted(r['bn']['rows'] for r in two) == [(k * 8 // world, (k + 1) * 8 // world) for k in range(world)]
     for r in two:
         assert np.abs(r['pe_grads'] - one['pe_grads']).max() <= 1e-12 * np.abs(one['pe_grads']).max()
         lo, hi = r['bn']['rows']
@@ -51,14 +59,15 @@ def test_dp_math_over_gloo_cpu(tmp_path):
         assert np.allclose(r['bn']['dx'], full['dx'][lo * 12:hi * 12], rtol=1e-11, atol=1e-13)
         assert np.allclose(r['bn']['dsum'], full['dsum'], rtol=1e-12)
     # local parameter-gradient sums add up to the global ones (what the flat gradient all-reduce then produces)
-    assert np.allclose(two[0]['bn']['dgamma_local'] + two[1]['bn']['dgamma_local'], one['bn']['dsum'][5:], rtol=1e-12)
-    # host sampling: every rank advanced the stream identically; the slices tile the single-process draw
-    assert two[0]['next'] == two[1]['next']
+    assert np.allclose(sum(r['bn']['dgamma_local'] for r in two), one['bn']['dsum'][5:], rtol=1e-12)
+    # host sampling: every rank advanced the stream identically; the rank slices, in rank order, ARE the single-process draw of 4096 rows
+    assert all(r['next'] == one['next'] for r in two)
     import random
     random.seed(1)
     for k in range(3):
-        full_draw = random.sample(range(1000), 8)
-        assert two[0]['idx'][k] + two[1]['idx'][k] == full_draw
+        full_draw = random.sample(range(100000), 4096)
+        assert all(len(r['idx'][k]) == 4096 // world for r in two)
+        assert sum((r['idx'][k] for r in two), []) == full_draw == one['idx'][k]
 
 
 @pytest.mark.gpu

@@ -99,3 +99,30 @@ def test_capture_while_the_launch_profiler_is_on():
         ops.prof_enable(False)
     assert got == eager
     assert ops.prof_collect(0)['launches'] > 0          # the eager first call was profiled; the capture was not (it would have failed)
+
+
+def test_a_captured_graph_keeps_its_scratch_buffer_alive():
+    """a captured graph holds the RAW address of ops.workspace()'s scratch; a later, larger eager request replaces that buffer.  The
+    graph must keep the one it captured alive (StepGraph.scratch), so replays after the replacement still equal the eager loop bit for bit --
+    here the old buffer is dropped from ops._ws, torch's cache emptied and the freed range deliberately overwritten by a new allocation."""
+    import gc
+    from gennet_amd import bbh, engine, ops
+    n_pix, B, steps = 256, 8, 6
+    nets, bank, _ = _setup(n_pix, 13)
+    eager = [bbh.pe_train_step(nets.signal_pe, bank, B) for _ in range(steps)]
+    nets, bank, _ = _setup(n_pix, 13)
+    step = bbh.GraphedPEStep(nets.signal_pe, bank, B)
+    got = [step() for _ in range(3)]                                     # eager, capture + replay, replay
+    assert step.sg is not None and len(step.sg.scratch) >= 1
+    key = (engine.device().type, engine.device().index)
+    old = ops._ws[key]
+    assert any(b is old for b in step.sg.scratch)
+    old_ptr, old_bytes = old.data_ptr(), old.numel()
+    big = ops.workspace(old_bytes * 3, engine.device())                  # what a later, larger eager layer would ask for
+    assert ops._ws[key] is big and big.data_ptr() != old_ptr
+    del old
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    junk = [torch.full((old_bytes // 4,), float('nan'), device=engine.device()) for _ in range(3)]      # would land on a freed buffer
+    assert all(j.data_ptr() != old_ptr for j in junk)                    # ... but the graph still owns it
+    got += [step() for _ in range(steps - 3)]
+    assert got == eager, (got, eager)

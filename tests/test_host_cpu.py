@@ -390,3 +390,24 @@ def test_measurement_tools_build_and_parse(tmp_path):
     subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'pmc_lds.py'), str(tmp_path / 'pmc'), str(out), '256'], check=True, timeout=60, stdout=subprocess.DEVNULL)
     k = json.load(open(out))['kernels']['k_conv']
     assert k['launches'] == 2 and abs(k['conflict_share_of_lds_cycles'] - 0.78) < 1e-12 and abs(k['lds_busy_share_of_launch'] - 3000.0 / (1500.0 * 256)) < 1e-12
+
+
+def test_expected_collectives_of_one_bench_step():
+    """dist.expected_collectives: what bench.py --gpus N checks DataParallel's counters against after its timed region (exit 4 on a mismatch) -- the
+    per-step exchange of SURVEY 8e at the headline size, from the models' shapes alone: the CNN's flat gradient twice (19.7 MB each), D's (15.2 MB),
+    G's (122 MB), twelve SyncBN sums (fp64), four loss-scalar blocks = 20 all-reduces, 185.4 MB."""
+    from gennet_amd import bbh, dist
+    nets = bbh.build_and_compile(np.zeros((2048, 1), np.float32), 2048)
+    e = dist.expected_collectives(nets, 2)
+    assert e['calls'] == 20
+    p = e['parts']
+    assert 2 * 19.7e6 < p['cnn_gradients'] < 2 * 19.75e6 and 15.2e6 < p['discriminator_gradients'] < 15.3e6
+    assert 122e6 < p['generator_through_frozen_discriminator_gradients'] < 122.6e6
+    assert p['syncbn_sums'] == 2 * 2 * 8 * (256 * 1024 + 64 + 128 + 256 + 512 + 1024)
+    assert p['cnn_loss_scalars'] == 32 and p['discriminator_loss_scalars'] == 8
+    assert e['bytes'] == sum(p.values()) and 185.3e6 < e['bytes'] < 185.5e6
+    # unpadded parameter counts of SURVEY Appendix A: 4 928 514 (CNN), 3 808 257 (D), 31 095 745 + 7 936 conv-BN (G)
+    assert sum(q.size for q in nets.signal_pe._train_params) == 4928514
+    assert sum(q.size for q in nets.signal_discriminator._train_params) == 3808257
+    # ... of which the moving statistics (half of every BatchNormalization's four vectors) are not trainable and are never exchanged
+    assert sum(q.size for q in nets.signal_discriminator_on_generator._train_params) == 31095745 + 7936 - 2 * (256 * 1024 + 1984)

@@ -114,6 +114,31 @@ def test_conv1d_fwd_with_batchnorm_statistics(B, L, Cin, Cout, s, padding):
     close(ops.bn_stats(y.reshape(-1, Cout)), got, 1e-12)
 
 
+@pytest.mark.parametrize("B,L,Cin,Cout", [(8, 100, 64, 64), (8, 65, 64, 64), (8, 192, 128, 64), (3, 100, 64, 128)])
+def test_conv1d_fwd_stats_stays_inside_an_exact_size_workspace(B, L, Cin, Cout):
+    """ADVICE r3: the narrow-wave launches of conv_pipe.hip use 64-row blocks, so the fused statistics write B * ceil(Lout / 64) partial rows;
+    gn_conv1d_fwd_stats_workspace sized them for 128-row tiles.  An exact-size C-API caller (no slack, unlike ops.workspace) must be safe: the
+    call runs in a buffer of EXACTLY the advertised size followed by a guard region that has to come back untouched."""
+    from gennet_amd import _lib, ops
+    rng = np.random.RandomState(B * L + Cout)
+    x = f32(rng.randn(B, L, Cin)); w = f32(rng.randn(5, Cin, Cout) / np.sqrt(5 * Cin)); b = f32(rng.randn(Cout) * 0.3)
+    Lout, pl = ops.conv_geometry(L, 5, 1, 'same')
+    nb = _lib.size('gn_conv1d_fwd_stats_workspace', B, Lout, Cout)
+    assert nb >= B * -(-Lout // 64) * 2 * Cout * 8
+    guard = 1 << 16
+    buf = torch.full((nb + guard,), 0xA5, dtype=torch.uint8, device='cuda')
+    xd, wd, bd = g(x), g(w), g(b)
+    y = torch.empty((B, Lout, Cout), dtype=torch.float32, device='cuda')
+    sums = torch.empty((2 * Cout,), dtype=torch.float64, device='cuda')
+    _lib.call('gn_conv1d_fwd_stats', ops._p(xd), ops._p(wd), ops._p(bd), ops._p(y), ops._p(sums), ops._p(buf), nb, B, L, Cin, Cout, 5, 1, pl, Lout, ops._stream())
+    torch.cuda.synchronize()
+    assert bool((buf[nb:] == 0xA5).all()), 'statistics partials written past the advertised workspace size'
+    close(y, K.conv1d_fwd(x, w, b, 1, 'same'))
+    yd = y.double().reshape(-1, Cout)
+    ref = torch.cat([yd.sum(0), (yd * yd).sum(0)]).cpu().numpy()
+    assert np.abs(sums.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
 def test_conv1d_mfma_exact_integers():
     """A = small integers, B asymmetric integers: fp32 MFMA must be bit-exact (catches row/col swaps, tap mix-ups)."""
     from gennet_amd import ops
