@@ -774,6 +774,18 @@ static int launch_wgrad(WgradArgs& a, float* dw, hipStream_t s) {
         }
         if (best) { a.xcd_order = 2; a.patch_px = best; }
       }
+      // the split-K reduction inside the kernel (last-arriving block per tile, wgrad_pipe.hip): dw bit-identical to wgrad_reduce_kernel's.
+      // Measured in round 4 on the headline step (two boxes, profiles/r04_ab_wgrad_fold.json): 1440.5 / 1437.0 waveforms/s with the separate reduce
+      // pass, 1403-1407 folded.  The 21 reduce launches (0.4 % of the step) go, but every weight-gradient launch grows by 0.33-0.40 ms (0.93 -> 0.86
+      // of peak), the same with 4 or 16 slab loads in flight per thread of the last block: what costs is the device-scope release / acquire every
+      // block executes -- on gfx950 an L2 write-back and an L2 invalidate of an XCD-private L2 -- under the blocks still in their main loop.  Opt-in.
+      static const bool fold = getenv("GN_WGRAD_FOLD") != nullptr;             // A/B switch
+      a.tile_done = nullptr; a.dw = dw;
+      if (fold) {
+        int cap = 0;
+        int* cnt = wgrad_pipe_tile_counters(&cap);
+        if (cnt && (int)(grid.x * grid.y) <= cap) a.tile_done = cnt;
+      }
       wgrad_pipe_launch(a, grid, WAVES_C == 2, s);                       // wgrad_pipe.hip
       piped = true;
     }
@@ -784,7 +796,8 @@ static int launch_wgrad(WgradArgs& a, float* dw, hipStream_t s) {
   int rc = check_launch("wgrad_mfma");
   if (rc) return rc;
   const size_t n = (size_t)NTAPS * a.Cin * a.Cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a.part, dw, n / 4, splits, n / 4);
+  if (!(piped && a.tile_done))
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a.part, dw, n / 4, splits, n / 4);
   if (piped && a.db_part) {
     int rc2 = colred_finalize_f32(a.db_part, a.db, (size_t)a.Cout, splits, s);      // db[n] = sum over splits, fp64, fixed order
     if (rc2) return rc2;

@@ -278,6 +278,52 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(W
       pj[(size_t)c * a.Cout + n] = acc[j][r];
     }
   }
+  // Split-K reduction in the kernel (round 4; OPT-IN, GN_WGRAD_FOLD: measured 2.3 % slower on the headline step, see launch_wgrad in conv_mfma.hip --
+  // the fences below cost more than the pass they replace): instead of a separate pass over all partial slabs (wgrad_reduce_kernel: 21 launches and 1.5 ms of
+  // the headline step), the block that arrives LAST at its (Cin tile, Cout tile) sums that tile's slabs -- written microseconds ago by the other
+  // splits -- in split order 0, 1, ..., the order of wgrad_reduce_kernel, so dw is bit-identical.  Release: every thread's stores, then a
+  // device-scope fence, then the block barrier, then ONE atomic per block; acquire: the fence after the counter read (the XCDs' L2s are not
+  // coherent with each other without it).  The last block puts the counter back to zero for the next launch.
+  if (a.tile_done) {
+    __threadfence();
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);                // the stages are free: every wave is past the loop's last barrier
+    const int S = gridDim.z;
+    if (tid == 0) {
+      int* cnt = a.tile_done + ct * (a.Cout / TN) + nt_;
+      const int last = atomicAdd(cnt, 1) == S - 1;
+      if (last) atomicExch(cnt, 0);
+      *flag = last;
+    }
+    __syncthreads();
+    if (*flag) {
+      __threadfence();
+      const size_t tapstride = (size_t)a.Cin * a.Cout, splitstride = (size_t)NTAPS * tapstride;
+      constexpr int V = TC * (TN / 4);                       // float4 values of one tap of the tile
+      // sixteen slab loads in flight per thread, summed in split order afterwards
+      constexpr int KB = 16;
+#pragma unroll 1
+      for (int j = 0; j < NTAPS; ++j)
+#pragma unroll 1
+        for (int idx = tid; idx < V; idx += NT) {
+          const size_t e = j * tapstride + (size_t)(c0 + idx / (TN / 4)) * a.Cout + n0 + 4 * (idx % (TN / 4));
+          float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int k0 = 0; k0 < S; k0 += KB) {
+            float4 v[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+              v[k] = k0 + k < S ? *reinterpret_cast<const float4*>(a.part + (size_t)(k0 + k) * splitstride + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+              if (k0 + k < S) {
+                if (k0 + k == 0) acc4 = v[0];
+                else { acc4.x += v[k].x; acc4.y += v[k].y; acc4.z += v[k].z; acc4.w += v[k].w; }
+              }
+          }
+          *reinterpret_cast<float4*>(a.dw + e) = acc4;
+        }
+    }
+  }
 #endif
 }
 
@@ -294,6 +340,21 @@ static void launch_wgrad_pipe(const WgradArgs& a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((wgrad_pipe_kernel<WAVES_C, WAVES_N, IS>), grid, dim3(64 * WAVES_C * WAVES_N), lds, s, a);
 }
 
+
+// per-tile arrival counters of the folded split-K reduction: zero at load, put back to zero by the last block of every launch (one stream per process)
+constexpr int WGRAD_TILE_COUNTERS = 8192;
+__device__ int g_wgrad_tile_done[WGRAD_TILE_COUNTERS];
+
+int* wgrad_pipe_tile_counters(int* capacity) {
+  static int* ptr = nullptr;
+  if (!ptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wgrad_tile_done)) != hipSuccess) return nullptr;
+    ptr = static_cast<int*>(p);
+  }
+  *capacity = WGRAD_TILE_COUNTERS;
+  return ptr;
+}
 
 void wgrad_pipe_launch(const WgradArgs& a, dim3 grid, bool narrow, hipStream_t s) {
   if (narrow) {
