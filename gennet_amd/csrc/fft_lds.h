@@ -8,7 +8,9 @@ namespace gn {
 
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ double2 cmulf(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// complex product with two fused multiply-adds (the library is built with -ffp-contract=off, so the fusion is spelled out): 4 instead of 6 fp64
+// instructions per product, and the transforms are mostly products -- each component has one rounding less than the unfused form
+__device__ __forceinline__ double2 cmulf(double2 a, double2 b) { return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x)); }
 __device__ __forceinline__ double2 muli(double2 a) { return make_double2(-a.y, a.x); }         // i * a
 
 // inverse (exp(+i ..)) 8-point DFT, natural order in and out

@@ -11,11 +11,17 @@
 // and a[] splits by sample parity into two M-point complex inverse FFTs: a[2n'] = IFFT_M(S)[n'], a[2n'+1] = IFFT_M(S * W_N^k)[n'].
 // The block keeps its M spectrum bins in registers (the cbrt / pow / sincos are evaluated once), runs the M-point transform in LDS
 // (in-place decimation in time, radix-8 stages plus one radix-2/4 stage: 4-5 barriers per transform instead of 12-13) and makes
-// three passes over the ONE LDS buffer: even samples (arg-max only), odd samples (arg-max, emit the odd half of the crop), even
-// samples again (emit the even half) -- a third transform is cheaper than a second 64 KiB buffer, which would halve the blocks per CU.
+// TWO passes over the ONE LDS buffer (round 4; three until then): even samples -- arg-max, and every thread keeps the detector strain
+// (hp Fp + hc Fc) g of its M / NT even samples in registers, ONE double per sample, in the registers the spectrum bins free once the odd
+// pass has loaded them --, then odd samples -- arg-max, the block's ref_idx, the odd half of the crop straight from LDS and the even half
+// from the registers of whichever thread owns the sample (thread np mod NT owns even sample 2 np: the crop position follows from np).
+// A second 64 KiB image would halve the blocks per CU; the third transform this replaces was a third of the kernel's LDS traffic: 10.14 -> 12.61 M
+// templates/s at fs 2048 (1.616 -> 1.299 ms per 16 384).  Measured next and NOT kept: the stage twiddles from a two-level table in LDS (W^i = Tc[i >> 6]
+// Tf[i & 63], 2 KiB) instead of three L2-resident global loads per butterfly -- 12.50 M/s, no change: the transform does not wait for its twiddles.
 // ref_idx = argmax(h+^2 + hx^2) over the rolled series (first maximum), slide = ref_idx - idx - peak_off with python slice
 // semantics, zero fill past the end, exactly as align_crop_kernel (synth.hip) does.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "fft_lds.h"
 #include "noise_chain.h"
@@ -175,7 +181,9 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 1 : 2)) void synth_fused_kernel(S
     }
     __syncthreads();
   };
-  auto argmax_pass = [&](int parity) {
+  double hte[KPT];                                            // even pass: (hp Fp + hc Fc) g of even sample 2 (tid + j NT), crop_value's expression
+  auto argmax_pass = [&](auto par) {
+    constexpr int parity = decltype(par)::value;
     const double sg = parity ? -1.0 : 1.0;
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
@@ -183,6 +191,10 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 1 : 2)) void synth_fused_kernel(S
       const double2 z = d[PH(np)];
       const double hp = fpn * (2.0 * z.x + c.nyq_re * sg), hc = cin * (2.0 * z.y + c.nyq_im * sg);
       const double pw = hp * hp + hc * hc;
+      if constexpr (parity == 0) {
+        const double t1 = hp * a.Fp, t2 = hc * a.Fc;
+        hte[j] = (t1 + t2) * a.g;
+      }
       int n = 2 * np + parity - a.roll;                       // rolled index: rolled[n] = series[(n + roll) mod N]
       if (n < 0) n += N;
       if (pw > best || (pw == best && n < bi)) { best = pw; bi = n; }
@@ -203,34 +215,61 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 1 : 2)) void synth_fused_kernel(S
     return true;
   };
   double keep[KC];                                            // noise mode: the template crop, n = tid + j NT
-  auto emit = [&](int parity) {
+  auto emit_odd = [&]() {                                     // odd samples from the LDS image + the zero fill past the end of the slid series
     if constexpr (NOISE) {
 #pragma unroll
       for (int j = 0; j < KC; ++j) {
         const int n = tid + j * NT;
         double v;
-        if (n < a.crop_len && crop_value(n, parity, &v)) keep[j] = v;
+        if (n < a.crop_len && crop_value(n, 1, &v)) keep[j] = v;
       }
     } else {
       for (int n = tid; n < a.crop_len; n += NT) {
         double v;
-        if (!crop_value(n, parity, &v)) continue;
+        if (!crop_value(n, 1, &v)) continue;
         const size_t o = (size_t)b * a.crop_len + n;
         if (a.out64) a.out64[o] = v;
         if (a.out32) a.out32[o] = (float)v;
       }
     }
   };
+  // even samples from the owners' registers: even sample 2 np sits at rolled index r = (2 np - roll) mod N, i.e. at position r - start of the slid
+  // series and at crop position n = r - start - crop0 (crop_value's map read backwards: sidx = r < N always, so no zero fill here)
+  auto emit_even = [&]() {
+    double* xch = reinterpret_cast<double*>(d);               // noise mode: crop-indexed exchange through the (now free) LDS image
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      int r = 2 * (tid + j * NT) - a.roll;
+      if (r < 0) r += N;
+      const long n = (long)r - start - a.crop0;
+      if (n < 0 || n >= a.crop_len) continue;
+      if constexpr (NOISE) xch[n] = hte[j];
+      else {
+        const size_t o = (size_t)b * a.crop_len + n;
+        if (a.out64) a.out64[o] = hte[j];
+        if (a.out32) a.out32[o] = (float)hte[j];
+      }
+    }
+    if constexpr (NOISE) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        const int n = tid + j * NT;
+        const long sidx = start + a.crop0 + n;
+        if (n < a.crop_len && sidx < N && (((sidx + a.roll) % N) & 1) == 0) keep[j] = xch[n];
+      }
+    }
+  };
 
-  // pass 1: even samples, arg-max only
+  // pass 1: even samples: arg-max, strain values into registers
   load_pass(0);
   ifft_lds<LOGM, NT>(d, a.W);
-  argmax_pass(0);
+  argmax_pass(std::integral_constant<int, 0>{});
   __syncthreads();
   // pass 2: odd samples
   load_pass(1);
   ifft_lds<LOGM, NT>(d, a.W);
-  argmax_pass(1);
+  argmax_pass(std::integral_constant<int, 1>{});
   // block arg-max (first maximum): wave shuffle, then one wave over the per-wave partials
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -256,12 +295,9 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 1 : 2)) void synth_fused_kernel(S
   if (tid == 0 && a.ref_out) a.ref_out[b] = ref;
   start = (long)ref - c.idx - a.peak_off;                  // python slice ht[start:]: negative counts from the end, clamped at 0
   if (start < 0) { start += N; if (start < 0) start = 0; }
-  emit(1);
-  __syncthreads();
-  // pass 3: even samples again, emit
-  load_pass(0);
-  ifft_lds<LOGM, NT>(d, a.W);
-  emit(0);
+  emit_odd();
+  if constexpr (NOISE) __syncthreads();                     // the odd samples have been read: the image becomes the exchange buffer
+  emit_even();
   if constexpr (NOISE) {
     __syncthreads();                                          // every read of the template image is done: the noise chain reuses it
     noise_chain<LOGM, NT>(d, a.nz, b);
@@ -278,13 +314,13 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 1 : 2)) void synth_fused_kernel(S
   }
 }
 
-// fp64 operations per template (the figure roofline_synth prices the kernel with): three M-point transforms (5 M log2 M each), the
-// spectrum (cbrt, pow, sincos and the phase polynomial: ~150 flop per live bin, M bins), the twiddle multiply of the odd pass (6 M),
-// two arg-max passes and the emit (~12 per sample, N samples)
+// fp64 operations per template (the figure roofline_synth prices the kernel with): TWO M-point transforms (5 M log2 M each; three until round 4 --
+// the third was the implementation's, not the algorithm's, and is no longer run or counted), the spectrum (cbrt, pow, sincos and the phase
+// polynomial: ~150 flop per live bin, M bins), the twiddle multiply of the odd pass (6 M), two arg-max passes and the emit (~12 per sample, N samples)
 static double synth_flops_per_template(int M) {
   double l2 = 0;
   for (int m = M; m > 1; m >>= 1) l2 += 1;
-  return 3.0 * 5.0 * M * l2 + 150.0 * M + 6.0 * M + 12.0 * 2.0 * M;
+  return 2.0 * 5.0 * M * l2 + 150.0 * M + 6.0 * M + 12.0 * 2.0 * M;
 }
 double noise_flops_per_row(int M);
 

@@ -35,13 +35,26 @@ def test_short_run_recovers_the_event_and_localises_chirp_mass():
     e_mc, e_q = cnn['mean_abs_error_heldout [mc, q]']
     s_mc, s_q = cnn['prior_std [mc, q]']
     assert e_mc < 0.15 * s_mc and e_q < 0.5 * s_q, (e_mc, e_q, s_mc, s_q)
-    # GAN after 2000 iterations of batch 8 (well before the saturated states the full-budget runs end in, profiles/r03_posterior_validation.json):
-    # the generator's waveforms overlap the clean event (normalised inner product > 0.35 -- the recorded runs show 0.52-0.79 at this point,
-    # an untrained generator ~0), and the chirp-mass read-out of 4000 draws sits within 5 solar masses of the exact posterior's mean
-    # (recorded: 1.1-3.3 with this test's short CNN training; the prior spans 15, the untrained generator reads 15-21 away)
+    # the q head's ReLU(max_value=1) rails (bbhMahoGANy.py:400) are reported, and a trained head is not pinned to them: the prior has q in [0.5, 1], so
+    # nothing may sit at 0 and at most a third of the held-out rows (those with q near 1) at the upper rail
+    rails = cnn['q_head_rails (ReLU(max_value=1), :400)']
+    assert rails['fraction_at_0'] == 0.0 and rails['fraction_at_1'] < 0.34, rails
+    assert rails['mean_abs_error_q_off_rail'] is not None and rails['mean_abs_error_q_off_rail'] < 0.5 * s_q, rails
+    # GAN after 2000 iterations of batch 8.  Round 4 settled what happens later (the discriminator wins outright and the pair falls into a
+    # saturated state of Keras 2.2.4's binary cross-entropy between iteration ~3 000 and ~12 000, in the HIP path AND in the independent torch-CPU port,
+    # profiles/r04_gan_dynamics_*.json), so the test scores the state the loop is in BEFORE that and asserts that it is the non-saturated one:
+    #  * the generator's waveforms overlap the clean event it only ever saw through the discriminator (normalised inner product > 0.35 -- the recorded
+    #    runs show 0.52-0.93 at this point, an untrained generator ~0) and have the event's scale (rms < 3; the saturated states sit at 7-17);
+    #  * neither loss is pinned at a clip value of the cross-entropy: sg_loss < 15 (16.1 = -log 1e-7 is the generator-starved state), sd_loss < 1
+    #    (7.97 = -0.5 log 1e-7 is the discriminator-starved state), and the generator still receives a gradient (sg_loss finite and > 0);
+    #  * the chirp-mass read-out of 4000 draws sits within 5 solar masses of the exact posterior's mean (recorded: 1.1-3.3 with this test's short CNN
+    #    training; the prior spans 15, the untrained generator reads 15-21 away).
     gan = out['gan']
     assert gan['iterations'] == 2000
     assert gan['trajectory'][0]['waveform_overlap_with_clean_event'] < 0.2 and abs(gan['trajectory'][0]['mc_mean'] - ex['mc_mean']) > 8
-    assert gan['final']['waveform_overlap_with_clean_event'] > 0.35, gan['final']
-    assert abs(gan['final']['mc_mean'] - ex['mc_mean']) < 5.0, (gan['final'], ex)
-    assert np.isfinite([gan['final']['q_mean'], gan['final']['mc_std']]).all()
+    fin = gan['final']
+    assert fin['waveform_overlap_with_clean_event'] > 0.35 and fin['waveform_rms'] < 3.0, fin
+    late = [r for r in gan['trajectory'] if r['iteration'] >= 1000]
+    assert late and all(0.0 < r['sg_loss'] < 15.0 and r['sd_loss'] < 1.0 and r['waveform_rms'] < 3.0 for r in late), late
+    assert abs(fin['mc_mean'] - ex['mc_mean']) < 5.0, (fin, ex)
+    assert np.isfinite([fin['q_mean'], fin['mc_std']]).all()
