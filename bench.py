@@ -44,7 +44,7 @@ def pmc_traffic_per_launch():
     """Fabric-side bytes per conv_mfma launch from the committed PMC passes of this same command (profiles/r0N_pmc_traffic.json,
     written by scripts/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs; counters cannot be read from
     inside the timed run).  Newest round first; (None, None) when no file is there."""
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             ks = json.load(open(path))['kernels']
@@ -247,7 +247,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    conv = ops.prof_collect(0); wgrad = ops.prof_collect(1); syn_in_step = ops.prof_collect(3)
+    conv = ops.prof_collect(0); wgrad = ops.prof_collect(1); syn_in_step = ops.prof_collect(3); x3 = ops.prof_collect(2)
     last_losses = {'cnn [total, mc_loss, q_loss, mc_acc, q_acc]': [float(v) for v in last['cnn']],
                    'gan [sg_loss, sg_acc, sd_loss, sd_acc]': [float(v) for v in last['gan']]}
     bad = [k for k, v in last_losses.items() if not np.all(np.isfinite(v))]
@@ -341,6 +341,9 @@ def main():
                                                'algorithmic_flop_per_launch': wgrad['flop'] / max(wgrad['launches'], 1),
                                                'algorithmic_bytes_per_launch': wgrad['bytes'] / max(wgrad['launches'], 1)},
                          'mfma_kernel_time_share': (conv['ms'] + wgrad['ms']) * 1e-3 / dt,
+                         'profiler_note': 'the per-launch figures come from HIP events the library records on the launch stream around every MFMA launch INSIDE the '
+                                          'timed region (two hipEventRecord per launch, ~%d launches per step): their cost is included in value, i.e. counts '
+                                          'against this line' % ((conv['launches'] + wgrad['launches']) // max(args.steps, 1)),
                          'step_algorithmic_tflops': world * WAVES * args.steps * (wl['gflop_cnn'] + wl['gflop_gan']) * 1e-3 / dt},
             'roofline_synth': {'bound': 'valu_f64', 'kernel': 'synth_fused_kernel<.., NOISE=%s> (%s)' % (('true', 'gn_synth_templates_noise: prior + template + coloured whitened noise')
                                                                                                          if wl['online'] else ('false', 'gn_synth_templates_prior')),
@@ -369,11 +372,14 @@ def main():
         }
         conv_math = os.environ.get('GENNET_CONV_MATH', 'fp32')
         if conv_math != 'fp32':      # the opt-in experiment: say so in the line; never the default configuration
-            x3 = ops.prof_collect(2)
             out['dtype'] = 'f32 operands split into 3 bf16 pieces on the large unit-stride conv launches (opt-in GENNET_CONV_MATH=%s), f32 elsewhere' % conv_math
             out['config']['conv_math'] = conv_math
             out['roofline']['bf16x3_launches'] = {'launches': x3['launches'], 'avg_launch_ms': x3['ms'] / max(x3['launches'], 1),
-                                                  'fp32_equivalent_tflops': x3['flop'] / (x3['ms'] * 1e-3) / 1e12 if x3['ms'] > 0 else 0.0}
+                                                  'fp32_equivalent_tflops': x3['flop'] / (x3['ms'] * 1e-3) / 1e12 if x3['ms'] > 0 else 0.0,
+                                                  'ceiling_fp32_equivalent_tflops': 310.0,
+                                                  'note': 'six bf16 products per fp32 product; the bare v_mfma_f32_32x32x16_bf16 stream sustains 1842-1881 TFLOP/s on live '
+                                                          'operands (scripts/mfma_bf16_peak.hip, profiles/r04_mfma_bf16_peak.txt): 307-313 fp32-equivalent is the ceiling; the '
+                                                          'split passes run before every such launch and are NOT inside this figure (they are inside value)'}
         if graphed:          # HIP events are not part of the captured graph: the per-kernel figures are not measured on this line
             for k in ('achieved', 'frac', 'traffic', 'avg_launch_ms'):
                 out['roofline'][k] = None

@@ -31,7 +31,11 @@
 // time, ~4x its LDS load (which was 31 %); the 160 KiB of LDS rules out the larger wave tiles that would cut it.
 // Limits: unit input stride only (the stride-2 slab needs 5 segments per region: 3 x 60 KiB); forward / data-gradient
 // geometry only (no weight gradient); an infinite input comes out as NaN (inf * 0 in a cross term).
+#include <algorithm>
+#include <type_traits>
+#include <stdlib.h>
 #include "common.h"
+#include "conv_epilogue.h"
 
 namespace gn {
 
@@ -288,6 +292,192 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgs a, const u
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same arithmetic on 64 x 64 WAVE tiles (256 x 64 block, four waves stacked in M, unit input stride, 4-5 taps).
+// The kernel above is LDS-bound: per tap a 64 x 32 wave issues 9 fragment reads (ds_read_b128) for 12 MFMAs -- with the staging
+// writes ~98 % of the CU's 128 B/cycle.  A 64 x 64 wave tile issues 12 reads for 24 MFMAs (A: 3 planes x 2 row tiles, B: 3 planes x
+// 2 column tiles): half the LDS bytes per MFMA, ~65 % with the staging.  One chunk is then 5 x 24 MFMAs = 3840 matrix cycles
+// (1.6 us), longer than the ~1.1 us an LDS-DMA takes to land, so TWO stages of 60 KiB suffice: chunk c+2 is issued right behind the
+// barrier that frees chunk c's stage (in front of chunk c's last tap) and retired by vmcnt(0) at the next barrier.
+// Block -> tile: XCD k (block i -> XCD i mod 8) takes a contiguous eighth of the (slab, column tile) list, so an input slab -- 6 bytes
+// per element here -- is fetched through one L2 and serves all its column tiles from there.
+// Ceiling (scripts/mfma_bf16_peak.hip): the bare six-product stream sustains 307-313 TFLOP/s fp32-equivalent on live data.
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ABL (timing experiments only, GN_BF16X3_ABL; results are wrong for ABL != 0): bit 0 = no fragment reads in the loop, bit 1 = no staging in the
+// loop, bit 2 = no epilogue
+template <int NTAPS, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, const unsigned short* __restrict__ xs, const unsigned short* __restrict__ ws,
+                                                                  size_t x_plane, size_t w_plane, int m_tiles, int n_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(NTAPS >= 4 && NTAPS <= 5, "a chunk must outlast the staging latency: 4 or 5 taps");
+  constexpr int TM = 256, TN = 64, ASEG = 5;
+  constexpr int A_BYTES = 6 * ASEG * 1024, B_BYTES = 6 * NTAPS * 1024, STAGE = A_BYTES + B_BYTES;
+  constexpr int Q_TOTAL = 6 * ASEG + 6 * NTAPS;            // wave-level DMA instructions per chunk
+  constexpr int Q_WAVE = (Q_TOTAL + 3) / 4;                // ... per wave
+  constexpr int Q_FIRST = (Q_WAVE + 1) / 2;                // issued behind the barrier (last tap of chunk c); the rest in tap 0 of chunk c + 1
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i32 = lane & 31, h = lane >> 5;
+  int lin = blockIdx.x;
+  const int nb = gridDim.x;
+  if (lin < (nb & ~7)) lin = (lin & 7) * (nb >> 3) + (lin >> 3);
+  const int n_tile = lin % n_tiles;
+  const int rest = lin / n_tiles;
+  const int m_tile = rest % m_tiles;
+  const int b = rest / m_tiles;
+  const int m0 = m_tile * TM, n0 = n_tile * TN;
+
+  int minoff = a.t.off[0], maxoff = a.t.off[0];
+#pragma unroll
+  for (int j = 1; j < NTAPS; ++j) {
+    minoff = min(minoff, a.t.off[j]);
+    maxoff = max(maxoff, a.t.off[j]);
+  }
+  const int R = (TM - 1) + (maxoff - minoff) + 1;          // <= 260 staged rows (the launcher checks the taps span <= 5 rows)
+  const int n_chunks = a.Cin >> 4;
+  const int Lg = a.Lin + 2;
+  const int t_base = m0 + minoff;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const unsigned short* src[Q_WAVE];
+  int dst[Q_WAVE];
+  size_t step[Q_WAVE];
+#pragma unroll
+  for (int i = 0; i < Q_WAVE; ++i) {
+    int q = wm + 4 * i;
+    if (q >= Q_TOTAL) q = Q_TOTAL - 1;                      // padding instruction: repeats the last one (same bytes, same place)
+    if (q < 6 * ASEG) {
+      const int ph = q / ASEG, seg = q % ASEG;
+      const int r = seg * 64 + lane;
+      const int t = t_base + r;
+      const int row = (r < R && t >= 0 && t < a.Lin) ? t + 1 : 0;                           // 0 = the leading zero guard row
+      src[i] = xs + (ph >> 1) * x_plane + ((((size_t)b * n_chunks) * 2 + (ph & 1)) * Lg + row) * 8;
+      dst[i] = q * 1024;
+      step[i] = (size_t)2 * Lg * 8;
+    } else {
+      const int qb = q - 6 * ASEG;
+      const int pt = qb >> 1, hh = qb & 1;
+      const int p = pt / NTAPS, tap = pt % NTAPS;
+      src[i] = ws + p * w_plane + ((((size_t)a.t.widx[tap] * n_chunks) * 2 + hh) * a.Cout + n0 + lane) * 8;
+      dst[i] = A_BYTES + qb * 1024;
+      step[i] = (size_t)2 * a.Cout * 8;
+    }
+  }
+  bool in_loop = false;
+  auto dma_one = [&](int i, int c, unsigned char* stage) {
+    if ((ABL & 2) && in_loop) return;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)c * step[i]), (lptr_t)(stage + dst[i]), 16, 0, 0);
+  };
+  auto read_tap = [&](const unsigned char* sa, int j, bf16x8 (&av)[3][2], bf16x8 (&bv)[3][2]) {
+    if ((ABL & 1) && in_loop) return;
+    const int rowbase = a.t.off[j] - minoff;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        av[p][mt] = *reinterpret_cast<const bf16x8*>(sa + ((p * 2 + h) * (ASEG * 64) + rowbase + wm * 64 + mt * 32 + i32) * 16);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        bv[p][nt] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + (((p * NTAPS + j) * 2 + h) * 64 + nt * 32 + i32) * 16);
+    }
+  };
+  auto mma_tap = [&](const bf16x8 (&av)[3][2], const bf16x8 (&bv)[3][2]) {
+    // smallest terms first: hi*lo, lo*hi, mid*mid, then hi*mid, mid*hi, then hi*hi
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[q]][mt], bv[PB[q]][nt], acc[mt][nt], 0, 0, 0);
+  };
+
+  // ---- prologue: chunks 0 and 1 staged and landed
+#pragma unroll
+  for (int i = 0; i < Q_WAVE; ++i) dma_one(i, 0, smem_b);
+#pragma unroll
+  for (int i = 0; i < Q_WAVE; ++i) dma_one(i, min(1, n_chunks - 1), smem_b + STAGE);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 fa[2][3][2], fb[2][3][2];                          // fragment double buffer: the tap with running parity P reads from [P], prefetches into [P ^ 1]
+  read_tap(smem_b, 0, fa[0], fb[0]);
+  // one chunk; P0 = buffer parity of its tap 0 (compile time: with five taps per chunk the parity alternates from chunk to chunk)
+  auto do_chunk = [&](int ch, auto p0) {
+    constexpr int P0 = decltype(p0)::value;
+    unsigned char* sa = smem_b + (ch & 1) * STAGE;
+    unsigned char* sb = smem_b + ((ch + 1) & 1) * STAGE;
+    const int c_dma1 = min(ch + 1, n_chunks - 1);           // second half of chunk ch+1's staging (into sb; the first half went out in chunk ch-1's last tap)
+    const int c_dma2 = min(ch + 2, n_chunks - 1);           // first half of chunk ch+2's staging (into sa, once the barrier below has freed it)
+#pragma unroll
+    for (int j = 0; j < NTAPS; ++j) {
+      constexpr int dummy = 0; (void)dummy;
+      const int P = (P0 + j) & 1;
+      __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): this tap's fragments are in registers
+      __builtin_amdgcn_sched_barrier(0);
+      int ndma = 0;
+      if (j + 1 < NTAPS) {
+        if (j == 0 && ch > 0) {
+#pragma unroll
+          for (int i = Q_FIRST; i < Q_WAVE; ++i) dma_one(i, c_dma1, sb);
+          ndma = Q_WAVE - Q_FIRST;
+        }
+        read_tap(sa, j + 1, fa[P ^ 1], fb[P ^ 1]);
+      } else {
+        // every read of stage sa has landed (lgkmcnt(0) above, on every wave once past the barrier); chunk ch+1 must have landed
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < Q_FIRST; ++i) dma_one(i, c_dma2, sa);      // (past the end: one harmless re-stage of the last chunk keeps the count uniform)
+        ndma = Q_FIRST;
+        if (ch + 1 < n_chunks) read_tap(sb, 0, fa[P ^ 1], fb[P ^ 1]);
+      }
+      mma_tap(fa[P], fb[P]);
+      // 24 MFMAs with the 12 fragment reads of the next tap (and this tap's share of the staging) between them
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (k < ndma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  in_loop = true;
+  if constexpr (NTAPS % 2 == 0) {
+    for (int ch = 0; ch < n_chunks; ++ch) do_chunk(ch, std::integral_constant<int, 0>{});
+  } else {
+    for (int ch = 0; ch < n_chunks; ch += 2) {
+      do_chunk(ch, std::integral_constant<int, 0>{});
+      if (ch + 1 < n_chunks) do_chunk(ch + 1, std::integral_constant<int, 1>{});
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): drain the trailing DMAs before the block may end
+
+  if constexpr ((ABL & 4) != 0) {
+    if (acc[0][0][0] == 12345.678f) a.y[0] = acc[0][0][0] + acc[1][1][15] + acc[0][1][3] + acc[1][0][7];      // keeps the accumulators alive
+    return;
+  }
+  // the lean epilogue of the hand-scheduled fp32 kernel (conv_epilogue.h): activation / fused variants decided once per wave, buffer stores with a
+  // scalar row offset, rows past M dropped by the descriptor's range check -- the generic per-element epilogue cost 10 % of this kernel's time at
+  // one block per CU (2.92 against 3.25 ms on G 512 -> 1024 at batch 64 without it)
+  const int mode = a.gy ? (a.gmask ? 3 : 2) : (a.mask ? 1 : 0);
+  pipe_epilogue_dispatch<2>(a, acc, b, m0 + wm * 64, n0, i32, h, a.t.out_off, mode);
+#endif
+}
+
 size_t conv_bf16x3_workspace_bytes(int B, int Lin, int Cin, int Cout, int w_taps) {
   return 6 * ((size_t)B * (Lin + 2) * Cin + (size_t)w_taps * Cin * Cout) + 256;
 }
@@ -338,10 +528,53 @@ static int launch_bf16x3(const ConvArgs& a, int w_taps, void* ws, hipStream_t s)
   return check_launch("conv_bf16x3");
 }
 
+template <int NTAPS, int ABL = 0>
+static int launch_bf16x3_wide(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
+  constexpr size_t lds = 2 * ((size_t)6 * 5 * 1024 + (size_t)6 * NTAPS * 1024);
+  static_assert(lds <= 160 * 1024, "two stages must fit the CU's LDS");
+  static unsigned long long lds_done = 0;
+  allow_big_lds((const void*)conv_bf16x3_wide_kernel<NTAPS, ABL>, &lds_done);
+  const int m_tiles = (a.M + 255) / 256, n_tiles = a.Cout / 64;
+  const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
+  if (blocks == 0 || blocks > 0x7fffffffull) {
+    set_error("conv_bf16x3_wide: bad grid %zu", blocks);
+    return GN_EINVAL;
+  }
+  const size_t xn = (size_t)a.B * (a.Lin + 2) * a.Cin, wn = (size_t)w_taps * a.Cin * a.Cout;
+  const unsigned short* xs = (const unsigned short*)ws;
+  const unsigned short* wsp = xs + 3 * xn;
+  prof_begin(s);
+  hipLaunchKernelGGL((conv_bf16x3_wide_kernel<NTAPS, ABL>), dim3((unsigned)blocks), dim3(256), lds, s, a, xs, wsp, xn, wn, m_tiles, n_tiles);
+  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 2);
+  return check_launch("conv_bf16x3_wide");
+}
+
 int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
   if (!conv_bf16x3_supported(a)) {
     set_error("conv_bf16x3: shape not supported (Cin %% 16, Cout %% 64, taps <= 5, unit input stride)");
     return GN_EINVAL;
+  }
+  // 64 x 64 wave tiles in 256-row blocks for the 4- / 5-tap launches whose rows fill them (round 4); GN_BF16X3_NARROW keeps round 1's kernel
+  static const bool narrow = getenv("GN_BF16X3_NARROW") != nullptr;
+  if (!narrow && a.t.ntaps >= 4 && a.M >= 192) {
+    int minoff = a.t.off[0], maxoff = a.t.off[0];
+    for (int j = 1; j < a.t.ntaps; ++j) {
+      minoff = std::min(minoff, a.t.off[j]);
+      maxoff = std::max(maxoff, a.t.off[j]);
+    }
+    if (maxoff - minoff + 1 <= 5) {
+      static const int abl = getenv("GN_BF16X3_ABL") ? atoi(getenv("GN_BF16X3_ABL")) : 0;      // timing experiments: wrong results
+      if (abl && a.t.ntaps == 5) {
+        switch (abl) {
+          case 1: return launch_bf16x3_wide<5, 1>(a, w_taps, ws, s);
+          case 2: return launch_bf16x3_wide<5, 2>(a, w_taps, ws, s);
+          case 3: return launch_bf16x3_wide<5, 3>(a, w_taps, ws, s);
+          case 4: return launch_bf16x3_wide<5, 4>(a, w_taps, ws, s);
+          default: return launch_bf16x3_wide<5, 7>(a, w_taps, ws, s);
+        }
+      }
+      return a.t.ntaps == 4 ? launch_bf16x3_wide<4>(a, w_taps, ws, s) : launch_bf16x3_wide<5>(a, w_taps, ws, s);
+    }
   }
   switch (a.t.ntaps) {
     case 1: return launch_bf16x3<1, 3>(a, w_taps, ws, s);

@@ -19,6 +19,9 @@ CASES = [
     (2, 100, 32, 64, 2, 'valid'),        # 2 taps: 30 DMA instructions over 4 waves -> two padding instructions
     (2, 131, 48, 128, 4, 'same'),        # 4 taps: 42 -> two padding instructions; asymmetric SAME padding
     (1, 256, 512, 1024, 5, 'same'),      # the dominant generator layer's channels
+    (2, 400, 32, 64, 4, 'same'),         # round 4's 256-row blocks of 64 x 64 wave tiles: 4 taps, ragged second tile, two chunks
+    (3, 700, 80, 192, 5, 'valid'),       # ... 5 taps, odd chunk count (the fragment double buffer's parity alternates per chunk), 3 N tiles, 3 M tiles
+    (1, 192, 16, 64, 5, 'same'),         # ... one chunk only
 ]
 
 
@@ -70,3 +73,43 @@ def test_bf16x3_rejects_unsupported_shapes():
     x = torch.zeros(1, 64, 32, device=dev); w = torch.ones(5, 32, 64, device=dev)
     with pytest.raises(_lib.GennetHipError):
         ops.conv1d_fwd_bf16x3(x, w, b, 2, 1, 32)                                  # stride 2 is not implemented
+
+
+def test_gan_iteration_under_the_opt_in_split_meets_the_fp32_path_tolerances():
+    """The opt-in conv math on the whole path (ops.set_conv_math('bf16x3'): the generator's 256 -> 512 and 512 -> 1024 convolutions, forward and
+    data gradient, run as six bf16 products on 64 x 64 wave tiles) against the fp64 oracle with the SAME tolerances as
+    test_nets_gpu.test_gan_iteration_matches_oracle asserts for the exact-fp32 kernels: losses 2e-5, gradients 3e-4 of each tensor's largest
+    entry (+ 1e-6 of the largest gradient), generator.predict 5e-5.  n_pix 256: the two layers' rows (256) fill the 256-row blocks."""
+    from gennet_amd import bbh, ops
+    from gennet_amd.engine import to_device
+    from oracle import nets_ref as N                                                   # noqa: F401
+    import test_nets_gpu as T
+    n_pix, B = 256, 3
+    rng = np.random.RandomState(17)
+    ref, nets, event = T._build_gan(n_pix, rng)
+    G, D, DG = nets.generator, nets.signal_discriminator, nets.signal_discriminator_on_generator
+    ops.prof_enable(True); ops.prof_reset()
+    ops.set_conv_math('bf16x3', workspace_gb=0.5)
+    try:
+        z = T.f32(rng.uniform(-1, 1, (B, 100)))
+        fake_ref = ref.generate(z)
+        assert T.rel(G.predict(z), fake_ref) < 5e-5
+        z2 = T.f32(rng.uniform(-1, 1, (B, 100)))
+        g_masks = T.stack_masks(ref.G, z2, rng)
+        d_masks2 = T.stack_masks(ref.D, K.mylayer_fwd(ref.G.forward(z2, False), ref.event), rng)
+        names = dict(T.masks_by_name(ref.G, g_masks, G.layers)); names.update(T.masks_by_name(ref.D, d_masks2, D.layers))
+        cap = {}
+        out = DG.train_on_batch(z2, [1] * B, dropout_masks=names, capture=cap)
+        out_ref = ref.g_train_on_batch(z2, [1] * B, g_masks, d_masks2, T.decisions_for(ref.D, D.layers, cap))
+        del cap
+        T.assert_decisions_consistent(ref.D)
+        assert abs(out[0] - out_ref[0]) <= 2e-5 * abs(out_ref[0]) and out[1] == pytest.approx(out_ref[1])
+        ggr = [p.grad.cpu().numpy() for l in G.layers for p in l.params]
+        gmax = max(np.abs(gr).max() for gr in ref.last_g_grads)
+        for k, (gq, gr) in enumerate(zip(ggr, ref.last_g_grads)):
+            assert np.abs(gq - gr).max() <= 3e-4 * np.abs(gr).max() + 1e-6 * gmax, (k, T.rel(gq, gr))
+        used = ops.prof_collect(2)['launches']
+    finally:
+        ops.set_conv_math('fp32')
+        ops.prof_enable(False)
+    assert used >= 4, used              # predict (2 layers) + train forward (2) + data gradients: the split kernels really ran
