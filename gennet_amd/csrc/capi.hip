@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <mutex>
 #include <vector>
+#include <stdlib.h>
 #include "common.h"
 
 namespace gn {
@@ -86,7 +87,11 @@ static size_t g_conv_ws_bytes = 0;
 static int conv_dispatch(const ConvArgs& a, hipStream_t s) {
   if (a.Cin <= 4) return conv_smallcin_dispatch(a, s);
   if (a.Cout <= 4) return conv_smallcout_dispatch(a, s);
-  if (g_conv_math == 1 && a.Cin >= 256 && a.Cout >= 256 && conv_bf16x3_supported(a)) {
+  // size threshold of the opt-in split (A/B: GN_BF16X3_MIN_CIN / GN_BF16X3_MIN_COUT): the split pass costs ~10 bytes per input element per launch,
+  // the conv gains ~0.02 ps per element and output channel, so small-Cout layers gain little and small-Cin layers (few K chunks) lose to the prologue
+  static const int min_cin = getenv("GN_BF16X3_MIN_CIN") ? atoi(getenv("GN_BF16X3_MIN_CIN")) : 256;
+  static const int min_cout = getenv("GN_BF16X3_MIN_COUT") ? atoi(getenv("GN_BF16X3_MIN_COUT")) : 256;
+  if (g_conv_math == 1 && a.Cin >= min_cin && a.Cout >= min_cout && conv_bf16x3_supported(a)) {
     int w_taps = 0;
     for (int j = 0; j < a.t.ntaps; ++j) w_taps = std::max(w_taps, a.t.widx[j] + 1);
     if (conv_bf16x3_workspace_bytes(a.B, a.Lin, a.Cin, a.Cout, w_taps) <= g_conv_ws_bytes) {
