@@ -478,6 +478,14 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
 #endif
 }
 
+// Measured and NOT kept (round 4): a wave-specialised form -- a fifth "producer" wave issues all 60 LDS-DMA instructions of a chunk, the four MFMA
+// waves only read fragments and multiply.  The ablation above reads as if the 12 % were the cost of issuing the staging from the MFMA waves; it is
+// not: with the producer wave the kernel runs at the same 226-228 TFLOP/s, so what the staging costs is LDS bandwidth shared with the fragment
+// reads (12 ds_read_b128 per 24 MFMAs and wave, the same B fragments read by all four waves), not instruction issue.  (One trap on the way: a raw
+// __builtin_amdgcn_s_barrier() is IntrNoMem, and along a code path with no visible store to LDS -- the MFMA waves, whose stages only LDS-DMA of
+// ANOTHER wave writes -- the optimiser treats LDS as invariant and reuses fragment loads from two chunks earlier: deterministic garbage in every
+// second row tile until the barrier was written as asm volatile("s_barrier" ::: "memory").)
+
 size_t conv_bf16x3_workspace_bytes(int B, int Lin, int Cin, int Cout, int w_taps) {
   return 6 * ((size_t)B * (Lin + 2) * Cin + (size_t)w_taps * Cin * Cout) + 256;
 }
