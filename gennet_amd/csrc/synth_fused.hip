@@ -327,7 +327,8 @@ double noise_flops_per_row(int M);
 template <int LOGM, int NT>
 static int launch_synth(const SynthArgs& a, hipStream_t s) {
   constexpr int M = 1 << LOGM;
-  const size_t lds = (size_t)(M + M / 8) * sizeof(double2) + sizeof(ChirpCoeffsF) + 16 * sizeof(double) + 16 * sizeof(int);
+  static const size_t lds_pad = getenv("GN_SYNTH_LDS_PAD") ? (size_t)atoi(getenv("GN_SYNTH_LDS_PAD")) : 0;      // experiment: force fewer blocks per CU
+  const size_t lds = (size_t)(M + M / 8) * sizeof(double2) + sizeof(ChirpCoeffsF) + 16 * sizeof(double) + 16 * sizeof(int) + lds_pad;
   const bool noise = a.nz.amp != nullptr;
   if (noise && a.crop_len > M / 2) {
     set_error("synth_templates: noise mode needs crop_len <= N/4 (crop %d, N %d)", a.crop_len, 2 * M);

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void mfma16_kernel(float* out, int iters) {
 // or buffer_load ... lds with a 32-bit lane offset and the chunk offset in an SGPR (MODE 2), all issued after the barrier or (SPREAD) one
 // every 80 / NDMA MFMAs.  Addresses are shared by the blocks of a slab group (8 groups), so most loads are L2 hits, as in the kernel; they
 // are drained (vmcnt(0)) in front of the barrier.  Says which piece the gap between the bare pipe and the kernel belongs to.
-template <bool LDS_READS, int MODE, int NDMA, int SZ, bool SPREAD>
+// TAPS (round 4): 5 = the 80-MFMA chunk of the 5-tap kernels; 3 / 2 = the 48- / 32-MFMA chunks of the stride-2 data gradient's phases
+template <bool LDS_READS, int MODE, int NDMA, int SZ, bool SPREAD, int TAPS = 5>
 __global__ __launch_bounds__(256) void chunk_loop_kernel(float* out, int iters, const float* src, unsigned src_mask) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) float lds[9216];           // 36 KiB: four blocks per CU, as the kernel
@@ -105,11 +106,11 @@ __global__ __launch_bounds__(256) void chunk_loop_kernel(float* out, int iters, 
       for (int k = 0; k < NDMA; ++k) dma(i, k);
     }
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < TAPS; ++t) {
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
         if constexpr (MODE != 0 && SPREAD) {
-          constexpr int every = 20 / (NDMA < 20 ? NDMA : 20);
+          constexpr int every = (4 * TAPS) / (NDMA < 4 * TAPS ? NDMA : 4 * TAPS);
           if ((t * 4 + st) % every == 0 && (t * 4 + st) / every < NDMA) dma(i, (t * 4 + st) / every);
         }
         if constexpr (LDS_READS) {
@@ -240,7 +241,7 @@ static void run_tiles(const char* name, int mode, int cus, float* out, const flo
 }
 
 template <typename K>
-static void run_chunk(const char* name, K kernel, int cus, int blocks_per_cu, float* out, const float* src, unsigned src_mask) {
+static void run_chunk(const char* name, K kernel, int cus, int blocks_per_cu, float* out, const float* src, unsigned src_mask, int mfmas_per_chunk = 80) {
   const int blocks = cus * blocks_per_cu;
   const int iters = 16000 / blocks_per_cu;
   hipEvent_t e0, e1;
@@ -256,7 +257,7 @@ static void run_chunk(const char* name, K kernel, int cus, int blocks_per_cu, fl
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     if (ms < best) best = ms;
   }
-  const double tf = (double)blocks * 4 * iters * 80 * 4096.0 / (best * 1e-3) / 1e12;
+  const double tf = (double)blocks * 4 * iters * mfmas_per_chunk * 4096.0 / (best * 1e-3) / 1e12;
   printf("%-44s blocks/CU %d  %8.3f ms  %7.2f TFLOP/s  %.4f of 157.3\n", name, blocks_per_cu, best, tf, tf / 157.3);
 }
 
@@ -315,6 +316,12 @@ int main() {
     run_chunk("  + 24 buffer_load lds x 4 B", chunk_loop_kernel<true, 2, 24, 4, false>, cus, w, out, src, mask);
     run_chunk("  + 6 buffer_load lds x 16 B, spread", chunk_loop_kernel<true, 2, 6, 16, true>, cus, w, out, src, mask);
     run_chunk("  + 6 buffer x 16 B, no operand reads", chunk_loop_kernel<false, 2, 6, 16, false>, cus, w, out, src, mask);
+  }
+  // the short-tap chunks of the stride-2 data gradient's two phases (48 / 32 MFMAs per barrier), reads + 5 spread staging pieces, as the kernel runs them
+  for (int w : {1, 2, 4}) {
+    run_chunk("48 MFMAs + barrier + reads + 5 spread pieces", chunk_loop_kernel<true, 2, 5, 16, true, 3>, cus, w, out, src, mask, 48);
+    run_chunk("32 MFMAs + barrier + reads + 4 spread pieces", chunk_loop_kernel<true, 2, 4, 16, true, 2>, cus, w, out, src, mask, 32);
+    run_chunk("32 MFMAs + barrier only", chunk_loop_kernel<false, 0, 0, 16, false, 2>, cus, w, out, src, mask, 32);
   }
   float* sink;
   CHECK(hipMalloc(&sink, (size_t)1 << 30));
