@@ -283,10 +283,10 @@ def main():
         # validates its own exchange step; a mismatch is an error, not a footnote
         expect = dist.expected_collectives(nets, WAVES // CNN_BATCH)
         coll['expected'] = expect
-        if (coll['calls'], coll['bytes']) != (expect['calls'], expect['bytes']):
+        coll['matches_expected'] = (coll['calls'], coll['bytes']) == (expect['calls'], expect['bytes'])
+        if not coll['matches_expected']:      # the line is still printed (the measurement is not thrown away); the process then exits 4
             sys.stderr.write('bench.py: rank %d: one step issued %d all-reduces / %d bytes, the models\' shapes say %d / %d (%r)\n'
                              % (rank, coll['calls'], coll['bytes'], expect['calls'], expect['bytes'], expect['parts']))
-            sys.exit(4)
         coll.update(step_ms=1e3 * t_coll_step, share_of_step=(coll['ms'] * 1e-3 / t_coll_step) if coll['ms'] is not None else None,
                     note='all-reduces of ONE step on rank 0 (flat gradient buffers of the CNN x2, D, G; SyncBN sums; loss scalars), event-bracketed on the '
                          'launch stream; they are not overlapped with compute, so ms is their whole cost to the step (it includes waiting for the slowest rank)')
@@ -393,6 +393,8 @@ def main():
     if dp:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+        if coll is not None and not coll['matches_expected']:
+            sys.exit(4)
 
 
 if __name__ == '__main__':
