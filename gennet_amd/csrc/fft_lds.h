@@ -48,7 +48,9 @@ __device__ __forceinline__ int digitrev(int k) {
   return p;
 }
 
-template <int LOGM, int NT>
+// WS: stride of the twiddle table.  W holds exp(+2 pi i k / N) for the caller's N; a transform of M points wants the table of N' = 2 M, which is
+// every (N / N')-th entry: WS = N / (2 M)  (1 for the M = N / 2 transforms, 2 for the quarter transforms of synth_fused.hip).
+template <int LOGM, int NT, int WS = 1>
 __device__ void ifft_lds(double2* d, const double2* __restrict__ W) {
   constexpr int M = 1 << LOGM, NR8 = LOGM / 3, REM = LOGM % 3;
   const int tid = threadIdx.x;
@@ -64,7 +66,7 @@ __device__ void ifft_lds(double2* d, const double2* __restrict__ W) {
       for (int q = 0; q < 8; ++q) a[q] = d[PH(base + (q << lspan))];
       if (s > 0) {
         const int i1 = pos << lstep;
-        const double2 w1 = W[i1], w2 = W[2 * i1], w4 = W[4 * i1];
+        const double2 w1 = W[WS * i1], w2 = W[WS * 2 * i1], w4 = W[WS * 4 * i1];
         const double2 w3 = cmulf(w1, w2);
         a[1] = cmulf(a[1], w1); a[2] = cmulf(a[2], w2); a[3] = cmulf(a[3], w3); a[4] = cmulf(a[4], w4);
         a[5] = cmulf(a[5], cmulf(w4, w1)); a[6] = cmulf(a[6], cmulf(w4, w2)); a[7] = cmulf(a[7], cmulf(w4, w3));
@@ -79,7 +81,7 @@ __device__ void ifft_lds(double2* d, const double2* __restrict__ W) {
     constexpr int lspan = 3 * NR8, span = 1 << lspan;        // last stage: span = M / 2, table step N / (2 span) = 2
     for (int bf = tid; bf < M / 2; bf += NT) {
       const int pos = bf & (span - 1);
-      const double2 x0 = d[PH(pos)], x1 = cmulf(d[PH(pos + span)], W[pos << 1]);
+      const double2 x0 = d[PH(pos)], x1 = cmulf(d[PH(pos + span)], W[WS * (pos << 1)]);
       d[PH(pos)] = cadd(x0, x1);
       d[PH(pos + span)] = csub(x0, x1);
     }
@@ -89,7 +91,7 @@ __device__ void ifft_lds(double2* d, const double2* __restrict__ W) {
     for (int bf = tid; bf < M / 4; bf += NT) {
       const int pos = bf & (span - 1);
       const int i1 = pos << 1;
-      const double2 w1 = W[i1], w2 = W[2 * i1];
+      const double2 w1 = W[WS * i1], w2 = W[WS * 2 * i1];
       const double2 u0 = d[PH(pos)], u1 = cmulf(d[PH(pos + span)], w1), u2 = cmulf(d[PH(pos + 2 * span)], w2), u3 = cmulf(d[PH(pos + 3 * span)], cmulf(w1, w2));
       const double2 s02 = cadd(u0, u2), d02 = csub(u0, u2), s13 = cadd(u1, u3), d13 = muli(csub(u1, u3));
       d[PH(pos)] = cadd(s02, s13);

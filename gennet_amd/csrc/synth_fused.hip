@@ -9,15 +9,17 @@
 // so with the one-sided complex series a[n] = sum_{k<M} S[k] exp(+2 pi i k n / N):
 //     irfft(h+~)[n] = fp/N * (2 Re a[n] + Re S[M] (-1)^n),   irfft(hx~)[n] = ci/N * (2 Im a[n] + Im S[M] (-1)^n)
 // and a[] splits by sample parity into two M-point complex inverse FFTs: a[2n'] = IFFT_M(S)[n'], a[2n'+1] = IFFT_M(S * W_N^k)[n'].
-// The block keeps its M spectrum bins in registers (the cbrt / pow / sincos are evaluated once), runs the M-point transform in LDS
-// (in-place decimation in time, radix-8 stages plus one radix-2/4 stage: 4-5 barriers per transform instead of 12-13) and makes
-// TWO passes over the ONE LDS buffer (round 4; three until then): even samples -- arg-max, and every thread keeps the detector strain
-// (hp Fp + hc Fc) g of its M / NT even samples in registers, ONE double per sample, in the registers the spectrum bins free once the odd
-// pass has loaded them --, then odd samples -- arg-max, the block's ref_idx, the odd half of the crop straight from LDS and the even half
-// from the registers of whichever thread owns the sample (thread np mod NT owns even sample 2 np: the crop position follows from np).
-// A second 64 KiB image would halve the blocks per CU; the third transform this replaces was a third of the kernel's LDS traffic: 10.14 -> 12.61 M
-// templates/s at fs 2048 (1.616 -> 1.299 ms per 16 384).  Measured next and NOT kept: the stage twiddles from a two-level table in LDS (W^i = Tc[i >> 6]
-// Tf[i & 63], 2 KiB) instead of three L2-resident global loads per butterfly -- 12.50 M/s, no change: the transform does not wait for its twiddles.
+// The block keeps its M spectrum bins in registers (the cbrt / pow / sincos are evaluated once) and runs the transforms in ONE LDS buffer
+// (in-place decimation in time, radix-8 stages plus one radix-2/4 stage: 4-5 barriers per transform instead of 12-13), in one of two forms
+// (round 4; three M-point passes until then):
+//   M >= 4096 (fs >= 2048): TWO M-point passes -- even samples (arg-max; every thread keeps the detector strain (hp Fp + hc Fc) g of its M / NT even
+//     samples in registers, ONE double per sample, in the registers the spectrum bins free once the odd pass has loaded them), then odd samples
+//     (arg-max, the block's ref_idx, the odd half of the crop straight from LDS, the even half from the registers of whichever thread owns the sample:
+//     thread np mod NT owns even sample 2 np, the crop position follows from np).  10.14 -> 12.9 M templates/s at fs 2048 against three passes.
+//   M <= 2048 (fs <= 1024): FOUR M/2-point passes in a half-size image after one radix-2 step in registers (see the kernel): four workgroups per CU
+//     instead of two, 16.2 -> 21.0 M templates/s at fs 1024; at the larger sizes the registers it needs do not fit four waves per SIMD and it loses.
+// Measured and NOT kept: the stage twiddles from a two-level table in LDS (W^i = Tc[i >> 6] Tf[i & 63], 2 KiB) instead of three L2-resident global loads
+// per butterfly -- no change: the transform does not wait for its twiddles.
 // ref_idx = argmax(h+^2 + hx^2) over the rolled series (first maximum), slide = ref_idx - idx - peak_off with python slice
 // semantics, zero fill past the end, exactly as align_crop_kernel (synth.hip) does.
 #include <stdlib.h>
@@ -115,12 +117,16 @@ __device__ __forceinline__ double2 chirp_bin(const ChirpCoeffsF& c, int k, doubl
   return make_double2(amp * cs * w, -amp * sn * w);       // h = amp * exp(-i phase)
 }
 
-template <int LOGM, int NT, bool NOISE>
-__global__ __launch_bounds__(NT, (NT >= 1024 ? 1 : 2)) void synth_fused_kernel(SynthArgs a) {
+// OCC: waves per SIMD the register allocation must allow (0: 1 for 1024 threads, 2 with the noise chain, 4 without)
+template <int LOGM, int NT, bool NOISE, int OCC = 0>
+__global__ __launch_bounds__(NT, (OCC ? OCC : (NT >= 1024 ? 1 : ((NOISE || LOGM > 11) ? 2 : 4)))) void synth_fused_kernel(SynthArgs a) {
   constexpr int M = 1 << LOGM, N = 2 * M, KPT = M / NT, KC = (KPT + 1) / 2;      // KC crop samples per thread in noise mode (crop_len <= M/2 = N/4)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double2* d = reinterpret_cast<double2*>(smem_raw);                                           // PH(M) padded complex values
-  ChirpCoeffsF* cf = reinterpret_cast<ChirpCoeffsF*>(smem_raw + (size_t)(M + M / 8) * sizeof(double2));
+  // the image: M / 2 complex slots (+ padding) for the template's quarter transforms; the noise chain (NOISE) runs M-point transforms in the same buffer
+  constexpr bool QUARTER = LOGM <= 11;
+  constexpr int IMG = (NOISE || !QUARTER) ? (M + M / 8) : (M / 2 + M / 16);
+  ChirpCoeffsF* cf = reinterpret_cast<ChirpCoeffsF*>(smem_raw + (size_t)IMG * sizeof(double2));
   double* rv = reinterpret_cast<double*>(cf + 1);                                              // per-wave arg-max partials
   int* ri = reinterpret_cast<int*>(rv + 16);
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -171,133 +177,248 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 1 : 2)) void synth_fused_kernel(S
   double best = -1.0;
   int bi = 0x7fffffff;
 
-  auto load_pass = [&](int parity) {
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-      const int k = tid + j * NT;
-      double2 v = S[j];
-      if (parity) v = cmulf(v, a.W[k]);
-      d[PH(digitrev<LOGM>(k))] = v;
-    }
-    __syncthreads();
-  };
-  double hte[KPT];                                            // even pass: (hp Fp + hc Fc) g of even sample 2 (tid + j NT), crop_value's expression
-  auto argmax_pass = [&](auto par) {
-    constexpr int parity = decltype(par)::value;
-    const double sg = parity ? -1.0 : 1.0;
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-      const int np = tid + j * NT;
-      const double2 z = d[PH(np)];
-      const double hp = fpn * (2.0 * z.x + c.nyq_re * sg), hc = cin * (2.0 * z.y + c.nyq_im * sg);
-      const double pw = hp * hp + hc * hc;
-      if constexpr (parity == 0) {
-        const double t1 = hp * a.Fp, t2 = hc * a.Fc;
-        hte[j] = (t1 + t2) * a.g;
-      }
-      int n = 2 * np + parity - a.roll;                       // rolled index: rolled[n] = series[(n + roll) mod N]
-      if (n < 0) n += N;
-      if (pw > best || (pw == best && n < bi)) { best = pw; bi = n; }
-    }
-  };
   long start = 0;
-  // sample n of the crop, if this parity pass owns it (the zero fill past the end of the slid series belongs to the odd pass)
-  auto crop_value = [&](int n, int parity, double* v) -> bool {
-    const long sidx = start + a.crop0 + n;
-    if (sidx >= N) { *v = 0.0; return parity == 1; }
-    const int s = (int)((sidx + a.roll) % N);
-    if ((s & 1) != parity) return false;
-    const double sg = parity ? -1.0 : 1.0;
-    const double2 z = d[PH(s >> 1)];
-    const double hp = fpn * (2.0 * z.x + c.nyq_re * sg), hc = cin * (2.0 * z.y + c.nyq_im * sg);
-    const double t1 = hp * a.Fp, t2 = hc * a.Fc;
-    *v = (t1 + t2) * a.g;
-    return true;
-  };
   double keep[KC];                                            // noise mode: the template crop, n = tid + j NT
-  auto emit_odd = [&]() {                                     // odd samples from the LDS image + the zero fill past the end of the slid series
-    if constexpr (NOISE) {
-#pragma unroll
-      for (int j = 0; j < KC; ++j) {
-        const int n = tid + j * NT;
-        double v;
-        if (n < a.crop_len && crop_value(n, 1, &v)) keep[j] = v;
+  // Two forms of the template transform (round 4).  QUARTER (M <= 2048, i.e. fs <= 1024): four M/2-point transforms in a half-size image -- the
+  // spectrum is 8 bins per thread there, everything stays in registers at four waves per SIMD, and the kernel gains 30 % (16.2 -> 21.0 M templates/s
+  // at fs 1024).  From M = 4096 on a thread holds 16 bins AND 16 kept samples per class pair: at the 128 registers four waves per SIMD allow the
+  // quarter form spills 600-760 bytes per lane and LOSES (fs 2048: 9.7 M/s at four workgroups per CU, 10.6 M/s at two, against 11.6 M/s for the
+  // two-transform form in the full image on the same box; fs 4096: 4.6 against 5.2), so the large sizes keep two M-point transforms.
+  if constexpr (QUARTER) {
+    // Four QUARTER transforms instead of two half ones (round 4): the series a[n], n < N, splits by n mod 4.  With X_p[k] = S[k] W_N^(p k)
+    // (p = sample parity, as before) one radix-2 decimation-in-frequency step done in registers -- a thread holds bin k and its partner k + M/2 --
+    //     a[4u + 2r + p] = IFFT_{M/2}(z_{p,r})[u],   z_{p,0}[k] = X_p[k] + X_p[k + M/2],   z_{p,1}[k] = (X_p[k] - X_p[k + M/2]) W_N^(2k),   k < M/2
+    // leaves transforms of M/2 points: the LDS image halves (36 KiB at fs 2048: four workgroups per CU instead of two; measured with the image padded
+    // back up, this kernel runs 1.57x faster at two workgroups per CU than at one).  Nothing of a sub-pass survives in LDS, so every thread keeps
+    // the detector strain of its M / NT samples per class -- one double per sample, 2 M / NT in all, the registers the spectrum bins free after the
+    // last load -- and the crop is written by whichever thread owns the sample.
+    constexpr int LOGH = LOGM - 1, MH = M / 2, HB = KPT / 2;    // bins k = tid + j NT, j < HB, and their partners k + M/2 (index j + HB)
+    static_assert(KPT % 2 == 0, "a thread must hold both halves of the spectrum");
+    double qv[4][HB];                                           // qv[2r + p][j] = (hp Fp + hc Fc) g of series sample 4 (tid + j NT) + 2r + p
+    auto sub_pass = [&](auto pc, auto rc) {
+      constexpr int p = decltype(pc)::value, r = decltype(rc)::value;
+  #pragma unroll
+      for (int j = 0; j < HB; ++j) {
+        const int k = tid + j * NT;
+        double2 x0 = S[j], x1 = S[j + HB];
+        if constexpr (p == 1) { x0 = cmulf(x0, a.W[k]); x1 = cmulf(x1, a.W[k + MH]); }
+        const double2 z = r ? cmulf(csub(x0, x1), a.W[2 * k]) : cadd(x0, x1);
+        d[PH(digitrev<LOGH>(k))] = z;
       }
-    } else {
-      for (int n = tid; n < a.crop_len; n += NT) {
-        double v;
-        if (!crop_value(n, 1, &v)) continue;
-        const size_t o = (size_t)b * a.crop_len + n;
-        if (a.out64) a.out64[o] = v;
-        if (a.out32) a.out32[o] = (float)v;
-      }
-    }
-  };
-  // even samples from the owners' registers: even sample 2 np sits at rolled index r = (2 np - roll) mod N, i.e. at position r - start of the slid
-  // series and at crop position n = r - start - crop0 (crop_value's map read backwards: sidx = r < N always, so no zero fill here)
-  auto emit_even = [&]() {
-    double* xch = reinterpret_cast<double*>(d);               // noise mode: crop-indexed exchange through the (now free) LDS image
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-      int r = 2 * (tid + j * NT) - a.roll;
-      if (r < 0) r += N;
-      const long n = (long)r - start - a.crop0;
-      if (n < 0 || n >= a.crop_len) continue;
-      if constexpr (NOISE) xch[n] = hte[j];
-      else {
-        const size_t o = (size_t)b * a.crop_len + n;
-        if (a.out64) a.out64[o] = hte[j];
-        if (a.out32) a.out32[o] = (float)hte[j];
-      }
-    }
-    if constexpr (NOISE) {
       __syncthreads();
-#pragma unroll
-      for (int j = 0; j < KC; ++j) {
-        const int n = tid + j * NT;
-        const long sidx = start + a.crop0 + n;
-        if (n < a.crop_len && sidx < N && (((sidx + a.roll) % N) & 1) == 0) keep[j] = xch[n];
+      ifft_lds<LOGH, NT, 2>(d, a.W);
+      const double sg = p ? -1.0 : 1.0;                         // (-1)^n of the Nyquist term: n = 4u + 2r + p
+  #pragma unroll
+      for (int j = 0; j < HB; ++j) {
+        const int u = tid + j * NT;
+        const double2 z = d[PH(u)];
+        const double hp = fpn * (2.0 * z.x + c.nyq_re * sg), hc = cin * (2.0 * z.y + c.nyq_im * sg);
+        const double pw = hp * hp + hc * hc;
+        const double t1 = hp * a.Fp, t2 = hc * a.Fc;
+        qv[2 * r + p][j] = (t1 + t2) * a.g;
+        int n = 4 * u + 2 * r + p - a.roll;                     // rolled index: rolled[n] = series[(n + roll) mod N]
+        if (n < 0) n += N;
+        if (pw > best || (pw == best && n < bi)) { best = pw; bi = n; }
       }
-    }
-  };
+      __syncthreads();                                          // the image is free for the next sub-pass (or the exchange / the noise chain)
+    };
+    // the crop from the owners' registers: series sample s sits at rolled index r_ = (s - roll) mod N, i.e. at position r_ - start of the slid series
+    // (python slice ht[start:]) and at crop position n = r_ - start - crop0; positions whose slid index start + crop0 + n is past the end are zeros
+    auto emit = [&]() {
+      double* xch = reinterpret_cast<double*>(d);               // noise mode: crop-indexed exchange through the (free) LDS image
+      if constexpr (NOISE) {
+  #pragma unroll
+        for (int j = 0; j < KC; ++j) keep[j] = 0.0;
+      } else {
+        for (int n = tid; n < a.crop_len; n += NT) {
+          if (start + a.crop0 + n < N) continue;
+          const size_t o = (size_t)b * a.crop_len + n;
+          if (a.out64) a.out64[o] = 0.0;
+          if (a.out32) a.out32[o] = 0.f;
+        }
+      }
+  #pragma unroll
+      for (int cls = 0; cls < 4; ++cls)
+  #pragma unroll
+        for (int j = 0; j < HB; ++j) {
+          int r_ = 4 * (tid + j * NT) + cls - a.roll;
+          if (r_ < 0) r_ += N;
+          const long n = (long)r_ - start - a.crop0;
+          if (n < 0 || n >= a.crop_len) continue;
+          if constexpr (NOISE) xch[n] = qv[cls][j];
+          else {
+            const size_t o = (size_t)b * a.crop_len + n;
+            if (a.out64) a.out64[o] = qv[cls][j];
+            if (a.out32) a.out32[o] = (float)qv[cls][j];
+          }
+        }
+      if constexpr (NOISE) {
+        __syncthreads();
+  #pragma unroll
+        for (int j = 0; j < KC; ++j) {
+          const int n = tid + j * NT;
+          if (n < a.crop_len && start + a.crop0 + n < N) keep[j] = xch[n];
+        }
+      }
+    };
 
-  // pass 1: even samples: arg-max, strain values into registers
-  load_pass(0);
-  ifft_lds<LOGM, NT>(d, a.W);
-  argmax_pass(std::integral_constant<int, 0>{});
-  __syncthreads();
-  // pass 2: odd samples
-  load_pass(1);
-  ifft_lds<LOGM, NT>(d, a.W);
-  argmax_pass(std::integral_constant<int, 1>{});
-  // block arg-max (first maximum): wave shuffle, then one wave over the per-wave partials
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const double ov = __shfl_down(best, off, 64);
-    const int oi = __shfl_down(bi, off, 64);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-  }
-  if ((tid & 63) == 0) { rv[tid >> 6] = best; ri[tid >> 6] = bi; }
-  __syncthreads();
-  if (tid < 64) {
-    best = tid < NT / 64 ? rv[tid] : -2.0;
-    bi = tid < NT / 64 ? ri[tid] : 0x7fffffff;
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
+    sub_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    sub_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    sub_pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    sub_pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    // block arg-max (first maximum): wave shuffle, then one wave over the per-wave partials
+  #pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
       const double ov = __shfl_down(best, off, 64);
       const int oi = __shfl_down(bi, off, 64);
       if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
-    if (tid == 0) ri[0] = bi;
+    if ((tid & 63) == 0) { rv[tid >> 6] = best; ri[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid < 64) {
+      best = tid < NT / 64 ? rv[tid] : -2.0;
+      bi = tid < NT / 64 ? ri[tid] : 0x7fffffff;
+  #pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        const double ov = __shfl_down(best, off, 64);
+        const int oi = __shfl_down(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      if (tid == 0) ri[0] = bi;
+    }
+    __syncthreads();
+    const int ref = ri[0];
+    if (tid == 0 && a.ref_out) a.ref_out[b] = ref;
+    start = (long)ref - c.idx - a.peak_off;                  // python slice ht[start:]: negative counts from the end, clamped at 0
+    if (start < 0) { start += N; if (start < 0) start = 0; }
+    emit();
+  } else {
+    auto load_pass = [&](int parity) {
+  #pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const int k = tid + j * NT;
+        double2 v = S[j];
+        if (parity) v = cmulf(v, a.W[k]);
+        d[PH(digitrev<LOGM>(k))] = v;
+      }
+      __syncthreads();
+    };
+    double hte[KPT];                                            // even pass: (hp Fp + hc Fc) g of even sample 2 (tid + j NT), crop_value's expression
+    auto argmax_pass = [&](auto par) {
+      constexpr int parity = decltype(par)::value;
+      const double sg = parity ? -1.0 : 1.0;
+  #pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const int np = tid + j * NT;
+        const double2 z = d[PH(np)];
+        const double hp = fpn * (2.0 * z.x + c.nyq_re * sg), hc = cin * (2.0 * z.y + c.nyq_im * sg);
+        const double pw = hp * hp + hc * hc;
+        if constexpr (parity == 0) {
+          const double t1 = hp * a.Fp, t2 = hc * a.Fc;
+          hte[j] = (t1 + t2) * a.g;
+        }
+        int n = 2 * np + parity - a.roll;                       // rolled index: rolled[n] = series[(n + roll) mod N]
+        if (n < 0) n += N;
+        if (pw > best || (pw == best && n < bi)) { best = pw; bi = n; }
+      }
+    };
+    // sample n of the crop, if this parity pass owns it (the zero fill past the end of the slid series belongs to the odd pass)
+    auto crop_value = [&](int n, int parity, double* v) -> bool {
+      const long sidx = start + a.crop0 + n;
+      if (sidx >= N) { *v = 0.0; return parity == 1; }
+      const int s = (int)((sidx + a.roll) % N);
+      if ((s & 1) != parity) return false;
+      const double sg = parity ? -1.0 : 1.0;
+      const double2 z = d[PH(s >> 1)];
+      const double hp = fpn * (2.0 * z.x + c.nyq_re * sg), hc = cin * (2.0 * z.y + c.nyq_im * sg);
+      const double t1 = hp * a.Fp, t2 = hc * a.Fc;
+      *v = (t1 + t2) * a.g;
+      return true;
+    };
+    auto emit_odd = [&]() {                                     // odd samples from the LDS image + the zero fill past the end of the slid series
+      if constexpr (NOISE) {
+  #pragma unroll
+        for (int j = 0; j < KC; ++j) {
+          const int n = tid + j * NT;
+          double v;
+          if (n < a.crop_len && crop_value(n, 1, &v)) keep[j] = v;
+        }
+      } else {
+        for (int n = tid; n < a.crop_len; n += NT) {
+          double v;
+          if (!crop_value(n, 1, &v)) continue;
+          const size_t o = (size_t)b * a.crop_len + n;
+          if (a.out64) a.out64[o] = v;
+          if (a.out32) a.out32[o] = (float)v;
+        }
+      }
+    };
+    // even samples from the owners' registers: even sample 2 np sits at rolled index r = (2 np - roll) mod N, i.e. at position r - start of the slid
+    // series and at crop position n = r - start - crop0 (crop_value's map read backwards: sidx = r < N always, so no zero fill here)
+    auto emit_even = [&]() {
+      double* xch = reinterpret_cast<double*>(d);               // noise mode: crop-indexed exchange through the (now free) LDS image
+  #pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        int r = 2 * (tid + j * NT) - a.roll;
+        if (r < 0) r += N;
+        const long n = (long)r - start - a.crop0;
+        if (n < 0 || n >= a.crop_len) continue;
+        if constexpr (NOISE) xch[n] = hte[j];
+        else {
+          const size_t o = (size_t)b * a.crop_len + n;
+          if (a.out64) a.out64[o] = hte[j];
+          if (a.out32) a.out32[o] = (float)hte[j];
+        }
+      }
+      if constexpr (NOISE) {
+        __syncthreads();
+  #pragma unroll
+        for (int j = 0; j < KC; ++j) {
+          const int n = tid + j * NT;
+          const long sidx = start + a.crop0 + n;
+          if (n < a.crop_len && sidx < N && (((sidx + a.roll) % N) & 1) == 0) keep[j] = xch[n];
+        }
+      }
+    };
+
+    // pass 1: even samples: arg-max, strain values into registers
+    load_pass(0);
+    ifft_lds<LOGM, NT>(d, a.W);
+    argmax_pass(std::integral_constant<int, 0>{});
+    __syncthreads();
+    // pass 2: odd samples
+    load_pass(1);
+    ifft_lds<LOGM, NT>(d, a.W);
+    argmax_pass(std::integral_constant<int, 1>{});
+    // block arg-max (first maximum): wave shuffle, then one wave over the per-wave partials
+  #pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double ov = __shfl_down(best, off, 64);
+      const int oi = __shfl_down(bi, off, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { rv[tid >> 6] = best; ri[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid < 64) {
+      best = tid < NT / 64 ? rv[tid] : -2.0;
+      bi = tid < NT / 64 ? ri[tid] : 0x7fffffff;
+  #pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        const double ov = __shfl_down(best, off, 64);
+        const int oi = __shfl_down(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      if (tid == 0) ri[0] = bi;
+    }
+    __syncthreads();
+    const int ref = ri[0];
+    if (tid == 0 && a.ref_out) a.ref_out[b] = ref;
+    start = (long)ref - c.idx - a.peak_off;                  // python slice ht[start:]: negative counts from the end, clamped at 0
+    if (start < 0) { start += N; if (start < 0) start = 0; }
+    emit_odd();
+    if constexpr (NOISE) __syncthreads();                     // the odd samples have been read: the image becomes the exchange buffer
+    emit_even();
   }
-  __syncthreads();
-  const int ref = ri[0];
-  if (tid == 0 && a.ref_out) a.ref_out[b] = ref;
-  start = (long)ref - c.idx - a.peak_off;                  // python slice ht[start:]: negative counts from the end, clamped at 0
-  if (start < 0) { start += N; if (start < 0) start = 0; }
-  emit_odd();
-  if constexpr (NOISE) __syncthreads();                     // the odd samples have been read: the image becomes the exchange buffer
-  emit_even();
   if constexpr (NOISE) {
     __syncthreads();                                          // every read of the template image is done: the noise chain reuses it
     noise_chain<LOGM, NT>(d, a.nz, b);
@@ -320,16 +441,16 @@ __global__ __launch_bounds__(NT, (NT >= 1024 ? 1 : 2)) void synth_fused_kernel(S
 static double synth_flops_per_template(int M) {
   double l2 = 0;
   for (int m = M; m > 1; m >>= 1) l2 += 1;
-  return 2.0 * 5.0 * M * l2 + 150.0 * M + 6.0 * M + 12.0 * 2.0 * M;
+  return 2.0 * 5.0 * M * l2 + 150.0 * M + 6.0 * M + 12.0 * 2.0 * M;      // (four M/2-point transforms + one radix-2 step in registers = two M-point transforms)
 }
 double noise_flops_per_row(int M);
 
-template <int LOGM, int NT>
+template <int LOGM, int NT, int OCC = 0>
 static int launch_synth(const SynthArgs& a, hipStream_t s) {
   constexpr int M = 1 << LOGM;
   static const size_t lds_pad = getenv("GN_SYNTH_LDS_PAD") ? (size_t)atoi(getenv("GN_SYNTH_LDS_PAD")) : 0;      // experiment: force fewer blocks per CU
-  const size_t lds = (size_t)(M + M / 8) * sizeof(double2) + sizeof(ChirpCoeffsF) + 16 * sizeof(double) + 16 * sizeof(int) + lds_pad;
   const bool noise = a.nz.amp != nullptr;
+  const size_t lds = (size_t)((noise || LOGM > 11) ? M + M / 8 : M / 2 + M / 16) * sizeof(double2) + sizeof(ChirpCoeffsF) + 16 * sizeof(double) + 16 * sizeof(int) + lds_pad;
   if (noise && a.crop_len > M / 2) {
     set_error("synth_templates: noise mode needs crop_len <= N/4 (crop %d, N %d)", a.crop_len, 2 * M);
     return GN_EINVAL;
@@ -340,8 +461,8 @@ static int launch_synth(const SynthArgs& a, hipStream_t s) {
     allow_big_lds((const void*)synth_fused_kernel<LOGM, NT, true>, &lds_done_nz);
     hipLaunchKernelGGL((synth_fused_kernel<LOGM, NT, true>), dim3(a.nb), dim3(NT), lds, s, a);
   } else {
-    allow_big_lds((const void*)synth_fused_kernel<LOGM, NT, false>, &lds_done);
-    hipLaunchKernelGGL((synth_fused_kernel<LOGM, NT, false>), dim3(a.nb), dim3(NT), lds, s, a);
+    allow_big_lds((const void*)synth_fused_kernel<LOGM, NT, false, OCC>, &lds_done);
+    hipLaunchKernelGGL((synth_fused_kernel<LOGM, NT, false, OCC>), dim3(a.nb), dim3(NT), lds, s, a);
   }
   // algorithmic bytes: per template 2 spectra of Nf complex128 + the PSD read, the cropped row written; noise mode adds the
   // noise spectrum (Nf complex128) and the window (N doubles) the unfused chain reads
