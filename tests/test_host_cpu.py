@@ -411,3 +411,38 @@ def test_expected_collectives_of_one_bench_step():
     assert sum(q.size for q in nets.signal_discriminator._train_params) == 3808257
     # ... of which the moving statistics (half of every BatchNormalization's four vectors) are not trainable and are never exchanged
     assert sum(q.size for q in nets.signal_discriminator_on_generator._train_params) == 31095745 + 7936 - 2 * (256 * 1024 + 1984)
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """The driver parses ONE JSON line from bench.py; the newest committed line (profiles/r04_bench_default.json, printed by `python bench.py` on an
+    MI355X) must carry every field of the contract, with the units and meanings the task fixes: whole-job waveforms/s, dtype = the arithmetic type,
+    vs_baseline null (BASELINE.md holds no published number), roofline with achieved / peak / frac / traffic, cpu_baseline with cores / kind / sample."""
+    import json
+    line = open(os.path.join(ROOT, 'profiles', 'r04_bench_default.json')).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
+              'roofline', 'cpu_baseline', 'last_losses'):
+        assert k in d, k
+    assert d['unit'] == 'waveforms/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and d['n_gpus'] == 1
+    assert 'workload' in d['config'] and 'configs[1]+[2]' in d['config']['workload'] and 'model' not in d['config']
+    assert abs(d['value'] - d['config']['waveforms_per_step_per_gpu'] * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0.5 < r['frac'] < 1.0
+    assert r['traffic'] > r['algorithmic_bytes_per_launch']                    # fabric-side bytes can only exceed the algorithmic ones
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['unit'] == 'waveforms/s'
+    assert 1426.0 < d['value'] < 1427.0 and c['value'] < d['value'] / 100.0      # the north-star's >= 100x over the CPU path
+
+
+def test_every_profile_the_readme_lists_is_committed():
+    import re
+    txt = open(os.path.join(ROOT, 'profiles', 'README.md')).read()
+    names = set(re.findall(r'`(r0[1-4]_[A-Za-z0-9_.]+\.(?:json|csv|txt|log))`', txt))
+    assert len(names) > 40
+    missing = sorted(n for n in names if not os.path.exists(os.path.join(ROOT, 'profiles', n)))
+    assert not missing, missing
