@@ -33,10 +33,12 @@ def _bn_fed_bias_indices(stack):
     return out
 
 
-def test_gan_100_iterations_follow_the_oracle():
+@pytest.mark.parametrize("n_pix,B,iters", [(64, 4, 100),
+                                          (1024, 8, 5)])       # the reference script's OWN operating point (bbhMahoGANy.py:84-89): the narrow-wave tiles, sub-batch
+                                                               # K-splits and merged stride-2 data gradients of the batch-8 launches, five iterations in a row
+def test_gan_100_iterations_follow_the_oracle(n_pix, B, iters):
     from gennet_amd import bbh
     from gennet_amd.engine import to_device
-    n_pix, B, iters = 64, 4, 100
     rng = np.random.RandomState(31)
     ref, nets, event = _build_gan(n_pix, rng)
     ev_dev = to_device(event.reshape(-1))
