@@ -115,10 +115,10 @@ def test_gan_100_iterations_follow_the_oracle(n_pix, B, iters):
     assert rel(G.predict(z3), ref.generate(z3)) < 2e-4
 
 
-def test_cnn_100_steps_follow_the_oracle():
+@pytest.mark.parametrize("n_pix,B,steps", [(64, 4, 100), (1024, 8, 10)])       # ... and ten steps at the reference script's own n_pix 1024 / batch 8
+def test_cnn_100_steps_follow_the_oracle(n_pix, B, steps):
     from gennet_amd import bbh
     from gennet_amd.engine import Adam
-    n_pix, B, steps = 64, 4, 100
     rng = np.random.RandomState(32)
     ref = N.PENet(n_pix, rng)
     round_stack(ref.mc); round_stack(ref.q)
