@@ -308,13 +308,21 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgs a, const u
 // ---------------------------------------------------------------------------------------------------------------------------------
 // ABL (timing experiments only, GN_BF16X3_ABL; results are wrong for ABL != 0): bit 0 = no fragment reads in the loop, bit 1 = no staging in the
 // loop, bit 2 = no epilogue
-template <int NTAPS, int ABL = 0>
+// IS = input stride (1, or 2 for the stride-2 forward: the slab is staged de-interleaved, even input rows then odd ones, so that every tap reads a
+// unit-stride run -- 258 + 258 rows per (plane, k-half) region, 80 256 bytes per stage: two stages just fit the 160 KiB).
+template <int NTAPS, int ABL = 0, int IS = 1>
 __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, const unsigned short* __restrict__ xs, const unsigned short* __restrict__ ws,
                                                                   size_t x_plane, size_t w_plane, int m_tiles, int n_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(NTAPS >= 4 && NTAPS <= 5, "a chunk must outlast the staging latency: 4 or 5 taps");
-  constexpr int TM = 256, TN = 64, ASEG = 5;
-  constexpr int A_BYTES = 6 * ASEG * 1024, B_BYTES = 6 * NTAPS * 1024, STAGE = A_BYTES + B_BYTES;
+  static_assert(IS == 1 || (IS == 2 && NTAPS == 5), "stride 2: the 5-tap forward only");
+  constexpr int TM = 256, TN = 64;
+  constexpr int RPER = IS == 1 ? 320 : 258;                // rows of one parity class of a region (stride 1: one class, padded to whole 64-row DMA segments)
+  constexpr int RTOT = IS * RPER;                          // LDS rows of one (plane, k-half) region
+  constexpr int ASEG = (RTOT + 63) / 64;                   // 64-row DMA segments per region (the last one partial at stride 2: lanes past the region are masked)
+  constexpr int REGION = RTOT * 16;
+  constexpr int A_BYTES = 6 * REGION, B_BYTES = 6 * NTAPS * 1024, STAGE = A_BYTES + B_BYTES;
+  static_assert(2 * STAGE <= 160 * 1024, "two stages must fit the CU's LDS");
   constexpr int Q_TOTAL = 6 * ASEG + 6 * NTAPS;            // wave-level DMA instructions per chunk
   constexpr int Q_WAVE = (Q_TOTAL + 3) / 4;                // ... per wave
   constexpr int Q_FIRST = (Q_WAVE + 1) / 2;                // issued behind the barrier (last tap of chunk c); the rest in tap 0 of chunk c + 1
@@ -340,10 +348,10 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
     minoff = min(minoff, a.t.off[j]);
     maxoff = max(maxoff, a.t.off[j]);
   }
-  const int R = (TM - 1) + (maxoff - minoff) + 1;          // <= 260 staged rows (the launcher checks the taps span <= 5 rows)
+  const int R = IS * (TM - 1) + (maxoff - minoff) + 1;     // staged input rows (the launcher checks the taps span <= 5 rows)
   const int n_chunks = a.Cin >> 4;
   const int Lg = a.Lin + 2;
-  const int t_base = m0 + minoff;
+  const int t_base = IS * m0 + minoff;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -355,6 +363,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
 
   const unsigned short* src[Q_WAVE];
   int dst[Q_WAVE];
+  bool live[Q_WAVE];
   size_t step[Q_WAVE];
 #pragma unroll
   for (int i = 0; i < Q_WAVE; ++i) {
@@ -362,11 +371,13 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
     if (q >= Q_TOTAL) q = Q_TOTAL - 1;                      // padding instruction: repeats the last one (same bytes, same place)
     if (q < 6 * ASEG) {
       const int ph = q / ASEG, seg = q % ASEG;
-      const int r = seg * 64 + lane;
+      const int lr = seg * 64 + lane;                                                        // LDS row inside the region
+      const int r = (IS == 1) ? lr : (lr < RPER ? 2 * lr : 2 * (lr - RPER) + 1);             // input row it holds (stride 2: even rows, then odd rows)
       const int t = t_base + r;
       const int row = (r < R && t >= 0 && t < a.Lin) ? t + 1 : 0;                           // 0 = the leading zero guard row
       src[i] = xs + (ph >> 1) * x_plane + ((((size_t)b * n_chunks) * 2 + (ph & 1)) * Lg + row) * 8;
-      dst[i] = q * 1024;
+      dst[i] = ph * REGION + seg * 1024;
+      live[i] = lr < RTOT;                                                                   // the partial last segment must not write into the next region
       step[i] = (size_t)2 * Lg * 8;
     } else {
       const int qb = q - 6 * ASEG;
@@ -374,22 +385,24 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
       const int p = pt / NTAPS, tap = pt % NTAPS;
       src[i] = ws + p * w_plane + ((((size_t)a.t.widx[tap] * n_chunks) * 2 + hh) * a.Cout + n0 + lane) * 8;
       dst[i] = A_BYTES + qb * 1024;
+      live[i] = true;
       step[i] = (size_t)2 * a.Cout * 8;
     }
   }
   bool in_loop = false;
   auto dma_one = [&](int i, int c, unsigned char* stage) {
     if ((ABL & 2) && in_loop) return;
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)c * step[i]), (lptr_t)(stage + dst[i]), 16, 0, 0);
+    if (IS == 1 || live[i]) __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)c * step[i]), (lptr_t)(stage + dst[i]), 16, 0, 0);
   };
   auto read_tap = [&](const unsigned char* sa, int j, bf16x8 (&av)[3][2], bf16x8 (&bv)[3][2]) {
     if ((ABL & 1) && in_loop) return;
-    const int rowbase = a.t.off[j] - minoff;
+    const int d = a.t.off[j] - minoff;
+    const int rowbase = (IS == 1) ? d : ((d & 1) * RPER + (d >> 1));
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
-        av[p][mt] = *reinterpret_cast<const bf16x8*>(sa + ((p * 2 + h) * (ASEG * 64) + rowbase + wm * 64 + mt * 32 + i32) * 16);
+        av[p][mt] = *reinterpret_cast<const bf16x8*>(sa + ((p * 2 + h) * RTOT + rowbase + wm * 64 + mt * 32 + i32) * 16);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
         bv[p][nt] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + (((p * NTAPS + j) * 2 + h) * 64 + nt * 32 + i32) * 16);
@@ -493,8 +506,19 @@ size_t conv_bf16x3_workspace_bytes(int B, int Lin, int Cin, int Cout, int w_taps
   return 6 * ((size_t)B * (Lin + 2) * Cin + (size_t)w_taps * Cin * Cout) + 256;
 }
 
+// stride-2 forward (round 4): the 5-tap launches whose rows fill the 256-row blocks of the wide kernel; everything else needs unit input stride
+static bool bf16x3_stride2_ok(const ConvArgs& a) {
+  if (a.t.in_stride != 2 || a.t.ntaps != 5 || a.M < 192 || a.t.out_stride != 1) return false;
+  int minoff = a.t.off[0], maxoff = a.t.off[0];
+  for (int j = 1; j < 5; ++j) {
+    minoff = std::min(minoff, a.t.off[j]);
+    maxoff = std::max(maxoff, a.t.off[j]);
+  }
+  return maxoff - minoff + 1 == 5;
+}
+
 bool conv_bf16x3_supported(const ConvArgs& a) {
-  return a.Cin % 16 == 0 && a.Cout % 64 == 0 && a.t.ntaps >= 1 && a.t.ntaps <= 5 && a.t.in_stride == 1;
+  return a.Cin % 16 == 0 && a.Cout % 64 == 0 && a.t.ntaps >= 1 && a.t.ntaps <= 5 && (a.t.in_stride == 1 || bf16x3_stride2_ok(a));
 }
 
 // splits: x (B, Lin, Cin) and the conv-layout weights w (w_taps, Cin, Cout) -> blocked bf16 planes in `ws`
@@ -539,12 +563,12 @@ static int launch_bf16x3(const ConvArgs& a, int w_taps, void* ws, hipStream_t s)
   return check_launch("conv_bf16x3");
 }
 
-template <int NTAPS, int ABL = 0>
+template <int NTAPS, int ABL = 0, int IS = 1>
 static int launch_bf16x3_wide(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
-  constexpr size_t lds = 2 * ((size_t)6 * 5 * 1024 + (size_t)6 * NTAPS * 1024);
+  constexpr size_t lds = 2 * ((size_t)6 * (IS == 1 ? 320 : 516) * 16 + (size_t)6 * NTAPS * 1024);
   static_assert(lds <= 160 * 1024, "two stages must fit the CU's LDS");
   static unsigned long long lds_done = 0;
-  allow_big_lds((const void*)conv_bf16x3_wide_kernel<NTAPS, ABL>, &lds_done);
+  allow_big_lds((const void*)conv_bf16x3_wide_kernel<NTAPS, ABL, IS>, &lds_done);
   const int m_tiles = (a.M + 255) / 256, n_tiles = a.Cout / 64;
   const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
   if (blocks == 0 || blocks > 0x7fffffffull) {
@@ -555,7 +579,7 @@ static int launch_bf16x3_wide(const ConvArgs& a, int w_taps, void* ws, hipStream
   const unsigned short* xs = (const unsigned short*)ws;
   const unsigned short* wsp = xs + 3 * xn;
   prof_begin(s);
-  hipLaunchKernelGGL((conv_bf16x3_wide_kernel<NTAPS, ABL>), dim3((unsigned)blocks), dim3(256), lds, s, a, xs, wsp, xn, wn, m_tiles, n_tiles);
+  hipLaunchKernelGGL((conv_bf16x3_wide_kernel<NTAPS, ABL, IS>), dim3((unsigned)blocks), dim3(256), lds, s, a, xs, wsp, xn, wn, m_tiles, n_tiles);
   prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 2);
   return check_launch("conv_bf16x3_wide");
 }
@@ -565,6 +589,7 @@ int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
     set_error("conv_bf16x3: shape not supported (Cin %% 16, Cout %% 64, taps <= 5, unit input stride)");
     return GN_EINVAL;
   }
+  if (a.t.in_stride == 2) return launch_bf16x3_wide<5, 0, 2>(a, w_taps, ws, s);
   // 64 x 64 wave tiles in 256-row blocks for the 4- / 5-tap launches whose rows fill them (round 4); GN_BF16X3_NARROW keeps round 1's kernel
   static const bool narrow = getenv("GN_BF16X3_NARROW") != nullptr;
   if (!narrow && a.t.ntaps >= 4 && a.M >= 192) {

@@ -113,3 +113,60 @@ def test_gan_iteration_under_the_opt_in_split_meets_the_fp32_path_tolerances():
         ops.set_conv_math('fp32')
         ops.prof_enable(False)
     assert used >= 4, used              # predict (2 layers) + train forward (2) + data gradients: the split kernels really ran
+
+
+@pytest.mark.parametrize('B,L,Cin,Cout,padding', [(2, 700, 64, 128, 'same'),        # 350 output rows: two 256-row blocks, the second ragged; zero guard rows on both sides
+                                                  (1, 600, 48, 192, 'valid'),       # 298 rows, 3 chunks (odd), 3 column tiles
+                                                  (3, 1030, 32, 64, 'same'),        # 515 rows: three blocks, the last with 3 live rows
+                                                  (1, 512, 512, 1024, 'same')])     # the discriminator's / point-estimator's channel counts
+def test_bf16x3_stride2_forward_is_fp32_grade(B, L, Cin, Cout, padding):
+    """Round 4: the stride-2 forward on the wide split kernel (de-interleaved slab: even input rows, then odd ones; the partial last DMA segment of
+    every region is lane-masked).  Same bounds as the unit-stride cases."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(B * 17 + L + Cin)
+    x = (rng.randn(B, L, Cin) * np.exp(rng.randn(B, L, Cin))).astype(np.float32)
+    w = (rng.randn(5, Cin, Cout) / np.sqrt(5 * Cin)).astype(np.float32)
+    b = rng.randn(Cout).astype(np.float32)
+    Lout, pl = ops.conv_geometry(L, 5, 2, padding)
+    ref = np.maximum(K.conv1d_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), 2, padding), 0.0)
+    dev = torch.device('cuda:0')
+    xt, wt, bt = (torch.tensor(v).to(dev) for v in (x, w, b))
+    y32 = ops.conv1d_fwd(xt, wt, bt, 2, pl, Lout, 'relu').cpu().numpy().astype(np.float64)
+    y3 = ops.conv1d_fwd_bf16x3(xt, wt, bt, 2, pl, Lout, 'relu').cpu().numpy().astype(np.float64)
+    scale = np.abs(ref).max()
+    e32, e3 = np.abs(y32 - ref).max() / scale, np.abs(y3 - ref).max() / scale
+    r32, r3 = np.sqrt(np.mean((y32 - ref) ** 2)) / scale, np.sqrt(np.mean((y3 - ref) ** 2)) / scale
+    assert e3 <= 2e-5, e3
+    assert e3 <= 2.0 * e32 + 1e-7, (e3, e32)
+    assert r3 <= 1.5 * r32 + 1e-8, (r3, r32)
+
+
+def test_discriminator_step_under_the_opt_in_split_meets_the_fp32_path_tolerances():
+    """The discriminator's folded width-2 Conv2D(256 -> 512, stride (2, 1)) -- a stride-2 Conv1D with 512 -> 1024 channels -- on the split kernel's
+    stride-2 form with the fused dropout epilogue, inside a whole train_on_batch at n_pix 1024 (256 output rows: one full block), against the oracle
+    at the tolerances test_nets_gpu asserts for the exact kernels (loss 2e-5, gradients 2e-4)."""
+    from gennet_amd import bbh, ops
+    import test_nets_gpu as T
+    n_pix, B = 1024, 2
+    rng = np.random.RandomState(23)
+    ref, nets, event = T._build_gan(n_pix, rng)
+    D = nets.signal_discriminator
+    sX = T.f32(rng.randn(2 * B, n_pix, 2, 1)); sy = [1.0] * B + [0.0] * B
+    d_masks = T.stack_masks(ref.D, sX, rng)
+    ops.prof_enable(True); ops.prof_reset()
+    ops.set_conv_math('bf16x3', workspace_gb=0.5)
+    try:
+        cap = {}
+        out = D.train_on_batch(sX, sy, dropout_masks=T.masks_by_name(ref.D, d_masks, D.layers), capture=cap)
+        out_ref = ref.d_train_on_batch(sX, sy, d_masks, T.decisions_for(ref.D, D.layers, cap))
+        del cap
+        T.assert_decisions_consistent(ref.D)
+        assert abs(out[0] - out_ref[0]) <= 2e-5 * abs(out_ref[0]) and out[1] == pytest.approx(out_ref[1])
+        dgr = [p.grad.cpu().numpy() for l in D.layers for p in l.params]
+        for gq, gr in zip(dgr, ref.last_d_grads):
+            assert T.rel(gq, gr) < 2e-4
+        used = ops.prof_collect(2)['launches']
+    finally:
+        ops.set_conv_math('fp32')
+        ops.prof_enable(False)
+    assert used >= 1, used              # the stride-2 forward really ran on the split kernel
