@@ -494,6 +494,188 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
 #endif
 }
 
+// The same 64 x 64 wave tiles for the 2- / 3-tap launches (the two output phases of a stride-2 data gradient).  A chunk is then 2 or 3 taps x 24
+// MFMAs = 0.64 / 0.96 us, shorter than an LDS-DMA takes to land, so chunk c+2 is staged during chunk c -- THREE stages of 42 / 48 KiB -- and retired
+// by a counted vmcnt(Q_WAVE) at the barrier of chunk c+1 (every wave issues the same number of DMA instructions per chunk: the count is valid).
+template <int NTAPS>
+__global__ __launch_bounds__(256, 1) void conv_bf16x3_wide3_kernel(ConvArgs a, const unsigned short* __restrict__ xs, const unsigned short* __restrict__ ws,
+                                                                  size_t x_plane, size_t w_plane, int m_tiles, int n_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(NTAPS >= 2 && NTAPS <= 3, "the short-tap launches");
+  constexpr int IS = 1, ABL = 0;
+  constexpr int TM = 256, TN = 64;
+  constexpr int RPER = IS == 1 ? 320 : 258;                // rows of one parity class of a region (stride 1: one class, padded to whole 64-row DMA segments)
+  constexpr int RTOT = IS * RPER;                          // LDS rows of one (plane, k-half) region
+  constexpr int ASEG = (RTOT + 63) / 64;                   // 64-row DMA segments per region (the last one partial at stride 2: lanes past the region are masked)
+  constexpr int REGION = RTOT * 16;
+  constexpr int A_BYTES = 6 * REGION, B_BYTES = 6 * NTAPS * 1024, STAGE = A_BYTES + B_BYTES;
+  static_assert(3 * STAGE <= 160 * 1024, "three stages must fit the CU's LDS");
+  constexpr int Q_TOTAL = 6 * ASEG + 6 * NTAPS;            // wave-level DMA instructions per chunk
+  constexpr int Q_WAVE = (Q_TOTAL + 3) / 4;                // ... per wave
+  constexpr int VMCNT_Q = 0x0F70 | (Q_WAVE & 15) | ((Q_WAVE >> 4) << 14);          // s_waitcnt vmcnt(Q_WAVE), lgkmcnt / expcnt untouched
+  constexpr int DMA_PER_TAP = (Q_WAVE + NTAPS - 2) / (NTAPS - 1);                   // chunk c+2 goes out over taps 0 .. NTAPS-2 of chunk c
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i32 = lane & 31, h = lane >> 5;
+  int lin = blockIdx.x;
+  const int nb = gridDim.x;
+  if (lin < (nb & ~7)) lin = (lin & 7) * (nb >> 3) + (lin >> 3);
+  const int n_tile = lin % n_tiles;
+  const int rest = lin / n_tiles;
+  const int m_tile = rest % m_tiles;
+  const int b = rest / m_tiles;
+  const int m0 = m_tile * TM, n0 = n_tile * TN;
+
+  int minoff = a.t.off[0], maxoff = a.t.off[0];
+#pragma unroll
+  for (int j = 1; j < NTAPS; ++j) {
+    minoff = min(minoff, a.t.off[j]);
+    maxoff = max(maxoff, a.t.off[j]);
+  }
+  const int R = IS * (TM - 1) + (maxoff - minoff) + 1;     // staged input rows (the launcher checks the taps span <= 5 rows)
+  const int n_chunks = a.Cin >> 4;
+  const int Lg = a.Lin + 2;
+  const int t_base = IS * m0 + minoff;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const unsigned short* src[Q_WAVE];
+  int dst[Q_WAVE];
+  bool live[Q_WAVE];
+  size_t step[Q_WAVE];
+#pragma unroll
+  for (int i = 0; i < Q_WAVE; ++i) {
+    int q = wm + 4 * i;
+    if (q >= Q_TOTAL) q = Q_TOTAL - 1;                      // padding instruction: repeats the last one (same bytes, same place)
+    if (q < 6 * ASEG) {
+      const int ph = q / ASEG, seg = q % ASEG;
+      const int lr = seg * 64 + lane;                                                        // LDS row inside the region
+      const int r = (IS == 1) ? lr : (lr < RPER ? 2 * lr : 2 * (lr - RPER) + 1);             // input row it holds (stride 2: even rows, then odd rows)
+      const int t = t_base + r;
+      const int row = (r < R && t >= 0 && t < a.Lin) ? t + 1 : 0;                           // 0 = the leading zero guard row
+      src[i] = xs + (ph >> 1) * x_plane + ((((size_t)b * n_chunks) * 2 + (ph & 1)) * Lg + row) * 8;
+      dst[i] = ph * REGION + seg * 1024;
+      live[i] = lr < RTOT;                                                                   // the partial last segment must not write into the next region
+      step[i] = (size_t)2 * Lg * 8;
+    } else {
+      const int qb = q - 6 * ASEG;
+      const int pt = qb >> 1, hh = qb & 1;
+      const int p = pt / NTAPS, tap = pt % NTAPS;
+      src[i] = ws + p * w_plane + ((((size_t)a.t.widx[tap] * n_chunks) * 2 + hh) * a.Cout + n0 + lane) * 8;
+      dst[i] = A_BYTES + qb * 1024;
+      live[i] = true;
+      step[i] = (size_t)2 * a.Cout * 8;
+    }
+  }
+  bool in_loop = false;
+  auto dma_one = [&](int i, int c, unsigned char* stage) {
+    if ((ABL & 2) && in_loop) return;
+    if (IS == 1 || live[i]) __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)c * step[i]), (lptr_t)(stage + dst[i]), 16, 0, 0);
+  };
+  auto read_tap = [&](const unsigned char* sa, int j, bf16x8 (&av)[3][2], bf16x8 (&bv)[3][2]) {
+    if ((ABL & 1) && in_loop) return;
+    const int d = a.t.off[j] - minoff;
+    const int rowbase = (IS == 1) ? d : ((d & 1) * RPER + (d >> 1));
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        av[p][mt] = *reinterpret_cast<const bf16x8*>(sa + ((p * 2 + h) * RTOT + rowbase + wm * 64 + mt * 32 + i32) * 16);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        bv[p][nt] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + (((p * NTAPS + j) * 2 + h) * 64 + nt * 32 + i32) * 16);
+    }
+  };
+  auto mma_tap = [&](const bf16x8 (&av)[3][2], const bf16x8 (&bv)[3][2]) {
+    // smallest terms first: hi*lo, lo*hi, mid*mid, then hi*mid, mid*hi, then hi*hi
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[q]][mt], bv[PB[q]][nt], acc[mt][nt], 0, 0, 0);
+  };
+
+  // ---- prologue: chunks 0 and 1 staged and landed
+#pragma unroll
+  for (int i = 0; i < Q_WAVE; ++i) dma_one(i, 0, smem_b);
+#pragma unroll
+  for (int i = 0; i < Q_WAVE; ++i) dma_one(i, min(1, n_chunks - 1), smem_b + STAGE);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 fa[2][3][2], fb[2][3][2];                          // fragment double buffer: the tap with running parity P reads from [P], prefetches into [P ^ 1]
+  read_tap(smem_b, 0, fa[0], fb[0]);
+  in_loop = true;
+  int s_cur = 0;                                            // stage of chunk ch; chunk ch+1 sits in s_cur + 1, chunk ch+2 goes to s_cur + 2 (mod 3)
+  auto do_chunk = [&](int ch, auto p0) {
+    constexpr int P0 = decltype(p0)::value;
+    const int s_nxt = s_cur == 2 ? 0 : s_cur + 1;
+    unsigned char* sa = smem_b + s_cur * STAGE;
+    unsigned char* sb = smem_b + s_nxt * STAGE;
+    unsigned char* s_dma = smem_b + (s_nxt == 2 ? 0 : s_nxt + 1) * STAGE;      // = the stage of chunk ch-1: every wave is past that chunk's barrier
+    const int c_dma = min(ch + 2, n_chunks - 1);            // past the end: one harmless re-stage of the last chunk keeps the count uniform
+#pragma unroll
+    for (int j = 0; j < NTAPS; ++j) {
+      const int P = (P0 + j) & 1;
+      __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): this tap's fragments are in registers
+      __builtin_amdgcn_sched_barrier(0);
+      int ndma = 0;
+      if (j + 1 < NTAPS) {
+#pragma unroll
+        for (int i = j * DMA_PER_TAP; i < (j + 1) * DMA_PER_TAP && i < Q_WAVE; ++i) { dma_one(i, c_dma, s_dma); ++ndma; }
+        read_tap(sa, j + 1, fa[P ^ 1], fb[P ^ 1]);
+      } else {
+        // every read of stage sa has landed; chunk ch+1 must have landed: at most this chunk's own Q_WAVE DMAs (chunk ch+2) stay in flight
+        __builtin_amdgcn_s_waitcnt(VMCNT_Q);
+        __builtin_amdgcn_s_barrier();
+        if (ch + 1 < n_chunks) read_tap(sb, 0, fa[P ^ 1], fb[P ^ 1]);
+      }
+      mma_tap(fa[P], fb[P]);
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (k < ndma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    s_cur = s_nxt;
+  };
+  if constexpr (NTAPS % 2 == 0) {
+    for (int ch = 0; ch < n_chunks; ++ch) do_chunk(ch, std::integral_constant<int, 0>{});
+  } else {
+    for (int ch = 0; ch < n_chunks; ch += 2) {
+      do_chunk(ch, std::integral_constant<int, 0>{});
+      if (ch + 1 < n_chunks) do_chunk(ch + 1, std::integral_constant<int, 1>{});
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): drain the trailing DMAs before the block may end
+
+  if constexpr ((ABL & 4) != 0) {
+    if (acc[0][0][0] == 12345.678f) a.y[0] = acc[0][0][0] + acc[1][1][15] + acc[0][1][3] + acc[1][0][7];      // keeps the accumulators alive
+    return;
+  }
+  // the lean epilogue of the hand-scheduled fp32 kernel (conv_epilogue.h): activation / fused variants decided once per wave, buffer stores with a
+  // scalar row offset, rows past M dropped by the descriptor's range check -- the generic per-element epilogue cost 10 % of this kernel's time at
+  // one block per CU (2.92 against 3.25 ms on G 512 -> 1024 at batch 64 without it)
+  const int mode = a.gy ? (a.gmask ? 3 : 2) : (a.mask ? 1 : 0);
+  pipe_epilogue_dispatch<2>(a, acc, b, m0 + wm * 64, n0, i32, h, a.t.out_off, mode);
+#endif
+}
+
 // Measured and NOT kept (round 4): a wave-specialised form -- a fifth "producer" wave issues all 60 LDS-DMA instructions of a chunk, the four MFMA
 // waves only read fragments and multiply.  The ablation above reads as if the 12 % were the cost of issuing the staging from the MFMA waves; it is
 // not: with the producer wave the kernel runs at the same 226-228 TFLOP/s, so what the staging costs is LDS bandwidth shared with the fragment
@@ -584,6 +766,27 @@ static int launch_bf16x3_wide(const ConvArgs& a, int w_taps, void* ws, hipStream
   return check_launch("conv_bf16x3_wide");
 }
 
+template <int NTAPS>
+static int launch_bf16x3_wide3(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
+  constexpr size_t lds = 3 * ((size_t)6 * 320 * 16 + (size_t)6 * NTAPS * 1024);
+  static_assert(lds <= 160 * 1024, "three stages must fit the CU's LDS");
+  static unsigned long long lds_done = 0;
+  allow_big_lds((const void*)conv_bf16x3_wide3_kernel<NTAPS>, &lds_done);
+  const int m_tiles = (a.M + 255) / 256, n_tiles = a.Cout / 64;
+  const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
+  if (blocks == 0 || blocks > 0x7fffffffull) {
+    set_error("conv_bf16x3_wide3: bad grid %zu", blocks);
+    return GN_EINVAL;
+  }
+  const size_t xn = (size_t)a.B * (a.Lin + 2) * a.Cin, wn = (size_t)w_taps * a.Cin * a.Cout;
+  const unsigned short* xs = (const unsigned short*)ws;
+  const unsigned short* wsp = xs + 3 * xn;
+  prof_begin(s);
+  hipLaunchKernelGGL((conv_bf16x3_wide3_kernel<NTAPS>), dim3((unsigned)blocks), dim3(256), lds, s, a, xs, wsp, xn, wn, m_tiles, n_tiles);
+  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 2);
+  return check_launch("conv_bf16x3_wide3");
+}
+
 int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
   if (!conv_bf16x3_supported(a)) {
     set_error("conv_bf16x3: shape not supported (Cin %% 16, Cout %% 64, taps <= 5, unit input stride)");
@@ -592,6 +795,14 @@ int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
   if (a.t.in_stride == 2) return launch_bf16x3_wide<5, 0, 2>(a, w_taps, ws, s);
   // 64 x 64 wave tiles in 256-row blocks for the 4- / 5-tap launches whose rows fill them (round 4); GN_BF16X3_NARROW keeps round 1's kernel
   static const bool narrow = getenv("GN_BF16X3_NARROW") != nullptr;
+  if (!narrow && (a.t.ntaps == 2 || a.t.ntaps == 3) && a.M >= 192) {
+    int minoff = a.t.off[0], maxoff = a.t.off[0];
+    for (int j = 1; j < a.t.ntaps; ++j) {
+      minoff = std::min(minoff, a.t.off[j]);
+      maxoff = std::max(maxoff, a.t.off[j]);
+    }
+    if (maxoff - minoff + 1 <= 5) return a.t.ntaps == 2 ? launch_bf16x3_wide3<2>(a, w_taps, ws, s) : launch_bf16x3_wide3<3>(a, w_taps, ws, s);
+  }
   if (!narrow && a.t.ntaps >= 4 && a.M >= 192) {
     int minoff = a.t.off[0], maxoff = a.t.off[0];
     for (int j = 1; j < a.t.ntaps; ++j) {

@@ -22,6 +22,9 @@ CASES = [
     (2, 400, 32, 64, 4, 'same'),         # round 4's 256-row blocks of 64 x 64 wave tiles: 4 taps, ragged second tile, two chunks
     (3, 700, 80, 192, 5, 'valid'),       # ... 5 taps, odd chunk count (the fragment double buffer's parity alternates per chunk), 3 N tiles, 3 M tiles
     (1, 192, 16, 64, 5, 'same'),         # ... one chunk only
+    (2, 500, 80, 128, 3, 'same'),        # the three-stage form of the short-tap launches: 3 taps, 5 chunks (odd), ragged second block
+    (1, 700, 64, 64, 2, 'valid'),        # ... 2 taps, 4 chunks: every chunk's DMAs go out in its first tap
+    (1, 256, 1024, 512, 3, 'same'),      # ... 64 chunks: the stage ring wraps many times
 ]
 
 
@@ -73,6 +76,33 @@ def test_bf16x3_rejects_unsupported_shapes():
     x = torch.zeros(1, 64, 32, device=dev); w = torch.ones(5, 32, 64, device=dev)
     with pytest.raises(_lib.GennetHipError):
         ops.conv1d_fwd_bf16x3(x, w, b, 2, 1, 32)                                  # stride 2 is not implemented
+
+
+@pytest.mark.parametrize('B,L,Cin,Cout,padding', [(2, 800, 256, 256, 'same'), (1, 1030, 256, 512, 'valid')])
+def test_stride2_data_gradient_under_the_opt_in_split(B, L, Cin, Cout, padding):
+    """The data gradient of a stride-2 convolution is two output phases of 3 and 2 taps: under the opt-in math they run on the three-stage
+    64 x 64-wave-tile kernel (chunk c + 2 staged during chunk c).  Checked against the fp64 definition at the exact path's tolerance."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(L + Cin)
+    w = (rng.randn(5, Cin, Cout) / np.sqrt(5 * Cin)).astype(np.float32)
+    Lout, pl = ops.conv_geometry(L, 5, 2, padding)
+    dy = (rng.randn(B, Lout, Cout) * np.exp(rng.randn(B, Lout, Cout))).astype(np.float32)
+    ref = K.conv1d_bwd(np.zeros((B, L, Cin)), w.astype(np.float64), dy.astype(np.float64), 2, padding)[0]
+    dev = torch.device('cuda:0')
+    dyt, wt = torch.tensor(dy).to(dev), ops.conv1d_transpose_w(torch.tensor(w).to(dev))
+    exact = ops.conv1d_dgrad(dyt, wt, L, 2, pl).cpu().numpy()
+    ops.prof_enable(True); ops.prof_reset()
+    ops.set_conv_math('bf16x3', workspace_gb=0.25)
+    try:
+        got = ops.conv1d_dgrad(dyt, wt, L, 2, pl).cpu().numpy()
+        used = ops.prof_collect(2)['launches']
+    finally:
+        ops.set_conv_math('fp32')
+        ops.prof_enable(False)
+    assert used == 2, used                       # both phases took the split kernel
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 2e-6 * scale, np.abs(got - ref).max() / scale
+    assert np.abs(got - ref).max() <= 2.0 * np.abs(exact - ref).max() + 1e-7 * scale
 
 
 def test_gan_iteration_under_the_opt_in_split_meets_the_fp32_path_tolerances():
