@@ -375,6 +375,13 @@ int gn_conv1d_wgrad(const float* x, const float* dy, float* dw, float* db, void*
     a.B = B; a.Lin = L; a.Cin = Cin; a.Cout = Cout; a.M = Lout; a.ntaps = k; a.in_stride = stride;
     for (int j = 0; j < k; ++j) a.off[j] = j - pad_left;
     a.db = db;
+    static const int min_cin = getenv("GN_BF16X3_MIN_CIN") ? atoi(getenv("GN_BF16X3_MIN_CIN")) : 256;
+    static const int min_cout = getenv("GN_BF16X3_MIN_COUT") ? atoi(getenv("GN_BF16X3_MIN_COUT")) : 256;
+    static const bool no_wgrad = getenv("GN_BF16X3_NO_WGRAD") != nullptr;           // A/B switch
+    if (g_conv_math == 1 && !no_wgrad && Cin >= min_cin && Cout >= min_cout) {
+      a.split_ws = g_conv_ws;
+      a.split_ws_bytes = g_conv_ws_bytes;
+    }
     rc = wgrad_mfma_dispatch(a, dw, ws_bytes, s);
     if (!rc && a.db_done) return GN_OK;                  // the weight-gradient kernel summed the bias gradient on the way
   }

@@ -77,6 +77,9 @@ struct WgradArgs {
   // wgrad_reduce_kernel, so dw comes out bit-identical -- writes dw and puts the counter back to zero.  NULL: the caller runs wgrad_reduce_kernel.
   int* tile_done;
   float* dw;
+  // opt-in conv math (gn_set_conv_math 'bf16x3'): the workspace of the split planes; NULL on the default path (wgrad_bf16x3.hip)
+  void* split_ws;
+  size_t split_ws_bytes;
   int xcd_order;    // wgrad_pipe_kernel: 1 = splits % 8 == 0 and every XCD (block i -> XCD i mod 8) takes whole K-splits; 2 = every XCD takes one patch of
                     // (Cin tiles / patch_px) x (Cout tiles / (8 / patch_px)) tiles of each split (see the kernel)
   int patch_px;
@@ -133,6 +136,10 @@ size_t conv_bf16x3_workspace_bytes(int B, int Lin, int Cin, int Cout, int w_taps
 bool conv_bf16x3_supported(const ConvArgs& a);
 int conv_bf16x3_split(const ConvArgs& a, int w_taps, void* ws, size_t ws_bytes, bool split_x, bool split_w, hipStream_t s);
 int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s);
+// wgrad_bf16x3.hip (the same split for the weight gradient, opt-in)
+size_t wgrad_bf16x3_workspace_bytes(int B, int M, int Cin, int Cout, int in_stride);
+bool wgrad_bf16x3_supported(const WgradArgs& a);
+int wgrad_bf16x3_run(const WgradArgs& a, int splits, void* ws, size_t ws_bytes, hipStream_t s);
 // small_conv.hip
 int conv_smallcin_dispatch(const ConvArgs& a, hipStream_t s);
 int conv_smallcout_dispatch(const ConvArgs& a, hipStream_t s);

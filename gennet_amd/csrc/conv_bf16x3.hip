@@ -29,8 +29,8 @@
 // ~64 % of the nominal 2.5 PFLOP/s because the chip clocks down under dense bf16 MFMA on random data, and what remains is LDS
 // throughput: per fp32-equivalent flop this scheme moves 1.5x the LDS bytes of the fp32 kernel in 2.67x less matrix-core
 // time, ~4x its LDS load (which was 31 %); the 160 KiB of LDS rules out the larger wave tiles that would cut it.
-// Limits: unit input stride only (the stride-2 slab needs 5 segments per region: 3 x 60 KiB); forward / data-gradient
-// geometry only (no weight gradient); an infinite input comes out as NaN (inf * 0 in a cross term).
+// Limits (round 1's 64 x 32-tile kernel described above; the 64 x 64-wave-tile kernels further down added the stride-2 forward and the 2- / 3-tap phases,
+// wgrad_bf16x3.hip the weight gradient): an infinite input comes out as NaN (inf * 0 in a cross term).
 #include <algorithm>
 #include <type_traits>
 #include <stdlib.h>

@@ -749,6 +749,16 @@ static int launch_wgrad(WgradArgs& a, float* dw, hipStream_t s) {
   dim3 grid(cdiv(a.Cin, TC), cdiv(a.Cout, TN), splits);
   static const bool no_pipe = getenv("GN_WGRAD_NOPIPE") != nullptr;      // A/B switch
   bool piped = false;
+  if constexpr (NTAPS == 5 && WNT == 1) {
+    // opt-in split math: six bf16 products per fp32 product (wgrad_bf16x3.hip); same K-split plan, partial slabs and reduce pass as the exact kernel
+    if (a.split_ws && wgrad_bf16x3_supported(a) && wgrad_bf16x3_workspace_bytes(a.B, a.M, a.Cin, a.Cout, a.in_stride) <= a.split_ws_bytes) {
+      int rc = wgrad_bf16x3_run(a, splits, a.split_ws, a.split_ws_bytes, s);
+      if (rc) return rc;
+      const size_t n = (size_t)NTAPS * a.Cin * a.Cout;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a.part, dw, n / 4, splits, n / 4);
+      return check_launch("wgrad_reduce");
+    }
+  }
   prof_begin(s);
   if constexpr (NTAPS == 5 && WNT == 1) {
     if (!no_pipe && a.Cin % TC == 0 && a.Cout % TN == 0 && maxoff - minoff + 1 == NTAPS && (size_t)a.Lin * a.Cin * 4 < 0x40000000ull &&

@@ -105,6 +105,46 @@ def test_stride2_data_gradient_under_the_opt_in_split(B, L, Cin, Cout, padding):
     assert np.abs(got - ref).max() <= 2.0 * np.abs(exact - ref).max() + 1e-7 * scale
 
 
+@pytest.mark.parametrize('B,L,Cin,Cout,padding,stride', [
+    (2, 300, 256, 256, 'same', 1),       # 10 chunks per batch element, the last one ragged (M = 300)
+    (1, 100, 256, 320, 'valid', 1),      # M = 96: whole chunks; 5 column tiles
+    (3, 77, 384, 256, 'same', 1),        # 3 row tiles of 128 ci, M = 77
+    (4, 20, 256, 256, 'same', 1),        # a batch element shorter than one chunk
+    (2, 1024, 512, 1024, 'same', 1),     # the dominant generator layer's channels; K split inside a batch element
+    (2, 600, 512, 256, 'same', 2),       # stride 2 (even / odd input rows as two classes; from 512 input channels on): pad_left 1 -> the odd class leads
+    (1, 601, 512, 320, 'same', 2),       # ... pad_left 2
+    (3, 155, 640, 256, 'valid', 2),      # ... pad_left 0, M = 76
+    (2, 1024, 512, 1024, 'same', 2)])    # ... the discriminator's / point-estimator's channel counts
+def test_weight_gradient_under_the_opt_in_split(B, L, Cin, Cout, padding, stride):
+    """The weight gradient on the bf16 matrix cores (csrc/wgrad_bf16x3.hip: operands split AND transposed, the tap shift done in registers): against the
+    fp64 definition at the exact kernel's tolerance and not further from it than the exact kernel is; the bias gradient still comes out."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(B + L + Cin)
+    x = (rng.randn(B, L, Cin) * np.exp(rng.randn(B, L, Cin))).astype(np.float32)
+    Lout, pl = ops.conv_geometry(L, 5, stride, padding)
+    dy = (rng.randn(B, Lout, Cout) * np.exp(rng.randn(B, Lout, Cout))).astype(np.float32)
+    _, ref, refb = K.conv1d_bwd(x.astype(np.float64), np.zeros((5, Cin, Cout)), dy.astype(np.float64), stride, padding)
+    dev = torch.device('cuda:0')
+    xt, dyt = torch.tensor(x).to(dev), torch.tensor(dy).to(dev)
+    exact = ops.conv1d_wgrad(xt, dyt, 5, stride, pl)[0].cpu().numpy()
+    ops.prof_enable(True); ops.prof_reset()
+    ops.set_conv_math('bf16x3', workspace_gb=0.25)
+    try:
+        dw, db = ops.conv1d_wgrad(xt, dyt, 5, stride, pl)
+        dw, db = dw.cpu().numpy(), db.cpu().numpy()
+        used = ops.prof_collect(2)['launches']
+    finally:
+        ops.set_conv_math('fp32')
+        ops.prof_enable(False)
+    assert used == 1, used
+    scale = np.abs(ref).max()
+    e3, e32 = np.abs(dw - ref).max() / scale, np.abs(exact - ref).max() / scale
+    assert e3 <= 2e-5, e3
+    assert e3 <= 2.0 * e32 + 1e-7, (e3, e32)
+    assert np.sqrt(np.mean((dw - ref) ** 2)) <= 1.5 * np.sqrt(np.mean((exact - ref) ** 2)) + 1e-8 * scale
+    assert np.abs(db - refb).max() <= 1e-5 * np.abs(refb).max()
+
+
 def test_gan_iteration_under_the_opt_in_split_meets_the_fp32_path_tolerances():
     """The opt-in conv math on the whole path (ops.set_conv_math('bf16x3'): the generator's 256 -> 512 and 512 -> 1024 convolutions, forward and
     data gradient, run as six bf16 products on 64 x 64 wave tiles) against the fp64 oracle with the SAME tolerances as
