@@ -130,8 +130,10 @@ __device__ __forceinline__ bf16x8 shifted_rows(const u32x4& lo, const uint2& hi)
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int IS, int PODD, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgradArgs a, const unsigned short* __restrict__ xt, const unsigned short* __restrict__ dyt,
+// IB = 32-channel blocks of x per wave: 2 -> 4 waves of 64 ci x 32 co (one per SIMD), 1 -> 8 waves of 32 x 32 (two per SIMD: one wave's barrier,
+// operand and VMEM-issue waits are covered by the other's MFMAs)
+template <int IS, int PODD, int ABL = 0, int IB = 2>
+__global__ __launch_bounds__(512 / IB, 1) void wgrad_bf16x3_kernel(WgradArgs a, const unsigned short* __restrict__ xt, const unsigned short* __restrict__ dyt,
                                                               size_t x_plane, size_t dy_plane) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NTAPS = 5, TC = 128, TN = 64, KC = 32;
@@ -141,14 +143,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgradArgs a, const
   static_assert(2 * STAGE <= 160 * 1024, "two stages must fit the CU's LDS");
   constexpr int QA_PLANE = IS * TC * 5 / 64, QB_PLANE = TN * 4 / 64;        // wave-level DMA instructions per plane: 10 (20 at stride 2) and 4
   constexpr int QA = 3 * QA_PLANE, Q_TOTAL = QA + 3 * QB_PLANE;
-  constexpr int Q_WAVE = (Q_TOTAL + 3) / 4;
+  constexpr int NW = 8 / IB;                                // waves per block
+  constexpr int Q_WAVE = (Q_TOTAL + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave >> 1, wn = wave & 1;
+  const int wc = wave >> 1, wn = wave & 1;                 // wc: 0 .. 1 (IB = 2) or 0 .. 3 (IB = 1)
   const int i32 = lane & 31, h = lane >> 5;
   // block -> (Cin tile, Cout tile, K-split).  xcd_order: block i runs on XCD i mod 8; every XCD takes whole K-splits (the splits k, k + 8, ...) with all
   // their tiles one after the other, so each x / dy chunk crosses the fabric once and its reuse by the tiles is served by that XCD's L2
@@ -168,11 +171,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgradArgs a, const
 #pragma unroll
   for (int j = 1; j < NTAPS; ++j) minoff = min(minoff, a.off[j]);
 
-  f32x16 acc[NTAPS][2];
+  f32x16 acc[NTAPS][IB];
 #pragma unroll
   for (int j = 0; j < NTAPS; ++j)
 #pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
+    for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][ib][r] = 0.f;
 
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgradArgs a, const
   int spar[Q_WAVE];                                         // x: parity class; dy: -1
 #pragma unroll
   for (int i = 0; i < Q_WAVE; ++i) {
-    int q = wave + 4 * i;
+    int q = wave + NW * i;
     if (q >= Q_TOTAL) q = Q_TOTAL - 1;                      // padding instruction: repeats the last one
     if (q < QA) {
       const int pl = q / QA_PLANE, f = q % QA_PLANE, par = f / (QA_PLANE / IS), piece = f % (QA_PLANE / IS);
@@ -218,8 +221,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgradArgs a, const
   // Fragment reads of one 16-row step, per plane: for each 32-channel block (and parity class) the aligned rows 16 * ks + 8 * h ... + 11 (a 16- and an
   // 8-byte load: the largest shift is 4 rows), and the 8 dy rows.
   struct Raw {
-    u32x4 alo[3][IS][2];
-    uint2 ahi[3][IS][2];
+    u32x4 alo[3][IS][IB];
+    uint2 ahi[3][IS][IB];
     u32x4 b[3];
   };
   auto read_plane = [&](const unsigned char* st, int ks, int p, Raw& r) {
@@ -228,17 +231,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgradArgs a, const
 #pragma unroll
     for (int par = 0; par < IS; ++par)
 #pragma unroll
-      for (int ib = 0; ib < 2; ++ib) {
-        const unsigned char* q = st + p * A_PLANE + (par * TC + wc * 64 + ib * 32 + i32) * CH_BYTES + rowb;
+      for (int ib = 0; ib < IB; ++ib) {
+        const unsigned char* q = st + p * A_PLANE + (par * TC + wc * (32 * IB) + ib * 32 + i32) * CH_BYTES + rowb;
         r.alo[p][par][ib] = *reinterpret_cast<const u32x4*>(q);
         r.ahi[p][par][ib] = *reinterpret_cast<const uint2*>(q + 16);
       }
     r.b[p] = *reinterpret_cast<const u32x4*>(st + A_BYTES + p * B_PLANE + (wn * 32 + i32) * 64 + (((2 * ks + h) ^ ((i32 >> 2) & 3)) << 4));
   };
   // the five tap fragments of plane p: tap j = rows shift_j .. shift_j + 7 of its parity class
-  auto prep = [&](const Raw& r, int p, bf16x8 (&f)[NTAPS][2]) {
+  auto prep = [&](const Raw& r, int p, bf16x8 (&f)[NTAPS][IB]) {
 #pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
+    for (int ib = 0; ib < IB; ++ib) {
       constexpr int P0 = tap_par<IS, PODD>(0), P1 = tap_par<IS, PODD>(1), P2 = tap_par<IS, PODD>(2), P3 = tap_par<IS, PODD>(3), P4 = tap_par<IS, PODD>(4);
       f[0][ib] = shifted_rows<tap_shift<IS, PODD>(0)>(r.alo[p][P0][ib], r.ahi[p][P0][ib]);
       f[1][ib] = shifted_rows<tap_shift<IS, PODD>(1)>(r.alo[p][P1][ib], r.ahi[p][P1][ib]);
@@ -247,18 +250,18 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgradArgs a, const
       f[4][ib] = shifted_rows<tap_shift<IS, PODD>(4)>(r.alo[p][P4][ib], r.ahi[p][P4][ib]);
     }
   };
-  auto mma = [&](const bf16x8 (&f)[NTAPS][2], const u32x4& braw) {
+  auto mma = [&](const bf16x8 (&f)[NTAPS][IB], const u32x4& braw) {
     const bf16x8 bv = __builtin_bit_cast(bf16x8, braw);
 #pragma unroll
     for (int j = 0; j < NTAPS; ++j)
 #pragma unroll
-      for (int ib = 0; ib < 2; ++ib) acc[j][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j][ib], bv, acc[j][ib], 0, 0, 0);
+      for (int ib = 0; ib < IB; ++ib) acc[j][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j][ib], bv, acc[j][ib], 0, 0, 0);
   };
   // One 16-row step in three stages, products grouped by the x plane (the accumulators persist over all steps of a split, so the order of the six
   // products inside a step does not matter for the rounding): lo * hi | mid * (mid, hi) | hi * (lo, mid, hi) = 10 + 20 + 30 MFMAs.  The fragments of
   // the NEXT stage's plane are formed (VALU) under the current stage's MFMAs, the next step's operands are read (DS) under the first two stages, the
   // staging DMAs (VMEM) go out under the third: sched_group_barrier pins that interleave, one wave per SIMD has nobody else to hide behind.
-  auto step = [&](const Raw& cur, Raw& nxt, const unsigned char* st_next, int ks_next, bf16x8 (&X)[NTAPS][2], bf16x8 (&Y)[NTAPS][2], bool barrier, int dma_ch,
+  auto step = [&](const Raw& cur, Raw& nxt, const unsigned char* st_next, int ks_next, bf16x8 (&X)[NTAPS][IB], bf16x8 (&Y)[NTAPS][IB], bool barrier, int dma_ch,
                   unsigned char* dma_stage) {
     // stage 0: X = lo fragments of cur
     read_plane(st_next, ks_next, 2, nxt);
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgradArgs a, const
     prep(cur, 1, Y);
     mma(X, cur.b[0]);
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
+    for (int k = 0; k < 5 * IB; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, IS, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgradArgs a, const
     mma(Y, cur.b[1]);
     mma(Y, cur.b[0]);
 #pragma unroll
-    for (int k = 0; k < 20; ++k) {
+    for (int k = 0; k < 10 * IB; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       if (k < 5 * IS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
@@ -299,9 +302,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgradArgs a, const
     mma(X, cur.b[1]);
     mma(X, cur.b[0]);
 #pragma unroll
-    for (int k = 0; k < 30; ++k) {
+    for (int k = 0; k < 15 * IB; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (Q_WAVE <= 15 ? (k % 2 == 0 && k / 2 < Q_WAVE) : k < Q_WAVE) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);      // staging DMAs spread under the MFMAs
+      if (2 * Q_WAVE <= 15 * IB ? (k % 2 == 0 && k / 2 < Q_WAVE) : k < Q_WAVE) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);      // staging DMAs spread under the MFMAs
       __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgradArgs a, const
   __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
   asm volatile("s_barrier" ::: "memory");
   Raw r0, r1;
-  bf16x8 X[NTAPS][2], Y[NTAPS][2];
+  bf16x8 X[NTAPS][IB], Y[NTAPS][IB];
   read_plane(smem_b, 0, 0, r0); read_plane(smem_b, 0, 1, r0); read_plane(smem_b, 0, 2, r0);
   __builtin_amdgcn_s_waitcnt(0xC07F);
   prep(r0, 2, X);
@@ -337,10 +340,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgradArgs a, const
       if (a.off[t] - minoff == j) tap = t;
     float* pj = a.part + ((size_t)split * NTAPS + tap) * a.Cin * a.Cout;
 #pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
+    for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int c = c0 + wc * 64 + ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int c = c0 + wc * (32 * IB) + ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         pj[(size_t)c * a.Cout + n] = acc[j][ib][r];
       }
   }
@@ -395,6 +398,7 @@ int wgrad_bf16x3_run(const WgradArgs& a_in, int splits, void* ws, size_t ws_byte
   dim3 grid(a.Cin / 128, a.Cout / 64, splits);
   const unsigned short* xc = xt;
   const unsigned short* dc = dyt;
+  static const bool four_waves = getenv("GN_WGBF_4WAVES") != nullptr;                  // A/B switch: 4 waves of 64 x 32 instead of 8 of 32 x 32 (stride 1)
   static const int abl = getenv("GN_WGBF_ABL") ? atoi(getenv("GN_WGBF_ABL")) : 0;       // timing ablations, stride 1 (results are wrong with any of them)
   prof_begin(s);
   if (IS == 1) {
@@ -409,19 +413,32 @@ int wgrad_bf16x3_run(const WgradArgs& a_in, int splits, void* ws, size_t ws_byte
     } else if (abl == 4) {
       allow_big_lds((const void*)wgrad_bf16x3_kernel<1, 0, 4>, &d4);
       hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 0, 4>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane);
-    } else {
+    } else if (four_waves) {
       allow_big_lds((const void*)wgrad_bf16x3_kernel<1, 0>, &d0);
       hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 0>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane);
+    } else {
+      static unsigned long long d8 = 0;
+      allow_big_lds((const void*)wgrad_bf16x3_kernel<1, 0, 0, 1>, &d8);
+      hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 0, 0, 1>), grid, dim3(512), lds, s, a, xc, dc, x_plane, dy_plane);
     }
   } else {
     constexpr size_t lds = 2 * (size_t)(3 * 2 * 128 * 80 + 3 * 64 * 64);
     static unsigned long long e0 = 0, e1 = 0;
-    if (pl & 1) {
-      allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 1>, &e1);
-      hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 1>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane);
+    static unsigned long long f0 = 0, f1 = 0;
+    if (four_waves) {
+      if (pl & 1) {
+        allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 1>, &e1);
+        hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 1>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane);
+      } else {
+        allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 0>, &e0);
+        hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 0>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane);
+      }
+    } else if (pl & 1) {
+      allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 1, 0, 1>, &f1);
+      hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 1, 0, 1>), grid, dim3(512), lds, s, a, xc, dc, x_plane, dy_plane);
     } else {
-      allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 0>, &e0);
-      hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 0>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane);
+      allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 0, 0, 1>, &f0);
+      hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 0, 0, 1>), grid, dim3(512), lds, s, a, xc, dc, x_plane, dy_plane);
     }
   }
   prof_end(s, 2.0 * a.B * (double)a.M * 5 * a.Cin * a.Cout, 2);

@@ -21,7 +21,10 @@ for (B, L, Cin, Cout) in (((256, 2048, 512, 1024), (256, 2048, 256, 512)) if ST 
         ms = e0.elapsed_time(e1) / 5
         k = ops.prof_collect(2 if name != 'fp32' else 1)
         ops.prof_enable(False)
-        km = k['ms'] / max(k['launches'], 1)
+        if not k['launches']:
+            print('s%d wgrad B%d L%d %d->%d  %-8s not taken (below the size threshold): %.3f ms on the exact kernel' % (ST, B, L, Cin, Cout, name, ms), flush=True)
+            continue
+        km = k['ms'] / k['launches']
         print('s%d ' % ST + 'wgrad B%d L%d %d->%d  %-8s %.3f ms whole (%.1f TFLOP/s), kernel alone %.3f ms (%.1f TFLOP/s)' % (B, L, Cin, Cout, name, ms, flop / ms / 1e9, km, flop / km / 1e9), flush=True)
     ops.set_conv_math('fp32')
     del x, dy
