@@ -10,6 +10,8 @@ layer that feeds a BatchNormalization has an EXACTLY zero gradient in exact arit
 rounding noise that Adam normalises to steps of order lr, so it random-walks by up to steps * lr while the oracle's stays put -- and BatchNormalization
 removes it again from everything downstream, which the loss / predict / statistics bounds confirm.  Its drift is bounded by the step budget instead.
 """
+import contextlib
+
 import numpy as np
 import pytest
 import torch
@@ -33,10 +35,34 @@ def _bn_fed_bias_indices(stack):
     return out
 
 
-@pytest.mark.parametrize("n_pix,B,iters", [(64, 4, 100),
-                                          (1024, 8, 5)])       # the reference script's OWN operating point (bbhMahoGANy.py:84-89): the narrow-wave tiles, sub-batch
-                                                               # K-splits and merged stride-2 data gradients of the batch-8 launches, five iterations in a row
-def test_gan_100_iterations_follow_the_oracle(n_pix, B, iters):
+@contextlib.contextmanager
+def _conv_math(mode):
+    """'bf16x3': the OPT-IN convolution math (six bf16 products per fp32 product: forward, data gradient and weight gradient of the wide layers) for the
+    duration of one test; it has to follow the oracle within the SAME bounds as the exact path -- that is the claim 'fp32-grade'."""
+    from gennet_amd import ops
+    if mode == 'fp32':
+        yield
+        return
+    ops.prof_enable(True); ops.prof_reset()
+    ops.set_conv_math(mode, workspace_gb=1.0)
+    try:
+        yield
+        assert ops.prof_collect(2)['launches'] > 0          # the split kernels really ran
+    finally:
+        ops.set_conv_math('fp32')
+        ops.prof_enable(False)
+
+
+@pytest.mark.parametrize("n_pix,B,iters,math", [(64, 4, 100, 'fp32'),
+                                               (1024, 8, 5, 'fp32'),       # the reference script's OWN operating point (bbhMahoGANy.py:84-89): the narrow-wave tiles,
+                                                                           # sub-batch K-splits and merged stride-2 data gradients of the batch-8 launches, five in a row
+                                               (1024, 8, 5, 'bf16x3')])    # ... and the same five iterations under the opt-in split math, same bounds
+def test_gan_100_iterations_follow_the_oracle(n_pix, B, iters, math):
+    with _conv_math(math):
+        _gan_iterations(n_pix, B, iters)
+
+
+def _gan_iterations(n_pix, B, iters):
     from gennet_amd import bbh
     from gennet_amd.engine import to_device
     rng = np.random.RandomState(31)
@@ -115,8 +141,14 @@ def test_gan_100_iterations_follow_the_oracle(n_pix, B, iters):
     assert rel(G.predict(z3), ref.generate(z3)) < 2e-4
 
 
-@pytest.mark.parametrize("n_pix,B,steps", [(64, 4, 100), (1024, 8, 10)])       # ... and ten steps at the reference script's own n_pix 1024 / batch 8
-def test_cnn_100_steps_follow_the_oracle(n_pix, B, steps):
+@pytest.mark.parametrize("n_pix,B,steps,math", [(64, 4, 100, 'fp32'), (1024, 8, 10, 'fp32'),       # ... and ten steps at the reference script's own n_pix 1024 / batch 8
+                                               (1024, 8, 10, 'bf16x3')])                           # ... and under the opt-in split math
+def test_cnn_100_steps_follow_the_oracle(n_pix, B, steps, math):
+    with _conv_math(math):
+        _cnn_steps(n_pix, B, steps)
+
+
+def _cnn_steps(n_pix, B, steps):
     from gennet_amd import bbh
     from gennet_amd.engine import Adam
     rng = np.random.RandomState(32)
