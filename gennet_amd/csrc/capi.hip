@@ -84,6 +84,16 @@ static int g_conv_math = 0;
 static void* g_conv_ws = nullptr;
 static size_t g_conv_ws_bytes = 0;
 
+// The output phases of one strided data gradient read the same dy and the same kernel: under the opt-in split math the first phase splits them (ALL k
+// taps of the kernel, so that the planes' layout does not depend on the phase), the later phases reuse the planes (8 of the 28 split passes of a
+// BASELINE step are such repeats).  Set by dgrad_impl around its phase loop.
+static int g_phase_w_taps = 0;
+static bool g_phase_have_split = false;
+struct PhaseScope {
+  explicit PhaseScope(int w_taps) { g_phase_w_taps = w_taps; g_phase_have_split = false; }
+  ~PhaseScope() { g_phase_w_taps = 0; g_phase_have_split = false; }
+};
+
 static int conv_dispatch(const ConvArgs& a, hipStream_t s) {
   if (a.Cin <= 4) return conv_smallcin_dispatch(a, s);
   if (a.Cout <= 4) return conv_smallcout_dispatch(a, s);
@@ -94,9 +104,15 @@ static int conv_dispatch(const ConvArgs& a, hipStream_t s) {
   if (g_conv_math == 1 && a.Cin >= min_cin && a.Cout >= min_cout && conv_bf16x3_supported(a)) {
     int w_taps = 0;
     for (int j = 0; j < a.t.ntaps; ++j) w_taps = std::max(w_taps, a.t.widx[j] + 1);
+    static const bool no_reuse = getenv("GN_BF16X3_NO_PHASE_REUSE") != nullptr;       // A/B switch
+    const bool phased = g_phase_w_taps > 0 && !no_reuse;
+    if (phased) w_taps = g_phase_w_taps;
     if (conv_bf16x3_workspace_bytes(a.B, a.Lin, a.Cin, a.Cout, w_taps) <= g_conv_ws_bytes) {
-      int rc = conv_bf16x3_split(a, w_taps, g_conv_ws, g_conv_ws_bytes, true, true, s);
-      if (rc) return rc;
+      if (!(phased && g_phase_have_split)) {
+        int rc = conv_bf16x3_split(a, w_taps, g_conv_ws, g_conv_ws_bytes, true, true, s);
+        if (rc) return rc;
+        g_phase_have_split = phased;
+      }
       return conv_bf16x3_run(a, w_taps, g_conv_ws, s);
     }
   }
@@ -325,6 +341,7 @@ static int dgrad_impl(const float* dy, const float* wt, float* dx, int B, int L,
     int rc = conv_pipe_try_merged(a, (hipStream_t)stream, &launched);
     if (rc || launched) return rc;
   }
+  PhaseScope phases(stride > 1 ? k : 0);
   for (int p = 0; p < stride; ++p) {
     if (p >= L) break;
     ConvArgs a = {};
