@@ -62,35 +62,47 @@ __device__ inline uint4 pack8(const unsigned short* p) {
 }
 
 // x (B, L, C) fp32 -> planes[3][B][C/16][2][L + 2][8] bf16 (row 0 and row L + 1 of every run are zeros).
-// Block = 32 rows x 64 channels; thread = (row, 8-channel group): reads are 256-byte runs per row, writes 128-byte runs
-// (8 consecutive rows of one group) per plane.
+// Block = 64 rows x 64 channels of one batch element.  Rows are read as 256-byte runs (all four loads of a thread in flight before the first is used),
+// split, regrouped through LDS into the 16-byte granules of 8 channels and written as 1-KiB runs (64 consecutive rows of one channel group) per plane.
+// (Until round 4 a thread read its own 32 bytes of a row and wrote its three granules: 64-byte pieces per wave and row, 3.9 TB/s.)
 __global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ x, unsigned short* __restrict__ planes, int B, int L, int C) {
-  // thread -> (8-channel group, row): a wave takes 2 groups x 32 rows, so that per plane it writes two 512-byte runs (32 consecutive rows of one
-  // group) instead of eight 128-byte ones; the four waves of the block cover the 8 groups of the same 32 rows, so every 256-byte row segment they
-  // read is shared inside the block (round 4: the pass ran at 2.6 TB/s with 128-byte runs)
-  const int g = (threadIdx.x >> 6) * 2 + ((threadIdx.x >> 5) & 1), rl = threadIdx.x & 31;
-  const int c8 = blockIdx.y * 8 + g;                       // 8-channel group index = chunk * 2 + half
-  const size_t row = (size_t)blockIdx.x * 32 + rl;         // flattened (b, t)
-  if (row >= (size_t)B * L || c8 * 8 >= C) return;
-  const int b = (int)(row / L), t = (int)(row % L);
-  const float* src = x + row * C + 8 * c8;
-  const float4 v0 = reinterpret_cast<const float4*>(src)[0], v1 = reinterpret_cast<const float4*>(src)[1];
-  const float vs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-  unsigned short h[8], m[8], l[8];
+  constexpr int GSTRIDE = 64 * 16 + 64;                     // bytes per (plane, channel group) in LDS: 64 granules + a pad that staggers the groups' banks
+  __shared__ __attribute__((aligned(16))) unsigned char T[3 * 8 * GSTRIDE];
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+  const int c4 = tid & 15, r16 = tid >> 4;
+  const float* sb = x + (size_t)b * L * C + min(c0 + 4 * c4, C - 4);      // (C % 16 == 0: the last channel tile may be partial; its surplus granules are not written)
+  float4 v[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) split3(vs[e], h[e], m[e], l[e]);
+  for (int pass = 0; pass < 4; ++pass) v[pass] = *reinterpret_cast<const float4*>(sb + (size_t)min(t0 + pass * 16 + r16, L - 1) * C);      // clamped, masked below
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int row = pass * 16 + r16;
+    const float e[4] = {v[pass].x, v[pass].y, v[pass].z, v[pass].w};
+    unsigned short h[4], m[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) split3(e[k], h[k], m[k], l[k]);
+    unsigned char* q = T + (c4 >> 1) * GSTRIDE + row * 16 + (c4 & 1) * 8;
+    *reinterpret_cast<uint2*>(q) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2*>(q + 8 * GSTRIDE) = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
+    *reinterpret_cast<uint2*>(q + 16 * GSTRIDE) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+  }
+  __syncthreads();
   const size_t plane = (size_t)B * C * (L + 2);
-  const size_t run = ((size_t)b * (C >> 3) + c8) * (L + 2);
-  const size_t o = (run + 1 + t) * 8;
-  *reinterpret_cast<uint4*>(planes + o) = pack8(h);
-  *reinterpret_cast<uint4*>(planes + plane + o) = pack8(m);
-  *reinterpret_cast<uint4*>(planes + 2 * plane + o) = pack8(l);
-  if (t == 0 || t == L - 1) {
-    const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      if (t == 0) *reinterpret_cast<uint4*>(planes + p * plane + run * 8) = z;
-      if (t == L - 1) *reinterpret_cast<uint4*>(planes + p * plane + (run + L + 1) * 8) = z;
+  for (int k = 0; k < 6; ++k) {
+    const int idx = tid + k * 256;
+    const int row = idx & 63, g = (idx >> 6) & 7, pl = idx >> 9;
+    const int t = t0 + row;
+    if (t < L && c0 + 8 * g < C) {
+      const uint4 val = *reinterpret_cast<const uint4*>(T + (pl * 8 + g) * GSTRIDE + row * 16);
+      const size_t run = ((size_t)b * (C >> 3) + (c0 >> 3) + g) * (L + 2);
+      unsigned short* o = planes + pl * plane + (run + 1 + t) * 8;
+      *reinterpret_cast<uint4*>(o) = val;
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      if (t == 0) *reinterpret_cast<uint4*>(planes + pl * plane + run * 8) = z;
+      if (t == L - 1) *reinterpret_cast<uint4*>(planes + pl * plane + (run + L + 1) * 8) = z;
     }
   }
 }
@@ -713,7 +725,7 @@ int conv_bf16x3_split(const ConvArgs& a, int w_taps, void* ws, size_t ws_bytes, 
   unsigned short* xs = (unsigned short*)ws;
   unsigned short* wsp = xs + 3 * xn;
   if (split_x) {
-    hipLaunchKernelGGL(split_x_kernel, dim3(cdiv((size_t)a.B * a.Lin, 32), cdiv(a.Cin, 64)), dim3(256), 0, s, a.x, xs, a.B, a.Lin, a.Cin);
+    hipLaunchKernelGGL(split_x_kernel, dim3(cdiv(a.Lin, 64), cdiv(a.Cin, 64), a.B), dim3(256), 0, s, a.x, xs, a.B, a.Lin, a.Cin);
     int rc = check_launch("split_x");
     if (rc) return rc;
   }
