@@ -320,7 +320,7 @@ static int dgrad_impl(const float* dy, const float* wt, float* dx, int B, int L,
   if (B == 0) return GN_OK;
   // dx[b, tau, ci] = sum_{k', co} dy[b, t, co] * wt[k', co, ci]  with  stride*t + k' - pad_left == tau.
   // Output phase p = tau mod stride uses the taps with (p + pad_left - k') divisible by stride, at dy row m + (p+pad_left-k')/stride.
-  if (stride == 2 && k == 5 && L >= 2 && Cin > 4 && Cout > 4 && g_conv_math == 0) {
+  if (stride == 2 && k == 5 && L >= 2 && Cin > 4 && Cout > 4) {
     // both output phases in one launch where the pipelined kernel takes it (conv_pipe_try_merged): tap kk belongs to phase (kk + pad_left) & 1
     ConvArgs a = {};
     a.x = dy; a.w = wt; a.bias = nullptr; a.y = dx;
@@ -337,9 +337,22 @@ static int dgrad_impl(const float* dy, const float* wt, float* dx, int B, int L,
     a.t.out_off_odd = 1 - (pad_left & 1);
     a.act = GN_ACT_LINEAR;
     a.gy = gy; a.gmask = gmask; a.gact = gact; a.gparam = gparam; a.gscale = 1.0f / (1.0f - grate);
-    bool launched = false;
-    int rc = conv_pipe_try_merged(a, (hipStream_t)stream, &launched);
-    if (rc || launched) return rc;
+    if (g_conv_math == 0) {
+      bool launched = false;
+      int rc = conv_pipe_try_merged(a, (hipStream_t)stream, &launched);
+      if (rc || launched) return rc;
+    } else {
+      // opt-in split math: one launch for both phases where the 256-row blocks fill (the x fragments of tap pairs that read the same rows are read once)
+      static const int min_cin = getenv("GN_BF16X3_MIN_CIN") ? atoi(getenv("GN_BF16X3_MIN_CIN")) : 256;
+      static const int min_cout = getenv("GN_BF16X3_MIN_COUT") ? atoi(getenv("GN_BF16X3_MIN_COUT")) : 256;
+      static const bool no_merge = getenv("GN_BF16X3_NO_MERGE") != nullptr;            // A/B switch
+      if (!no_merge && a.Cin >= min_cin && a.Cout >= min_cout && conv_bf16x3_merged_kind(a) &&
+          conv_bf16x3_workspace_bytes(a.B, a.Lin, a.Cin, a.Cout, 5) <= g_conv_ws_bytes) {
+        int rc = conv_bf16x3_split(a, 5, g_conv_ws, g_conv_ws_bytes, true, true, (hipStream_t)stream);
+        if (rc) return rc;
+        return conv_bf16x3_run_merged(a, g_conv_ws, (hipStream_t)stream);
+      }
+    }
   }
   PhaseScope phases(stride > 1 ? k : 0);
   for (int p = 0; p < stride; ++p) {

@@ -136,6 +136,8 @@ size_t conv_bf16x3_workspace_bytes(int B, int Lin, int Cin, int Cout, int w_taps
 bool conv_bf16x3_supported(const ConvArgs& a);
 int conv_bf16x3_split(const ConvArgs& a, int w_taps, void* ws, size_t ws_bytes, bool split_x, bool split_w, hipStream_t s);
 int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s);
+int conv_bf16x3_merged_kind(const ConvArgs& a);            // 0: not the merged two-phase shape
+int conv_bf16x3_run_merged(const ConvArgs& a, void* ws, hipStream_t s);
 // wgrad_bf16x3.hip (the same split for the weight gradient, opt-in)
 size_t wgrad_bf16x3_workspace_bytes(int B, int M, int Cin, int Cout, int in_stride);
 bool wgrad_bf16x3_supported(const WgradArgs& a);

@@ -322,12 +322,24 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgs a, const u
 // loop, bit 2 = no epilogue
 // IS = input stride (1, or 2 for the stride-2 forward: the slab is staged de-interleaved, even input rows then odd ones, so that every tap reads a
 // unit-stride run -- 258 + 258 rows per (plane, k-half) region, 80 256 bytes per stage: two stages just fit the 160 KiB).
-template <int NTAPS, int ABL = 0, int IS = 1>
+// MERGE (1, 2): BOTH output phases of a stride-2 data gradient in one launch -- five taps in kernel-tap order, even index -> accumulator set 0 (rows
+// out_stride * m + out_off), odd index -> set 1 (out_off_odd), offsets spanning three rows.  Two pairs of neighbouring taps read the SAME input rows
+// (pad_left odd, MERGE 1: taps (1, 2) and (3, 4); even, MERGE 2: (0, 1) and (2, 3)): their x fragments are read once -- 18 + 30 fragment reads per
+// chunk instead of the 30 + 30 of five distinct taps, in a kernel that is bound by exactly those reads -- and the slab is staged once, not per phase.
+template <int MERGE> __host__ __device__ constexpr bool tap_shares_a(int j) { return MERGE == 1 ? (j == 2 || j == 4) : MERGE == 2 ? (j == 1 || j == 3) : false; }
+template <int MERGE> __host__ __device__ constexpr int a_reads_upto(int j) {       // x-fragment reads among taps 1 .. j
+  int n = 0;
+  for (int t = 1; t <= j; ++t) n += tap_shares_a<MERGE>(t) ? 0 : 1;
+  return n;
+}
+template <int NTAPS, int ABL = 0, int IS = 1, int MERGE = 0>
 __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, const unsigned short* __restrict__ xs, const unsigned short* __restrict__ ws,
                                                                   size_t x_plane, size_t w_plane, int m_tiles, int n_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(NTAPS >= 4 && NTAPS <= 5, "a chunk must outlast the staging latency: 4 or 5 taps");
   static_assert(IS == 1 || (IS == 2 && NTAPS == 5), "stride 2: the 5-tap forward only");
+  static_assert(MERGE == 0 || (NTAPS == 5 && IS == 1), "merged phases: five taps, unit input stride");
+  constexpr int NSETS = MERGE ? 2 : 1;
   constexpr int TM = 256, TN = 64;
   constexpr int RPER = IS == 1 ? 320 : 258;                // rows of one parity class of a region (stride 1: one class, padded to whole 64-row DMA segments)
   constexpr int RTOT = IS * RPER;                          // LDS rows of one (plane, k-half) region
@@ -365,13 +377,15 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
   const int Lg = a.Lin + 2;
   const int t_base = IS * m0 + minoff;
 
-  f32x16 acc[2][2];
+  f32x16 acc[NSETS][2][2];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int st = 0; st < NSETS; ++st)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[st][mt][nt][r] = 0.f;
 
   const unsigned short* src[Q_WAVE];
   int dst[Q_WAVE];
@@ -406,21 +420,23 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
     if ((ABL & 2) && in_loop) return;
     if (IS == 1 || live[i]) __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)c * step[i]), (lptr_t)(stage + dst[i]), 16, 0, 0);
   };
-  auto read_tap = [&](const unsigned char* sa, int j, bf16x8 (&av)[3][2], bf16x8 (&bv)[3][2]) {
+  auto read_tap = [&](const unsigned char* sa, int j, bf16x8 (&av)[3][2], bf16x8 (&bv)[3][2], bool with_a = true) {
     if ((ABL & 1) && in_loop) return;
     const int d = a.t.off[j] - minoff;
     const int rowbase = (IS == 1) ? d : ((d & 1) * RPER + (d >> 1));
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
+      if (with_a) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        av[p][mt] = *reinterpret_cast<const bf16x8*>(sa + ((p * 2 + h) * RTOT + rowbase + wm * 64 + mt * 32 + i32) * 16);
+        for (int mt = 0; mt < 2; ++mt)
+          av[p][mt] = *reinterpret_cast<const bf16x8*>(sa + ((p * 2 + h) * RTOT + rowbase + wm * 64 + mt * 32 + i32) * 16);
+      }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
         bv[p][nt] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + (((p * NTAPS + j) * 2 + h) * 64 + nt * 32 + i32) * 16);
     }
   };
-  auto mma_tap = [&](const bf16x8 (&av)[3][2], const bf16x8 (&bv)[3][2]) {
+  auto mma_tap = [&](const bf16x8 (&av)[3][2], const bf16x8 (&bv)[3][2], int st) {
     // smallest terms first: hi*lo, lo*hi, mid*mid, then hi*mid, mid*hi, then hi*hi
     constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
@@ -428,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[q]][mt], bv[PB[q]][nt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < 2; ++nt) acc[st][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[q]][mt], bv[PB[q]][nt], acc[st][mt][nt], 0, 0, 0);
   };
 
   // ---- prologue: chunks 0 and 1 staged and landed
@@ -451,7 +467,10 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
 #pragma unroll
     for (int j = 0; j < NTAPS; ++j) {
       constexpr int dummy = 0; (void)dummy;
-      const int P = (P0 + j) & 1;
+      const int P = (P0 + j) & 1;                           // weight fragments: one set per tap
+      const int PA_ = (P0 + a_reads_upto<MERGE>(j)) & 1;    // x fragments: a tap that shares its rows with the tap before keeps that tap's set
+      const int PAn = (P0 + a_reads_upto<MERGE>(j) + 1) & 1;
+      const bool nxt_a = j + 1 < NTAPS ? !tap_shares_a<MERGE>(j + 1) : true;
       __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): this tap's fragments are in registers
       __builtin_amdgcn_sched_barrier(0);
       int ndma = 0;
@@ -461,7 +480,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
           for (int i = Q_FIRST; i < Q_WAVE; ++i) dma_one(i, c_dma1, sb);
           ndma = Q_WAVE - Q_FIRST;
         }
-        read_tap(sa, j + 1, fa[P ^ 1], fb[P ^ 1]);
+        read_tap(sa, j + 1, fa[nxt_a ? PAn : PA_], fb[P ^ 1], nxt_a);
       } else {
         // every read of stage sa has landed (lgkmcnt(0) above, on every wave once past the barrier); chunk ch+1 must have landed
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -469,9 +488,9 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
 #pragma unroll
         for (int i = 0; i < Q_FIRST; ++i) dma_one(i, c_dma2, sa);      // (past the end: one harmless re-stage of the last chunk keeps the count uniform)
         ndma = Q_FIRST;
-        if (ch + 1 < n_chunks) read_tap(sb, 0, fa[P ^ 1], fb[P ^ 1]);
+        if (ch + 1 < n_chunks) read_tap(sb, 0, fa[PAn], fb[P ^ 1]);
       }
-      mma_tap(fa[P], fb[P]);
+      mma_tap(fa[PA_], fb[P], MERGE ? (j & 1) : 0);
       // 24 MFMAs with the 12 fragment reads of the next tap (and this tap's share of the staging) between them
 #pragma unroll
       for (int k = 0; k < 12; ++k) {
@@ -495,14 +514,15 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
   __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): drain the trailing DMAs before the block may end
 
   if constexpr ((ABL & 4) != 0) {
-    if (acc[0][0][0] == 12345.678f) a.y[0] = acc[0][0][0] + acc[1][1][15] + acc[0][1][3] + acc[1][0][7];      // keeps the accumulators alive
+    if (acc[0][0][0][0] == 12345.678f) a.y[0] = acc[0][0][0][0] + acc[0][1][1][15] + acc[0][0][1][3] + acc[0][1][0][7];      // keeps the accumulators alive
     return;
   }
   // the lean epilogue of the hand-scheduled fp32 kernel (conv_epilogue.h): activation / fused variants decided once per wave, buffer stores with a
   // scalar row offset, rows past M dropped by the descriptor's range check -- the generic per-element epilogue cost 10 % of this kernel's time at
   // one block per CU (2.92 against 3.25 ms on G 512 -> 1024 at batch 64 without it)
   const int mode = a.gy ? (a.gmask ? 3 : 2) : (a.mask ? 1 : 0);
-  pipe_epilogue_dispatch<2>(a, acc, b, m0 + wm * 64, n0, i32, h, a.t.out_off, mode);
+  pipe_epilogue_dispatch<2>(a, acc[0], b, m0 + wm * 64, n0, i32, h, a.t.out_off, mode);
+  if constexpr (MERGE != 0) pipe_epilogue_dispatch<2>(a, acc[1], b, m0 + wm * 64, n0, i32, h, a.t.out_off_odd, mode);
 #endif
 }
 
@@ -757,12 +777,12 @@ static int launch_bf16x3(const ConvArgs& a, int w_taps, void* ws, hipStream_t s)
   return check_launch("conv_bf16x3");
 }
 
-template <int NTAPS, int ABL = 0, int IS = 1>
+template <int NTAPS, int ABL = 0, int IS = 1, int MERGE = 0>
 static int launch_bf16x3_wide(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
   constexpr size_t lds = 2 * ((size_t)6 * (IS == 1 ? 320 : 516) * 16 + (size_t)6 * NTAPS * 1024);
   static_assert(lds <= 160 * 1024, "two stages must fit the CU's LDS");
   static unsigned long long lds_done = 0;
-  allow_big_lds((const void*)conv_bf16x3_wide_kernel<NTAPS, ABL, IS>, &lds_done);
+  allow_big_lds((const void*)conv_bf16x3_wide_kernel<NTAPS, ABL, IS, MERGE>, &lds_done);
   const int m_tiles = (a.M + 255) / 256, n_tiles = a.Cout / 64;
   const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
   if (blocks == 0 || blocks > 0x7fffffffull) {
@@ -773,7 +793,7 @@ static int launch_bf16x3_wide(const ConvArgs& a, int w_taps, void* ws, hipStream
   const unsigned short* xs = (const unsigned short*)ws;
   const unsigned short* wsp = xs + 3 * xn;
   prof_begin(s);
-  hipLaunchKernelGGL((conv_bf16x3_wide_kernel<NTAPS, ABL, IS>), dim3((unsigned)blocks), dim3(256), lds, s, a, xs, wsp, xn, wn, m_tiles, n_tiles);
+  hipLaunchKernelGGL((conv_bf16x3_wide_kernel<NTAPS, ABL, IS, MERGE>), dim3((unsigned)blocks), dim3(256), lds, s, a, xs, wsp, xn, wn, m_tiles, n_tiles);
   prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 2);
   return check_launch("conv_bf16x3_wide");
 }
@@ -797,6 +817,21 @@ static int launch_bf16x3_wide3(const ConvArgs& a, int w_taps, void* ws, hipStrea
   hipLaunchKernelGGL((conv_bf16x3_wide3_kernel<NTAPS>), dim3((unsigned)blocks), dim3(256), lds, s, a, xs, wsp, xn, wn, m_tiles, n_tiles);
   prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 2);
   return check_launch("conv_bf16x3_wide3");
+}
+
+// Both output phases of a stride-2 data gradient in one launch (a.t as conv_pipe_try_merged takes it: five taps in kernel-tap order, even index -> rows
+// out_stride * m + out_off, odd index -> out_off_odd).  Returns 0 when the launch does not have the merged form's shape (the caller runs the phases).
+int conv_bf16x3_merged_kind(const ConvArgs& a) {
+  if (a.t.ntaps != 5 || a.t.in_stride != 1 || a.t.out_stride != 2 || a.stat_part || a.mask || a.bias || a.M < 192 || a.Cin % 16 || a.Cout % 64) return 0;
+  for (int j = 0; j < 5; ++j)
+    if (a.t.widx[j] != j) return 0;
+  const int* o = a.t.off;
+  if (o[1] == o[2] && o[3] == o[4] && o[0] == o[1] + 1 && o[3] == o[2] - 1) return 1;       // pad_left odd
+  if (o[0] == o[1] && o[2] == o[3] && o[2] == o[1] - 1 && o[4] == o[3] - 1) return 2;       // pad_left even
+  return 0;
+}
+int conv_bf16x3_run_merged(const ConvArgs& a, void* ws, hipStream_t s) {
+  return conv_bf16x3_merged_kind(a) == 1 ? launch_bf16x3_wide<5, 0, 1, 1>(a, 5, ws, s) : launch_bf16x3_wide<5, 0, 1, 2>(a, 5, ws, s);
 }
 
 int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {

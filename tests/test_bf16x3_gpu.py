@@ -2,6 +2,8 @@
 pieces, six MFMA products, fp32 accumulation).  It is not on the default path; what is checked here is the claim that makes it
 worth keeping: its results are fp32-grade -- within the tolerance of the exact-fp32 MFMA path's own parity test, and not
 further from the fp64 oracle than that path is."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -9,6 +11,7 @@ import torch
 from oracle import keras_ref as K
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CASES = [
     # B, L, Cin, Cout, k, padding
@@ -78,10 +81,13 @@ def test_bf16x3_rejects_unsupported_shapes():
         ops.conv1d_fwd_bf16x3(x, w, b, 2, 1, 32)                                  # stride 2 is not implemented
 
 
-@pytest.mark.parametrize('B,L,Cin,Cout,padding', [(2, 800, 256, 256, 'same'), (1, 1030, 256, 512, 'valid')])
-def test_stride2_data_gradient_under_the_opt_in_split(B, L, Cin, Cout, padding):
-    """The data gradient of a stride-2 convolution is two output phases of 3 and 2 taps: under the opt-in math they run on the three-stage
-    64 x 64-wave-tile kernel (chunk c + 2 staged during chunk c).  Checked against the fp64 definition at the exact path's tolerance."""
+_S2_DGRAD_CASES = [(2, 800, 256, 256, 'same'),        # pad_left 1: taps (1, 2) and (3, 4) of the merged launch read the same rows
+                   (1, 1030, 256, 512, 'valid'),     # pad_left 0: taps (0, 1) and (2, 3); 515 rows per phase
+                   (2, 801, 256, 256, 'same')]       # odd length (pad_left 2): the odd phase is one row shorter than the even one
+
+
+def _s2_dgrad(B, L, Cin, Cout, padding):
+    """(result under the opt-in math, split launches it took, exact-kernel result, fp64 definition)"""
     from gennet_amd import ops
     rng = np.random.RandomState(L + Cin)
     w = (rng.randn(5, Cin, Cout) / np.sqrt(5 * Cin)).astype(np.float32)
@@ -99,10 +105,39 @@ def test_stride2_data_gradient_under_the_opt_in_split(B, L, Cin, Cout, padding):
     finally:
         ops.set_conv_math('fp32')
         ops.prof_enable(False)
-    assert used == 2, used                       # both phases took the split kernel
+    return got, used, exact, ref
+
+
+@pytest.mark.parametrize('B,L,Cin,Cout,padding', _S2_DGRAD_CASES)
+def test_stride2_data_gradient_under_the_opt_in_split(B, L, Cin, Cout, padding):
+    """The data gradient of a stride-2 convolution under the opt-in math: ONE launch of the 64 x 64-wave-tile kernel with two accumulator sets (five taps in
+    kernel order, even taps -> one output phase, odd taps -> the other; tap pairs that read the same rows share their x fragments).  Checked against the
+    fp64 definition at the exact path's tolerance."""
+    got, used, exact, ref = _s2_dgrad(B, L, Cin, Cout, padding)
+    assert used == (2 if os.environ.get('GN_BF16X3_NO_MERGE') else 1), used
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() <= 2e-6 * scale, np.abs(got - ref).max() / scale
     assert np.abs(got - ref).max() <= 2.0 * np.abs(exact - ref).max() + 1e-7 * scale
+
+
+def test_stride2_data_gradient_as_two_phase_launches(tmp_path):
+    """GN_BF16X3_NO_MERGE=1 (A/B switch, read once per process: a child process runs this leg): the two output phases as launches of 3 and 2 taps on the
+    three-stage kernel, the second phase reusing the first one's split planes.  Same bounds."""
+    import subprocess
+    import sys
+    out = str(tmp_path / 'phases.npz')
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch; import test_bf16x3_gpu as T; "
+            "r = [T._s2_dgrad(*c) for c in T._S2_DGRAD_CASES]; assert all(x[1] == 2 for x in r), [x[1] for x in r]; "
+            "np.savez(%r, *[x[0] for x in r])") % (ROOT, os.path.join(ROOT, 'tests'), out)
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, GN_BF16X3_NO_MERGE='1'), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    phases = np.load(out)
+    for k, case in enumerate(_S2_DGRAD_CASES):
+        got, used, exact, ref = _s2_dgrad(*case)
+        scale = np.abs(ref).max()
+        two = phases['arr_%d' % k]
+        assert np.abs(two - ref).max() <= 2e-6 * scale, (case, np.abs(two - ref).max() / scale)
+        assert np.abs(two - got).max() <= 2e-6 * scale                      # the merged launch and the two phases agree to rounding
 
 
 @pytest.mark.parametrize('B,L,Cin,Cout,padding,stride', [
