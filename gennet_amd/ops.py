@@ -278,9 +278,11 @@ _CONV_MATH_WS = [None]
 
 
 def set_conv_math(mode='fp32', workspace_gb=7.0, device=None):
-    """'fp32' (default): exact-fp32 MFMA everywhere.  'bf16x3': EXPERIMENTAL opt-in -- the large unit-stride Conv1D forward / data
-    gradient launches run on the bf16 matrix cores with 3-way split operands (csrc/conv_bf16x3.hip; fp32-grade results, see
-    tests/test_bf16x3_gpu.py).  workspace_gb must hold 6 * (B * (L + 2) * Cin + k * Cin * Cout) bytes of the largest such launch."""
+    """'fp32' (default): exact-fp32 MFMA everywhere.  'bf16x3': opt-in -- the Conv1D forward, data-gradient and weight-gradient launches with at least
+    256 channels on either side run on the bf16 matrix cores with 3-way split operands (csrc/conv_bf16x3.hip, csrc/wgrad_bf16x3.hip; fp32-grade results,
+    see tests/test_bf16x3_gpu.py).  workspace_gb must hold the split operands of the largest such launch -- 6 * (B * (L + 2) * Cin + k * Cin * Cout) bytes
+    for a forward / data gradient, 6 * B * ceil(Lout / 32) * (40 * stride * Cin + 32 * Cout) for a weight gradient; a launch that does not fit runs on
+    the exact kernel."""
     if mode == 'fp32':
         _lib.call('gn_set_conv_math', 0, None, 0)
         _CONV_MATH_WS[0] = None

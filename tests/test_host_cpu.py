@@ -439,6 +439,18 @@ def test_committed_bench_line_keeps_the_driver_contract():
     assert 1426.0 < d['value'] < 1427.0 and c['value'] < d['value'] / 100.0      # the north-star's >= 100x over the CPU path
 
 
+def test_bench_line_with_the_opt_in_leg_keeps_the_headline_exact():
+    """The opt-in conv math is reported beside the headline, never as it: the committed default line computes `value` in f32 and carries the
+    bf16-split figure in its own object."""
+    import json
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r04_bench_default_with_opt_in.json')))
+    assert d['dtype'] == 'f32' and 'conv_math' not in d['config'] and d['vs_baseline'] is None
+    o = d['opt_in']
+    assert o['conv_math'] == 'bf16x3' and o['unit'] == d['unit'] and o['steps'] == d['steps']
+    assert abs(o['ratio_to_value'] - o['value'] / d['value']) < 1e-12 and 1.1 < o['ratio_to_value'] < 1.5
+    assert all(np.isfinite(v) for v in o['last_losses']['cnn'] + o['last_losses']['gan'])
+
+
 def test_every_profile_the_readme_lists_is_committed():
     import re
     txt = open(os.path.join(ROOT, 'profiles', 'README.md')).read()
