@@ -274,8 +274,8 @@ def main():
     opt_in = None
     if world == 1 and not graphed and not args.no_opt_in and os.environ.get('GENNET_CONV_MATH', 'fp32') == 'fp32':
         ws_gb = float(os.environ.get('GENNET_CONV_WS_GB', '12'))
-        ops.set_conv_math('bf16x3', ws_gb, dev)
         try:
+            ops.set_conv_math('bf16x3', ws_gb, dev)
             for _ in range(max(1, min(args.warmup, 2))):
                 step()
             ops.prof_enable(True); ops.prof_reset()
@@ -298,6 +298,8 @@ def main():
                               'way right after the timed region, under ops.set_conv_math("bf16x3"); results are fp32-grade -- error against fp64 not larger than the '
                               'exact kernels\' (tests/test_bf16x3_gpu.py, and the n_pix-1024 trajectories of tests/test_trajectory_gpu.py at the exact path\'s bounds); '
                               'split passes included; DESIGN.md section 6c'}
+        except Exception as e:        # the extra leg must never cost the headline line
+            opt_in = {'conv_math': 'bf16x3', 'value': None, 'error': '%s: %s' % (type(e).__name__, e)}
         finally:
             ops.set_conv_math('fp32')
             ops.prof_enable(False)
@@ -421,7 +423,7 @@ def main():
             out['roofline']['note'] = ('loop bodies replayed as hipGraphs: the launch-stream HIP events of the eager path are not captured, so per-kernel '
                                        'figures are not measured here; the same command with --no-graph measures them (eager, same losses bit for bit)')
         if opt_in is not None:
-            if opt_in['value'] is not None:
+            if opt_in.get('value') is not None:
                 opt_in['ratio_to_value'] = opt_in['value'] / out['value']
             out['opt_in'] = opt_in
         if world == 1 and not args.no_cpu_baseline:
