@@ -387,38 +387,86 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[st][mt][nt][r] = 0.f;
 
-  const unsigned short* src[Q_WAVE];
-  int dst[Q_WAVE];
-  bool live[Q_WAVE];
-  size_t step[Q_WAVE];
+  // Staging plan.  Wave wm stages the slab segments wm, wm + 4, ... (64 rows of all six (plane, k-half) regions each); the LAST segment of the regions
+  // (ASEG = 4 NREG + 1) is shared out by region: wave wm takes regions wm and wm + 4; a share of the 6 * NTAPS weight pieces evens the count out to
+  // Q_WAVE instructions per wave (slab rows are gathers, weight pieces contiguous: the slab work has to be even, the barrier waits for the slowest wave).
+  // What differs between the lanes of one instruction is then only the row offset of the wave's NREG + 1 segments or the column (one register each);
+  // everything else is wave-uniform and lives in scalar registers -- the per-instruction pointer / stride / destination arrays this replaces took ~6
+  // registers per instruction.
+  static_assert((ASEG - 1) % 4 == 0, "segments per region: 4 NREG + 1");
+  constexpr int NREG = (ASEG - 1) / 4;
+  constexpr int NB_PURE = Q_WAVE - 6 * NREG - 2;           // instructions that are weight pieces on every wave
+  constexpr int QB = 6 * NTAPS;
+  constexpr bool MASKED = (RTOT % 64) != 0;                // the last segment of a region is partial: lanes past it must not write into the next region
+  static_assert(NB_PURE >= 0, "a wave's slab share must fit its instruction count");
+  const bool x1_inv = wm + 4 >= 6;                         // waves 2, 3 have no second region of the last segment: that instruction carries a weight piece
+  int b_first = 0;                                         // first weight piece of this wave
 #pragma unroll
-  for (int i = 0; i < Q_WAVE; ++i) {
-    int q = wm + 4 * i;
-    if (q >= Q_TOTAL) q = Q_TOTAL - 1;                      // padding instruction: repeats the last one (same bytes, same place)
-    if (q < 6 * ASEG) {
-      const int ph = q / ASEG, seg = q % ASEG;
-      const int lr = seg * 64 + lane;                                                        // LDS row inside the region
-      const int r = (IS == 1) ? lr : (lr < RPER ? 2 * lr : 2 * (lr - RPER) + 1);             // input row it holds (stride 2: even rows, then odd rows)
-      const int t = t_base + r;
-      const int row = (r < R && t >= 0 && t < a.Lin) ? t + 1 : 0;                           // 0 = the leading zero guard row
-      src[i] = xs + (ph >> 1) * x_plane + ((((size_t)b * n_chunks) * 2 + (ph & 1)) * Lg + row) * 8;
-      dst[i] = ph * REGION + seg * 1024;
-      live[i] = lr < RTOT;                                                                   // the partial last segment must not write into the next region
-      step[i] = (size_t)2 * Lg * 8;
-    } else {
-      const int qb = q - 6 * ASEG;
-      const int pt = qb >> 1, hh = qb & 1;
-      const int p = pt / NTAPS, tap = pt % NTAPS;
-      src[i] = ws + p * w_plane + ((((size_t)a.t.widx[tap] * n_chunks) * 2 + hh) * a.Cout + n0 + lane) * 8;
-      dst[i] = A_BYTES + qb * 1024;
-      live[i] = true;
-      step[i] = (size_t)2 * a.Cout * 8;
-    }
-  }
+  for (int w2 = 0; w2 < 3; ++w2)
+    if (w2 < wm) b_first += NB_PURE + (w2 + 4 >= 6 ? 1 : 0);
+  auto row_offset = [&](int seg) {                         // byte offset of the lane's row inside a (plane, k-half) run; -1: the lane is past the region
+    const int lr = seg * 64 + lane;                                                          // LDS row inside the region
+    const int r = (IS == 1) ? lr : (lr < RPER ? 2 * lr : 2 * (lr - RPER) + 1);               // input row it holds (stride 2: even rows, then odd rows)
+    const int t = t_base + r;
+    const int row = (r < R && t >= 0 && t < a.Lin) ? t + 1 : 0;                             // 0 = the leading zero guard row
+    return (MASKED && lr >= RTOT) ? -1 : row * 16;
+  };
+  int rowoff[NREG + 1];
+#pragma unroll
+  for (int sl = 0; sl < NREG; ++sl) rowoff[sl] = row_offset(wm + 4 * sl);
+  rowoff[NREG] = row_offset(ASEG - 1);
+  const int coloff = lane * 16;
+  auto a_run = [&](int ph) { return ((size_t)(ph >> 1) * x_plane + (((size_t)b * n_chunks) * 2 + (ph & 1)) * Lg * 8) * 2; };      // (plane, k-half) run of chunk 0, bytes
+  size_t a_base[6];
+#pragma unroll
+  for (int ph = 0; ph < 6; ++ph) a_base[ph] = a_run(ph);
+  const size_t a_step = (size_t)2 * Lg * 8 * 2, b_step = (size_t)2 * a.Cout * 8 * 2;      // bytes per chunk
+  auto piece = [&](int ord, size_t& off, int& dst_) {      // weight piece number b_first + ord (clamped: the padding instructions repeat the last piece)
+    const int qb = min(b_first + ord, QB - 1);
+    const int pt = qb >> 1, hh = qb & 1;
+    const int pp = pt / NTAPS, tap = pt % NTAPS;
+    int wi = a.t.widx[0];
+#pragma unroll
+    for (int t2 = 1; t2 < NTAPS; ++t2) wi = (tap == t2) ? a.t.widx[t2] : wi;                // (no indexed load of the argument block)
+    off = ((size_t)pp * w_plane + (((size_t)wi * n_chunks) * 2 + hh) * a.Cout * 8 + (size_t)n0 * 8) * 2;
+    dst_ = A_BYTES + qb * 1024;
+  };
+  // the two instructions of the last segment: regions wm and wm + 4 (the second one a weight piece on waves 2, 3)
+  const size_t x0_off = a_run(wm);
+  const int x0_dst = wm * REGION + (ASEG - 1) * 1024;
+  size_t x1_off;
+  int x1_dst;
+  piece(0, x1_off, x1_dst);
+  if (!x1_inv) { x1_off = a_run(wm + 4); x1_dst = (wm + 4) * REGION + (ASEG - 1) * 1024; }
+  size_t pure_off[NB_PURE > 0 ? NB_PURE : 1];
+  int pure_dst[NB_PURE > 0 ? NB_PURE : 1];
+#pragma unroll
+  for (int k = 0; k < NB_PURE; ++k) piece((x1_inv ? 1 : 0) + k, pure_off[k], pure_dst[k]);
   bool in_loop = false;
   auto dma_one = [&](int i, int c, unsigned char* stage) {
     if ((ABL & 2) && in_loop) return;
-    if (IS == 1 || live[i]) __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)c * step[i]), (lptr_t)(stage + dst[i]), 16, 0, 0);
+    const char* base;
+    int voff, d;
+    if (i < 6 * NREG) {
+      const int sl = i / 6, ph = i % 6;
+      base = (const char*)xs + a_base[ph] + (size_t)c * a_step;
+      voff = rowoff[sl];
+      d = ph * REGION + (wm + 4 * sl) * 1024;
+    } else if (i == 6 * NREG) {
+      base = (const char*)xs + x0_off + (size_t)c * a_step;
+      voff = rowoff[NREG];
+      d = x0_dst;
+    } else if (i == 6 * NREG + 1) {
+      base = (x1_inv ? (const char*)ws : (const char*)xs) + x1_off + (size_t)c * (x1_inv ? b_step : a_step);
+      voff = x1_inv ? coloff : rowoff[NREG];
+      d = x1_dst;
+    } else {
+      base = (const char*)ws + pure_off[i - 6 * NREG - 2] + (size_t)c * b_step;
+      voff = coloff;
+      d = pure_dst[i - 6 * NREG - 2];
+    }
+    // only the two instructions of the (partial) last segment can have lanes past the region
+    if (!MASKED || (i != 6 * NREG && i != 6 * NREG + 1) || voff >= 0) __builtin_amdgcn_global_load_lds((gptr_t)(base + voff), (lptr_t)(stage + d), 16, 0, 0);
   };
   auto read_tap = [&](const unsigned char* sa, int j, bf16x8 (&av)[3][2], bf16x8 (&bv)[3][2], bool with_a = true) {
     if ((ABL & 1) && in_loop) return;
