@@ -273,7 +273,7 @@ def main():
     # region, with the wide convolutions (forward, data gradient, weight gradient) as six bf16 products per fp32 product.  N = 1, eager loops only.
     opt_in = None
     if world == 1 and not graphed and not args.no_opt_in and os.environ.get('GENNET_CONV_MATH', 'fp32') == 'fp32':
-        ws_gb = float(os.environ.get('GENNET_CONV_WS_GB', '12'))
+        ws_gb = float(os.environ.get('GENNET_CONV_WS_GB', str(12 * max(1, N_PIX // 2048))))      # the split operands of the largest launch: 12 GB at n_pix 2048
         try:
             ops.set_conv_math('bf16x3', ws_gb, dev)
             for _ in range(max(1, min(args.warmup, 2))):
