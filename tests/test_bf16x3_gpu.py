@@ -275,3 +275,41 @@ def test_discriminator_step_under_the_opt_in_split_meets_the_fp32_path_tolerance
         ops.set_conv_math('fp32')
         ops.prof_enable(False)
     assert used >= 1, used              # the stride-2 forward really ran on the split kernel
+
+
+def test_random_shapes_under_the_opt_in_split_agree_with_the_exact_kernels():
+    """Forty seeded random launches -- forward, data gradient, weight gradient; both strides, both paddings, row counts from 5 to 900, ragged everything --
+    under the opt-in math against the exact-fp32 kernels on the same inputs: every result within 4e-6 of the tensor's largest entry (both are fp32-grade
+    evaluations of the same sums), whichever of the split kernels (wide, merged, three-stage, narrow, weight gradient) or the exact fallback the shape selects."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(2024)
+    dev = torch.device('cuda:0')
+    taken = 0
+    for case in range(40):
+        B = int(rng.randint(1, 5)); L = int(rng.choice([5, 17, 33, 64, 100, 191, 192, 257, 400, 513, 900]))
+        Cin = int(rng.choice([256, 384, 512])); Cout = int(rng.choice([256, 320, 512]))
+        stride = int(rng.choice([1, 2])); padding = str(rng.choice(['same', 'valid']))
+        if padding == 'valid' and L < 5:
+            continue
+        Lout, pl = ops.conv_geometry(L, 5, stride, padding)
+        x = torch.tensor((rng.randn(B, L, Cin) * np.exp(rng.randn(B, L, 1))).astype(np.float32)).to(dev)
+        w = torch.tensor((rng.randn(5, Cin, Cout) / np.sqrt(5 * Cin)).astype(np.float32)).to(dev)
+        b = torch.tensor(rng.randn(Cout).astype(np.float32)).to(dev)
+        dy = torch.tensor((rng.randn(B, Lout, Cout) * np.exp(rng.randn(B, Lout, 1))).astype(np.float32)).to(dev)
+        wt = ops.conv1d_transpose_w(w)
+
+        def run():
+            return (ops.conv1d_fwd(x, w, b, stride, pl, Lout, 'relu'), ops.conv1d_dgrad(dy, wt, L, stride, pl), ops.conv1d_wgrad(x, dy, 5, stride, pl)[0])
+        exact = [t.cpu().numpy().astype(np.float64) for t in run()]
+        ops.prof_enable(True); ops.prof_reset()
+        ops.set_conv_math('bf16x3', workspace_gb=0.25)
+        try:
+            got = [t.cpu().numpy().astype(np.float64) for t in run()]
+            taken += ops.prof_collect(2)['launches']
+        finally:
+            ops.set_conv_math('fp32')
+            ops.prof_enable(False)
+        for name, g_, e_ in zip(('fwd', 'dgrad', 'wgrad'), got, exact):
+            scale = max(np.abs(e_).max(), 1e-30)
+            assert np.abs(g_ - e_).max() <= 4e-6 * scale, (case, name, B, L, Cin, Cout, stride, padding, np.abs(g_ - e_).max() / scale)
+    assert taken >= 60, taken                    # most of the 120 launches did go through the split kernels
