@@ -132,16 +132,21 @@ __device__ __forceinline__ bf16x8 shifted_rows(const u32x4& lo, const uint2& hi)
 
 // IB = 32-channel blocks of x per wave: 2 -> 4 waves of 64 ci x 32 co (one per SIMD), 1 -> 8 waves of 32 x 32 (two per SIMD: one wave's barrier,
 // operand and VMEM-issue waits are covered by the other's MFMAs)
-template <int IS, int PODD, int ABL = 0, int IB = 2>
+// WNN = waves across the output channels: 2 -> 128 ci x 64 co blocks; 4 (stride 2, IB = 1) -> 64 ci x 128 co: at stride 2 the x tile is staged twice (even and
+// odd input rows), so the narrower x tile stages 54 instead of 73 KiB per chunk for the same MFMAs
+template <int IS, int PODD, int ABL = 0, int IB = 2, int WNN = 2>
 __global__ __launch_bounds__(512 / IB, 1) void wgrad_bf16x3_kernel(WgradArgs a, const unsigned short* __restrict__ xt, const unsigned short* __restrict__ dyt,
                                                               size_t x_plane, size_t dy_plane) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int NTAPS = 5, TC = 128, TN = 64, KC = 32;
+  constexpr int NTAPS = 5, KC = 32;
+  constexpr int TN = 32 * WNN, TC = 32 * IB * ((8 / IB) / WNN);
+  static_assert(TC * TN == 128 * 64, "eight (four) waves of 32 (64) x 32");
   constexpr int CH_BYTES = 80;                              // 40 rows of one channel
   constexpr int A_PLANE = IS * TC * CH_BYTES, B_PLANE = TN * 64;        // dy: 32 rows per channel, granules swizzled (see split_t_kernel)
   constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 3 * B_PLANE, STAGE = A_BYTES + B_BYTES;
   static_assert(2 * STAGE <= 160 * 1024, "two stages must fit the CU's LDS");
   constexpr int QA_PLANE = IS * TC * 5 / 64, QB_PLANE = TN * 4 / 64;        // wave-level DMA instructions per plane: 10 (20 at stride 2) and 4
+  static_assert((IS * TC * 5) % 64 == 0 && (TN * 4) % 64 == 0, "whole 1-KiB pieces");
   constexpr int QA = 3 * QA_PLANE, Q_TOTAL = QA + 3 * QB_PLANE;
   constexpr int NW = 8 / IB;                                // waves per block
   constexpr int Q_WAVE = (Q_TOTAL + NW - 1) / NW;
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(512 / IB, 1) void wgrad_bf16x3_kernel(WgradArgs a, 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave >> 1, wn = wave & 1;                 // wc: 0 .. 1 (IB = 2) or 0 .. 3 (IB = 1)
+  const int wc = wave / WNN, wn = wave % WNN;
   const int i32 = lane & 31, h = lane >> 5;
   // block -> (Cin tile, Cout tile, K-split).  xcd_order: block i runs on XCD i mod 8; every XCD takes whole K-splits (the splits k, k + 8, ...) with all
   // their tiles one after the other, so each x / dy chunk crosses the fabric once and its reuse by the tiles is served by that XCD's L2
@@ -398,6 +403,8 @@ int wgrad_bf16x3_run(const WgradArgs& a_in, int splits, void* ws, size_t ws_byte
   dim3 grid(a.Cin / 128, a.Cout / 64, splits);
   const unsigned short* xc = xt;
   const unsigned short* dc = dyt;
+  static const bool no_wide_n = getenv("GN_WGBF_NO_WIDE_N") != nullptr;                 // A/B switch: stride 2 on 128 ci x 64 co blocks as at unit stride
+  const bool wide_n = !no_wide_n && a.Cout % 128 == 0;
   static const bool four_waves = getenv("GN_WGBF_4WAVES") != nullptr;                  // A/B switch: 4 waves of 64 x 32 instead of 8 of 32 x 32 (stride 1)
   static const int abl = getenv("GN_WGBF_ABL") ? atoi(getenv("GN_WGBF_ABL")) : 0;       // timing ablations, stride 1 (results are wrong with any of them)
   prof_begin(s);
@@ -432,6 +439,18 @@ int wgrad_bf16x3_run(const WgradArgs& a_in, int splits, void* ws, size_t ws_byte
       } else {
         allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 0>, &e0);
         hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 0>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane);
+      }
+    } else if (wide_n) {
+      // 64 ci x 128 co blocks
+      constexpr size_t lds2 = 2 * (size_t)(3 * 2 * 64 * 80 + 3 * 128 * 64);
+      dim3 grid2(a.Cin / 64, a.Cout / 128, splits);
+      static unsigned long long g0 = 0, g1 = 0;
+      if (pl & 1) {
+        allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 1, 0, 1, 4>, &g1);
+        hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 1, 0, 1, 4>), grid2, dim3(512), lds2, s, a, xc, dc, x_plane, dy_plane);
+      } else {
+        allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 0, 0, 1, 4>, &g0);
+        hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 0, 0, 1, 4>), grid2, dim3(512), lds2, s, a, xc, dc, x_plane, dy_plane);
       }
     } else if (pl & 1) {
       allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 1, 0, 1>, &f1);
