@@ -313,3 +313,34 @@ def test_random_shapes_under_the_opt_in_split_agree_with_the_exact_kernels():
             scale = max(np.abs(e_).max(), 1e-30)
             assert np.abs(g_ - e_).max() <= 4e-6 * scale, (case, name, B, L, Cin, Cout, stride, padding, np.abs(g_ - e_).max() / scale)
     assert taken >= 60, taken                    # most of the 120 launches did go through the split kernels
+
+
+@pytest.mark.parametrize('stride', [1, 2])
+def test_split_kernels_are_deterministic_at_bench_like_sizes(stride):
+    """A race in the staging choreography (counted vmcnt, one barrier per chunk, stages reused every other chunk) would show as run-to-run differences on
+    launches that keep every CU busy for several rounds: forward, data gradient and weight gradient of a 512 -> 1024 layer on 48 x 2048 rows, five times
+    each, bit for bit."""
+    from gennet_amd import ops
+    dev = torch.device('cuda:0')
+    B, L, Cin, Cout = 48, 2048, 512, 1024
+    Lout, pl = ops.conv_geometry(L, 5, stride, 'same')
+    x = ops.fill_normal((B, L, Cin), 0.0, 1.0, 11, 0, dev)
+    dy = ops.fill_normal((B, Lout, Cout), 0.0, 1.0, 12, 0, dev)
+    w = ops.fill_normal((5, Cin, Cout), 0.0, 0.02, 13, 0, dev)
+    b = ops.fill_normal((Cout,), 0.0, 1.0, 14, 0, dev)
+    wt = ops.conv1d_transpose_w(w)
+    ops.prof_enable(True); ops.prof_reset()
+    ops.set_conv_math('bf16x3', workspace_gb=2.0)
+    try:
+        first = None
+        for rep in range(5):
+            out = (ops.conv1d_fwd(x, w, b, stride, pl, Lout, 'relu'), ops.conv1d_dgrad(dy, wt, L, stride, pl), ops.conv1d_wgrad(x, dy, 5, stride, pl)[0])
+            if first is None:
+                first = [t.clone() for t in out]
+            else:
+                for name, t, f in zip(('fwd', 'dgrad', 'wgrad'), out, first):
+                    assert torch.equal(t, f), (rep, name, float((t - f).abs().max()))
+        assert ops.prof_collect(2)['launches'] == 15
+    finally:
+        ops.set_conv_math('fp32')
+        ops.prof_enable(False)
