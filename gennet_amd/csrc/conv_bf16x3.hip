@@ -574,176 +574,6 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
 #endif
 }
 
-// EXPERIMENT (GN_BF16X3_GA=1): the five-tap launch with the x operand taken OUT of the LDS.  An x fragment is a 16-byte granule of the split planes (8
-// channels of one row); the 32 lanes of a k-half read 32 consecutive rows = 512 contiguous bytes, and no wave shares its rows with another (only the five
-// taps overlap: the vector L1 serves that).  So the fragments go global -> registers, one whole chunk ahead (a ring of 5 taps x 6 fragments), and the LDS
-// stages and serves the weights only: half the staging and half the fragment reads of conv_bf16x3_wide_kernel, whose own ablation prices those at 8 % each.
-// The tap is a row offset in the lane's address, so the input stride is a multiplier, not a de-interleaved second slab.
-template <int IS>
-__global__ __launch_bounds__(256, 1) void conv_bf16x3_ga_kernel(ConvArgs a, const unsigned short* __restrict__ xs, const unsigned short* __restrict__ ws,
-                                                                size_t x_plane, size_t w_plane, int m_tiles, int n_tiles) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int NTAPS = 5, TM = 256, TN = 64;
-  constexpr int STAGE = 6 * NTAPS * 1024;                  // weights only: [plane][tap][k-half][64 columns] granules
-  constexpr int QB = 6 * NTAPS, Q_WAVE = (QB + 3) / 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i32 = lane & 31, h = lane >> 5;
-  int lin = blockIdx.x;
-  const int nb = gridDim.x;
-  if (lin < (nb & ~7)) lin = (lin & 7) * (nb >> 3) + (lin >> 3);
-  const int n_tile = lin % n_tiles;
-  const int rest = lin / n_tiles;
-  const int m_tile = rest % m_tiles;
-  const int b = rest / m_tiles;
-  const int m0 = m_tile * TM, n0 = n_tile * TN;
-  const int n_chunks = a.Cin >> 4;
-  const int Lg = a.Lin + 2;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  // x fragments: lane byte offset inside one (plane, chunk) pair of k-half runs, per tap and 32-row block; rows outside [0, Lin) -> the zero guard row 0
-  int aoff[NTAPS][2];
-#pragma unroll
-  for (int j = 0; j < NTAPS; ++j)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int t = IS * (m0 + wm * 64 + mt * 32 + i32) + a.t.off[j];
-      const int row = (t >= 0 && t < a.Lin) ? t + 1 : 0;
-      aoff[j][mt] = (h * Lg + row) * 16;
-    }
-  const char* xrun[3];                                      // chunk 0 of the block's batch element, per plane
-#pragma unroll
-  for (int p = 0; p < 3; ++p) xrun[p] = (const char*)xs + ((size_t)p * x_plane + ((size_t)b * n_chunks) * 2 * Lg * 8) * 2;
-  const size_t a_step = (size_t)2 * Lg * 8 * 2, b_step = (size_t)2 * a.Cout * 8 * 2;
-  auto load_a = [&](int c, int j, bf16x8 (&f)[3][2]) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) f[p][mt] = *reinterpret_cast<const bf16x8*>(xrun[p] + (size_t)c * a_step + aoff[j][mt]);
-  };
-  // weight pieces: wave wm stages pieces wm, wm + 4, ... of the 30 (1 KiB each: [plane][tap][k-half] x 64 columns)
-  size_t boff[Q_WAVE];
-  int bdst[Q_WAVE];
-#pragma unroll
-  for (int i = 0; i < Q_WAVE; ++i) {
-    const int qb = min(wm + 4 * i, QB - 1);
-    const int pt = qb >> 1, hh = qb & 1;
-    const int pp = pt / NTAPS, tap = pt % NTAPS;
-    int wi = a.t.widx[0];
-#pragma unroll
-    for (int t2 = 1; t2 < NTAPS; ++t2) wi = (tap == t2) ? a.t.widx[t2] : wi;
-    boff[i] = ((size_t)pp * w_plane + (((size_t)wi * n_chunks) * 2 + hh) * a.Cout * 8 + (size_t)n0 * 8) * 2;
-    bdst[i] = qb * 1024;
-  }
-  const int coloff = lane * 16;
-  // The weight pieces go global -> registers -> LDS with plain loads and ds_write, NOT by LDS-DMA: with LDS-DMA and register loads in flight together the
-  // compiler's wait insertion treats the counter as out of order and waits vmcnt(0) at the first use of every prefetched fragment (seen in the ISA of the
-  // first version of this kernel); plain loads keep its counted waits exact.
-  bf16x8 breg[Q_WAVE];
-  auto load_b = [&](int c) {
-#pragma unroll
-    for (int i = 0; i < Q_WAVE; ++i) breg[i] = *reinterpret_cast<const bf16x8*>((const char*)ws + boff[i] + (size_t)c * b_step + coloff);
-  };
-  auto store_b = [&](unsigned char* stage) {
-#pragma unroll
-    for (int i = 0; i < Q_WAVE; ++i) *reinterpret_cast<bf16x8*>(stage + bdst[i] + coloff) = breg[i];
-  };
-  auto read_b = [&](const unsigned char* st, int j, bf16x8 (&bv)[3][2]) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) bv[p][nt] = *reinterpret_cast<const bf16x8*>(st + (((p * NTAPS + j) * 2 + h) * 64 + nt * 32 + i32) * 16);
-  };
-  auto mma_tap = [&](const bf16x8 (&av)[3][2], const bf16x8 (&bv)[3][2]) {
-    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[q]][mt], bv[PB[q]][nt], acc[mt][nt], 0, 0, 0);
-  };
-
-  bf16x8 fa[NTAPS][3][2], fb[2][3][2];
-  load_b(0);
-  store_b(smem_b);
-  load_b(min(1, n_chunks - 1));                             // chunk 1's pieces wait in registers for chunk 0's first tap
-#pragma unroll
-  for (int j = 0; j < NTAPS; ++j) load_a(0, j, fa[j]);
-  __syncthreads();
-  read_b(smem_b, 0, fb[0]);
-  auto do_chunk = [&](int ch, auto p0) {
-    constexpr int P0 = decltype(p0)::value;
-    const unsigned char* sa = smem_b + (ch & 1) * STAGE;
-    unsigned char* sb = smem_b + ((ch + 1) & 1) * STAGE;
-    const int c_a = min(ch + 1, n_chunks - 1), c_b = min(ch + 2, n_chunks - 1);
-#pragma unroll
-    for (int j = 0; j < NTAPS; ++j) {
-      const int P = (P0 + j) & 1;
-      __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): this tap's weight fragments are in registers (and this wave's ds_writes are done)
-      __builtin_amdgcn_sched_barrier(0);
-      if (j == 0) {
-        store_b(sb);                                        // chunk ch + 1's pieces (loaded a chunk ago) into the stage the barrier of chunk ch - 1 freed
-        load_b(c_b);
-      }
-      if (j + 1 < NTAPS) {
-        read_b(sa, j + 1, fb[P ^ 1]);
-      } else {
-        asm volatile("s_barrier" ::: "memory");             // every wave's pieces of chunk ch + 1 are in the LDS, every wave has read the last of chunk ch
-        read_b(sb, 0, fb[P ^ 1]);
-      }
-      mma_tap(fa[j], fb[P]);
-      load_a(c_a, j, fa[j]);                                // this tap's fragments of the NEXT chunk, into the registers just consumed
-#pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (j == 0 && k < Q_WAVE) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (j == 0 ? k >= 4 : (k & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // x loads (and at tap 0 the weight pieces) spread under the MFMAs
-      }
-      __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  for (int ch = 0; ch < n_chunks; ch += 2) {
-    do_chunk(ch, std::integral_constant<int, 0>{});
-    if (ch + 1 < n_chunks) do_chunk(ch + 1, std::integral_constant<int, 1>{});
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  const int mode = a.gy ? (a.gmask ? 3 : 2) : (a.mask ? 1 : 0);
-  pipe_epilogue_dispatch<2>(a, acc, b, m0 + wm * 64, n0, i32, h, a.t.out_off, mode);
-#endif
-}
-
-template <int IS>
-static int launch_bf16x3_ga(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
-  constexpr size_t lds = 2 * (size_t)6 * 5 * 1024;
-  const int m_tiles = (a.M + 255) / 256, n_tiles = a.Cout / 64;
-  const size_t blocks = (size_t)m_tiles * n_tiles * a.B;
-  if (blocks == 0 || blocks > 0x7fffffffull) {
-    set_error("conv_bf16x3_ga: bad grid %zu", blocks);
-    return GN_EINVAL;
-  }
-  const size_t xn = (size_t)a.B * (a.Lin + 2) * a.Cin, wn = (size_t)w_taps * a.Cin * a.Cout;
-  const unsigned short* xs = (const unsigned short*)ws;
-  const unsigned short* wsp = xs + 3 * xn;
-  prof_begin(s);
-  hipLaunchKernelGGL((conv_bf16x3_ga_kernel<IS>), dim3((unsigned)blocks), dim3(256), lds, s, a, xs, wsp, xn, wn, m_tiles, n_tiles);
-  prof_end(s, 2.0 * a.B * (double)a.M * a.t.ntaps * a.Cin * a.Cout, 2);
-  return check_launch("conv_bf16x3_ga");
-}
-
 // The same 64 x 64 wave tiles for the 2- / 3-tap launches (the two output phases of a stride-2 data gradient).  A chunk is then 2 or 3 taps x 24
 // MFMAs = 0.64 / 0.96 us, shorter than an LDS-DMA takes to land, so chunk c+2 is staged during chunk c -- THREE stages of 42 / 48 KiB -- and retired
 // by a counted vmcnt(Q_WAVE) at the barrier of chunk c+1 (every wave issues the same number of DMA instructions per chunk: the count is valid).
@@ -1056,12 +886,6 @@ int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
   if (!conv_bf16x3_supported(a)) {
     set_error("conv_bf16x3: shape not supported (Cin %% 16, Cout %% 64, taps <= 5, unit input stride)");
     return GN_EINVAL;
-  }
-  static const bool ga = getenv("GN_BF16X3_GA") != nullptr;                // experiment: x fragments straight from the split planes
-  if (ga && a.t.ntaps == 5 && a.M >= 192 && a.t.out_stride == 1) {
-    int lo = a.t.off[0], hi = a.t.off[0];
-    for (int j = 1; j < 5; ++j) { lo = std::min(lo, a.t.off[j]); hi = std::max(hi, a.t.off[j]); }
-    if (hi - lo == 4) return a.t.in_stride == 2 ? launch_bf16x3_ga<2>(a, w_taps, ws, s) : launch_bf16x3_ga<1>(a, w_taps, ws, s);
   }
   if (a.t.in_stride == 2) return launch_bf16x3_wide<5, 0, 2>(a, w_taps, ws, s);
   // 64 x 64 wave tiles in 256-row blocks for the 4- / 5-tap launches whose rows fill them (round 4); GN_BF16X3_NARROW keeps round 1's kernel
