@@ -94,6 +94,14 @@ struct PhaseScope {
   ~PhaseScope() { g_phase_w_taps = 0; g_phase_have_split = false; }
 };
 
+// Size gate of the opt-in split: below ~50 GFLOP a launch does not keep the 256-row blocks of the split kernels busy for more than a round or two and
+// the split pass in front of it is pure latency (at the reference script's own batch 8 every launch is below it: the opt-in then changes nothing there
+// instead of costing 1 %).  GN_BF16X3_MIN_GFLOP: A/B switch.
+static bool split_worth_it(int B, int M, int ntaps, int Cin, int Cout) {
+  static const double min_gflop = getenv("GN_BF16X3_MIN_GFLOP") ? atof(getenv("GN_BF16X3_MIN_GFLOP")) : 50.0;
+  return 2.0 * B * (double)M * ntaps * Cin * Cout >= min_gflop * 1e9;
+}
+
 static int conv_dispatch(const ConvArgs& a, hipStream_t s) {
   if (a.Cin <= 4) return conv_smallcin_dispatch(a, s);
   if (a.Cout <= 4) return conv_smallcout_dispatch(a, s);
@@ -101,7 +109,9 @@ static int conv_dispatch(const ConvArgs& a, hipStream_t s) {
   // the conv gains ~0.02 ps per element and output channel, so small-Cout layers gain little and small-Cin layers (few K chunks) lose to the prologue
   static const int min_cin = getenv("GN_BF16X3_MIN_CIN") ? atoi(getenv("GN_BF16X3_MIN_CIN")) : 256;
   static const int min_cout = getenv("GN_BF16X3_MIN_COUT") ? atoi(getenv("GN_BF16X3_MIN_COUT")) : 256;
-  if (g_conv_math == 1 && a.Cin >= min_cin && a.Cout >= min_cout && conv_bf16x3_supported(a)) {
+  if (g_conv_math == 1 && a.Cin >= min_cin && a.Cout >= min_cout && conv_bf16x3_supported(a) &&
+      (g_phase_w_taps > 0 ? split_worth_it(a.B, (a.Ly + 1) / 2, g_phase_w_taps, a.Cin, a.Cout) :      // (every phase of one data gradient decides alike)
+                            split_worth_it(a.B, a.M, a.t.ntaps, a.Cin, a.Cout))) {
     int w_taps = 0;
     for (int j = 0; j < a.t.ntaps; ++j) w_taps = std::max(w_taps, a.t.widx[j] + 1);
     static const bool no_reuse = getenv("GN_BF16X3_NO_PHASE_REUSE") != nullptr;       // A/B switch
@@ -337,21 +347,21 @@ static int dgrad_impl(const float* dy, const float* wt, float* dx, int B, int L,
     a.t.out_off_odd = 1 - (pad_left & 1);
     a.act = GN_ACT_LINEAR;
     a.gy = gy; a.gmask = gmask; a.gact = gact; a.gparam = gparam; a.gscale = 1.0f / (1.0f - grate);
-    if (g_conv_math == 0) {
+    // opt-in split math: one launch for both phases where the 256-row blocks fill (the x fragments of tap pairs that read the same rows are read once)
+    static const int min_cin = getenv("GN_BF16X3_MIN_CIN") ? atoi(getenv("GN_BF16X3_MIN_CIN")) : 256;
+    static const int min_cout = getenv("GN_BF16X3_MIN_COUT") ? atoi(getenv("GN_BF16X3_MIN_COUT")) : 256;
+    static const bool no_merge = getenv("GN_BF16X3_NO_MERGE") != nullptr;            // A/B switch
+    const bool split_ok = g_conv_math == 1 && a.Cin >= min_cin && a.Cout >= min_cout && split_worth_it(a.B, a.M, 5, a.Cin, a.Cout);
+    if (split_ok && !no_merge && conv_bf16x3_merged_kind(a) && conv_bf16x3_workspace_bytes(a.B, a.Lin, a.Cin, a.Cout, 5) <= g_conv_ws_bytes) {
+      int rc = conv_bf16x3_split(a, 5, g_conv_ws, g_conv_ws_bytes, true, true, (hipStream_t)stream);
+      if (rc) return rc;
+      return conv_bf16x3_run_merged(a, g_conv_ws, (hipStream_t)stream);
+    }
+    if (!split_ok) {
+      // the exact kernel's merged form (it takes the small launches): a launch the split leaves alone must find it exactly as on the default path
       bool launched = false;
       int rc = conv_pipe_try_merged(a, (hipStream_t)stream, &launched);
       if (rc || launched) return rc;
-    } else {
-      // opt-in split math: one launch for both phases where the 256-row blocks fill (the x fragments of tap pairs that read the same rows are read once)
-      static const int min_cin = getenv("GN_BF16X3_MIN_CIN") ? atoi(getenv("GN_BF16X3_MIN_CIN")) : 256;
-      static const int min_cout = getenv("GN_BF16X3_MIN_COUT") ? atoi(getenv("GN_BF16X3_MIN_COUT")) : 256;
-      static const bool no_merge = getenv("GN_BF16X3_NO_MERGE") != nullptr;            // A/B switch
-      if (!no_merge && a.Cin >= min_cin && a.Cout >= min_cout && conv_bf16x3_merged_kind(a) &&
-          conv_bf16x3_workspace_bytes(a.B, a.Lin, a.Cin, a.Cout, 5) <= g_conv_ws_bytes) {
-        int rc = conv_bf16x3_split(a, 5, g_conv_ws, g_conv_ws_bytes, true, true, (hipStream_t)stream);
-        if (rc) return rc;
-        return conv_bf16x3_run_merged(a, g_conv_ws, (hipStream_t)stream);
-      }
     }
   }
   PhaseScope phases(stride > 1 ? k : 0);
@@ -408,7 +418,7 @@ int gn_conv1d_wgrad(const float* x, const float* dy, float* dw, float* db, void*
     static const int min_cin = getenv("GN_BF16X3_MIN_CIN") ? atoi(getenv("GN_BF16X3_MIN_CIN")) : 256;
     static const int min_cout = getenv("GN_BF16X3_MIN_COUT") ? atoi(getenv("GN_BF16X3_MIN_COUT")) : 256;
     static const bool no_wgrad = getenv("GN_BF16X3_NO_WGRAD") != nullptr;           // A/B switch
-    if (g_conv_math == 1 && !no_wgrad && Cin >= min_cin && Cout >= min_cout) {
+    if (g_conv_math == 1 && !no_wgrad && Cin >= min_cin && Cout >= min_cout && split_worth_it(B, Lout, k, Cin, Cout)) {
       a.split_ws = g_conv_ws;
       a.split_ws_bytes = g_conv_ws_bytes;
     }
