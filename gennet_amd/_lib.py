@@ -16,6 +16,7 @@ vp, i32, f32, f64, u64, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_uin
 _SIGS = {
     'gn_conv1d_fwd': [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     'gn_conv1d_fwd_bf16x3': [vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp],
+    'gn_conv1d_fwd_wino': [vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     'gn_conv1d_fwd_stats': [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'gn_conv1d_fwd_dropout': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp],
     'gn_conv1d_transpose_w': [vp, vp, i32, i32, i32, vp],
@@ -87,6 +88,7 @@ _SIGS = {
 }
 _SIZE_FNS = {
     'gn_conv1d_bf16x3_workspace': [i32, i32, i32, i32, i32],
+    'gn_conv1d_wino_workspace': [i32, i32],
     'gn_conv1d_wgrad_workspace': [i32, i32, i32, i32, i32, i32, i32],
     'gn_dense_bwd_workspace': [i32, i32, i32],
     'gn_bn_stats_workspace': [sz, i32],

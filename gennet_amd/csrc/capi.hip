@@ -288,6 +288,21 @@ int gn_conv1d_fwd_bf16x3(const float* x, const float* w, const float* bias, floa
   return conv_bf16x3_run(a, k, ws, (hipStream_t)stream);
 }
 
+size_t gn_conv1d_wino_workspace(int Cin, int Cout) { return conv_wino_workspace_bytes(Cin, Cout); }
+
+int gn_conv1d_fwd_wino(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B, int L, int Cin, int Cout, int k, int stride,
+                       int pad_left, int Lout, int act, float act_param, void* stream) {
+  GN_REQUIRE(x && w && y && ws, "conv1d_fwd_wino: null pointer");
+  GN_REQUIRE(B >= 0 && L > 0 && Cin > 0 && Cout > 0 && k == 5 && stride == 1 && Lout > 0 && pad_left >= 0, "conv1d_fwd_wino: 5 taps, unit stride");
+  if (B == 0) return GN_OK;
+  ConvArgs a = {};
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.B = B; a.Lin = L; a.Cin = Cin; a.Cout = Cout; a.M = Lout; a.Ly = Lout;
+  fwd_taps(&a.t, k, stride, pad_left);
+  a.act = act; a.act_param = act_param;
+  return conv_wino_run(a, ws, ws_bytes, (hipStream_t)stream);
+}
+
 int gn_conv1d_fwd_dropout(const float* x, const float* w, const float* bias, const uint8_t* mask, float* y, int B, int L, int Cin, int Cout, int k, int stride,
                           int pad_left, int Lout, int act, float act_param, float rate, void* stream) {
   GN_REQUIRE(x && w && y && mask, "conv1d_fwd_dropout: null pointer");

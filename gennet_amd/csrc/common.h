@@ -15,7 +15,7 @@ int check_launch(const char* what);
 // rng_base() = the device word every Philox kernel adds to its counter offset (NULL outside graph capture; gn_set_rng_base).
 const uint64_t* rng_base();
 void prof_begin(hipStream_t s);
-void prof_end(hipStream_t s, double flop, int kind, double bytes = 0.0);  // kind 0: conv_mfma (fwd, dgrad), 1: wgrad_mfma, 2: bf16x3 conv, 3: fused synthesiser, 4: fused noise chain
+void prof_end(hipStream_t s, double flop, int kind, double bytes = 0.0);  // kind 0: conv_mfma (fwd, dgrad), 1: wgrad_mfma, 2: bf16x3 conv, 3: fused synthesiser, 4: fused noise chain, 5: transform-domain conv (flop = algorithmic), 6: transform-domain wgrad
 
 
 // ---------------------------------------------------------------------------------------------
@@ -138,6 +138,10 @@ int conv_bf16x3_split(const ConvArgs& a, int w_taps, void* ws, size_t ws_bytes, 
 int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s);
 int conv_bf16x3_merged_kind(const ConvArgs& a);            // 0: not the merged two-phase shape
 int conv_bf16x3_run_merged(const ConvArgs& a, void* ws, hipStream_t s);
+// conv_wino.hip (transform-domain F(2,5) fp32 convolution for the unit-stride 5-tap launches)
+size_t conv_wino_workspace_bytes(int Cin, int Cout);
+bool conv_wino_supported(const ConvArgs& a);
+int conv_wino_run(const ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s);
 // wgrad_bf16x3.hip (the same split for the weight gradient, opt-in)
 size_t wgrad_bf16x3_workspace_bytes(int B, int M, int Cin, int Cout, int in_stride);
 bool wgrad_bf16x3_supported(const WgradArgs& a);

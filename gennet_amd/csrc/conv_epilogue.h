@@ -1,5 +1,5 @@
 // Epilogue shared by the hand-scheduled fp32 conv kernel (conv_pipe.hip) and the wide-tile bf16-split kernel (conv_bf16x3.hip): both leave a
-// wave's outputs as 32 x 32 MFMA accumulator tiles acc[2][WN] (rows m_base + mt*32 + (r & 3) + 8 (r >> 2) + 4 h, columns n_base + nt*32 + i32).
+// wave's outputs as 32 x 32 MFMA accumulator tiles acc[WMT][WN] (WMT = 2 row tiles per wave; 1 in the transform-domain kernel, conv_wino.hip) (rows m_base + mt*32 + (r & 3) + 8 (r >> 2) + 4 h, columns n_base + nt*32 + i32).
 #pragma once
 #include "common.h"
 #ifndef GN_STORE_AUX
@@ -19,8 +19,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // dropped by the hardware bounds check (out row = out_stride*m + out_off >= Ly exactly when m >= M).
 // MODE 0: y = act(acc + bias);  MODE 1: ... then the fused Dropout keep-mask;  MODE 2: data gradient times the producer's act'(gy);
 // MODE 3: MODE 2 through the producer's dropout.
-template <int ACT, int MODE, int GACT, int WN>
-__device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&acc)[2][WN], int b, int m_base, int n_base, int i32, int h, int out_off) {
+template <int ACT, int MODE, int GACT, int WN, int WMT = 2>
+__device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&acc)[WMT][WN], int b, int m_base, int n_base, int i32, int h, int out_off) {
   const uintptr_t yp = (uintptr_t)(a.y + (size_t)b * a.Ly * a.Cout);
   const unsigned ylo = __builtin_amdgcn_readfirstlane((unsigned)yp), yhi = __builtin_amdgcn_readfirstlane((unsigned)(yp >> 32));
   const int ybytes = __builtin_amdgcn_readfirstlane(a.Ly * a.Cout * 4);
@@ -44,7 +44,7 @@ __device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&
     const float bias = a.bias ? a.bias[n] : 0.f;
     const int voff = rowstride * (4 * h) + out_off * a.Cout + n;                   // element offset of (row 4h, column n)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < WMT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int soff = rowstride * (m_base + mt * 32 + (r & 3) + 8 * (r >> 2));   // wave-uniform
@@ -77,10 +77,10 @@ __device__ __forceinline__ void pipe_epilogue(const ConvArgs& a, const f32x16 (&
 // uniform dispatch, decided once per wave; every case is straight-line code.  Specialised: the forms the three networks run (forward
 // linear / relu / LeakyReLU / tanh, LeakyReLU + dropout, data gradient through relu, through LeakyReLU + dropout); the rest take the
 // variants that decide the activation per element.
-template <int WN>
-__device__ __forceinline__ void pipe_epilogue_dispatch(const ConvArgs& a, const f32x16 (&acc)[2][WN], int b, int m_base, int n_base, int i32, int h, int out_off,
+template <int WN, int WMT = 2>
+__device__ __forceinline__ void pipe_epilogue_dispatch(const ConvArgs& a, const f32x16 (&acc)[WMT][WN], int b, int m_base, int n_base, int i32, int h, int out_off,
                                                        int mode) {
-#define GN_EPI(A_, M_, G_) pipe_epilogue<A_, M_, G_, WN>(a, acc, b, m_base, n_base, i32, h, out_off)
+#define GN_EPI(A_, M_, G_) pipe_epilogue<A_, M_, G_, WN, WMT>(a, acc, b, m_base, n_base, i32, h, out_off)
   if (mode == 0) {
     switch (a.act) {
       case GN_ACT_LINEAR: GN_EPI(GN_ACT_LINEAR, 0, -1); break;

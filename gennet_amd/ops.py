@@ -104,6 +104,18 @@ def conv1d_fwd_bf16x3(x, w, b, stride, pad_left, Lout, act='linear', act_param=0
     return y
 
 
+def conv1d_fwd_wino(x, w, b, pad_left, Lout, act='linear', act_param=0.0):
+    """conv1d_fwd of a unit-stride 5-tap layer through the transform-domain kernel directly (csrc/conv_wino.hip; tests and layer benchmarks)."""
+    _chk(x, w, b)
+    B, L, Cin = x.shape
+    k, _, Cout = w.shape
+    n = _lib.size('gn_conv1d_wino_workspace', Cin, Cout)
+    ws = workspace(n, x.device)
+    y = torch.empty((B, Lout, Cout), dtype=torch.float32, device=x.device)
+    _lib.call('gn_conv1d_fwd_wino', _p(x), _p(w), _p(b), _p(y), _p(ws), ws.numel(), B, L, Cin, Cout, k, 1, pad_left, Lout, ACT[act], float(act_param), _stream())
+    return y
+
+
 def conv1d_fwd_dropout(x, w, b, mask, stride, pad_left, Lout, act, act_param, rate):
     """conv + activation + inverted dropout in one epilogue; mask: uint8 keep-mask with the shape of the output."""
     _chk(x, w, b, mask)

@@ -53,6 +53,15 @@ size_t gn_conv1d_bf16x3_workspace(int B, int L, int Cin, int Cout, int k);
 int gn_conv1d_fwd_bf16x3(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
                          int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout,
                          int act, float act_param, int resplit, void* stream);
+/* Transform-domain fp32 convolution (Cook-Toom / Winograd F(2,5), gennet_amd/csrc/conv_wino.hip) for the unit-stride 5-tap layers --
+ * generator Conv1D(128..1024, 5, padding='same') bbhMahoGANy.py:259-283, PE q branch Conv1D(128, 5) / Conv1D(256, 5) :382-384: six fp32
+ * multiplies per two outputs instead of ten, every product still an exact fp32 fma on v_mfma_f32_32x32x2_f32.  Direct entry (tests, layer
+ * benchmarks); `ws` receives the transformed kernel of this launch (gn_conv1d_wino_workspace bytes).  Needs k == 5, stride 1, Cin % 8 == 0,
+ * Cout % 64 == 0. */
+size_t gn_conv1d_wino_workspace(int Cin, int Cout);
+int gn_conv1d_fwd_wino(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
+                       int B, int L, int Cin, int Cout, int k, int stride, int pad_left, int Lout,
+                       int act, float act_param, void* stream);
 /* Process-wide opt-in: mode 1 routes every Conv1D forward / data-gradient launch that the bf16x3 kernel supports and that is
  * large enough to gain from it (Cin >= 256 and Cout >= 256, unit input stride) through it, operands split per launch into the
  * caller-owned device `workspace` (launches whose planes do not fit stay on the fp32 kernel); mode 0 (the default) restores
