@@ -14,6 +14,8 @@ LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libgennet_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
+# development only (timing-ablation builds, -DGN_ABLATION: kernels that skip work and return wrong results); never set for the shipped library
+FLAGS += os.environ.get('GENNET_HIPCC_EXTRA', '').split()
 
 
 def _stale(out, deps):
