@@ -78,8 +78,10 @@ static void fwd_taps(ConvTaps* t, int k, int stride, int pad_left) {
   t->out_off = 0;
 }
 
-// Opt-in conv arithmetic (gn_set_conv_math): 0 = exact fp32 MFMA (default), 1 = bf16 x 3 operand split for the launches it
-// supports and that are large enough to gain from it; everything else stays on the fp32 kernels.
+// Conv arithmetic (gn_set_conv_math): 0 = direct fp32 MFMA kernels only; 1 = opt-in bf16 x 3 operand split for the launches it supports and that
+// are large enough to gain from it; 2 = transform-domain fp32 (Cook-Toom F(2,5), conv_wino.hip) for every unit-stride 5-tap launch it supports --
+// decided by the layer's shape alone, never by the batch size, so a batch and its chunks take the same kernel and agree bit for bit.  Everything
+// else stays on the direct fp32 kernels.
 static int g_conv_math = 0;
 static void* g_conv_ws = nullptr;
 static size_t g_conv_ws_bytes = 0;
@@ -105,6 +107,8 @@ static bool split_worth_it(int B, int M, int ntaps, int Cin, int Cout) {
 static int conv_dispatch(const ConvArgs& a, hipStream_t s) {
   if (a.Cin <= 4) return conv_smallcin_dispatch(a, s);
   if (a.Cout <= 4) return conv_smallcout_dispatch(a, s);
+  if (g_conv_math == 2 && a.Cin >= 32 && conv_wino_supported(a) && conv_wino_workspace_bytes(a.Cin, a.Cout) <= g_conv_ws_bytes)
+    return conv_wino_run(a, g_conv_ws, g_conv_ws_bytes, s);
   // size threshold of the opt-in split (A/B: GN_BF16X3_MIN_CIN / GN_BF16X3_MIN_COUT): the split pass costs ~10 bytes per input element per launch,
   // the conv gains ~0.02 ps per element and output channel, so small-Cout layers gain little and small-Cin layers (few K chunks) lose to the prologue
   static const int min_cin = getenv("GN_BF16X3_MIN_CIN") ? atoi(getenv("GN_BF16X3_MIN_CIN")) : 256;
@@ -130,8 +134,8 @@ static int conv_dispatch(const ConvArgs& a, hipStream_t s) {
 }
 
 static int set_conv_math_impl(int mode, void* workspace, size_t workspace_bytes) {
-  GN_REQUIRE(mode == 0 || mode == 1, "set_conv_math: mode %d (0 = fp32, 1 = bf16x3)", mode);
-  GN_REQUIRE(mode == 0 || workspace, "set_conv_math: bf16x3 needs a device workspace");
+  GN_REQUIRE(mode >= 0 && mode <= 2, "set_conv_math: mode %d (0 = direct fp32, 1 = bf16x3, 2 = transform-domain fp32)", mode);
+  GN_REQUIRE(mode == 0 || workspace, "set_conv_math: modes 1 and 2 need a device workspace");
   g_conv_math = mode;
   g_conv_ws = mode ? workspace : nullptr;
   g_conv_ws_bytes = mode ? workspace_bytes : 0;

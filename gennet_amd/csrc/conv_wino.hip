@@ -5,15 +5,21 @@
 // six multiplies per two outputs instead of ten: 0.6 of the direct kernel's matrix-core work for the layers that carry most of the step
 // (generator 128 -> 256 -> 512 -> 1024, bbhMahoGANy.py:259-283; PE q branch 64 -> 128 -> 256, :382-386).  Points {0, 1, -1, 1/2, -2, inf}:
 // the set whose fp32 error stays closest to the direct k-ordered fma chain's (profiles/r05_winograd_gate1.txt: 1.4x rms on the forward map).
-// Operands stay fp32 and every product runs on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains in the transform domain): dtype f32.
+// Operands stay fp32 and every product runs on the fp32 matrix instruction (exact fp32 fma chains in the transform domain): dtype f32.
 //
-// Structure = conv_pipe.hip's with the input side of a stride-2, 6-tap convolution (tile t reads rows 2t .. 2t+5: the slab is staged as an even-row
-// and an odd-row plane, same conflict-free granule swap) and the six "taps" kept apart: a wave owns 32 tiles (64 output rows) x 32 columns x 6
-// points = six accumulator tiles; per 8-channel chunk it reads its six raw row fragments (ds_read_b128: four channels each), forms the six
-// transformed fragments in registers (26 fma per channel) and issues 24 MFMAs against the staged U tile.  THREE LDS stages: the raw fragments of
-// chunk c+1 are read and transformed underneath the MFMAs of chunk c, so no wave waits for the LDS or the VALU after a barrier.
-// The epilogue applies AT in registers (even rows: sum of points 0..4; odd rows: p1 - p2 + p3/2 - 2 p4 + p5) and hands the two 32 x 32 tiles to
-// the shared lean epilogue (bias, activation, dropout, fused backward, BatchNorm statistics) with an output row stride of 2.
+// What shaped the kernel (measured, profiles/r05_winograd_gate.txt): fp32 VALU work does NOT hide under the fp32 MFMA -- the instruction runs at
+// the fp32 vector rate and a v_fma_f32 beside it costs its full four cycles of the SIMD -- so the input transform, done in registers by the wave
+// that consumes it, must be amortised over as many output columns as the accumulator budget allows: v_mfma_f32_16x16x4_f32 (four accumulator
+// registers per 16 x 16 tile) lets a wave own 16 tiles (32 output rows) x 64 columns x 6 points in 96 accumulator registers, so one transformed
+// fragment feeds four column tiles, and the transform itself runs as packed fp32 (v_pk_fma_f32 on channel pairs): 18 VALU instructions per 48 MFMAs.
+//
+// Block = WAVES_M waves stacked in M, 64 columns; per 8-channel chunk: input slab (the rows of a stride-2, 6-tap convolution: tile t reads rows
+// 2t .. 2t+5; staged as an even-row and an odd-row plane, so a wave's 16 tiles x 4 channel pairs are 512 contiguous bytes per row offset: no
+// bank conflicts, one address register) and the chunk's U tile, both by LDS-DMA; the global U image is written by wino_u_kernel in exactly the
+// order the lanes read it (one ds_read_b128 = two column tiles x two k-steps), so its staging is a contiguous copy.  THREE LDS stages: the raw
+// fragments of chunk c+1 are read and transformed beside the MFMAs of chunk c.  The epilogue applies AT in registers (even rows: sum of points
+// 0..4; odd rows: p1 - p2 + p3/2 - 2 p4 + p5) and hands the 16 x 16 tiles to the shared epilogue (bias, activation, dropout, fused backward) with an
+// output row stride of 2; BatchNorm statistics leave the epilogue as in conv_pipe.hip.
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
@@ -29,167 +35,175 @@ struct WinoTaps {
   int wq[5];      // kernel index (into w's leading axis) of the tap at offset off0 + q
 };
 
-// U[p][ci][co] = sum_q G[p][q] * w[wq[q]][ci][co], formed in fp64 and rounded once.
-__global__ void wino_u_kernel(const float* __restrict__ w, float* __restrict__ U, size_t cc, WinoTaps t) {
+// U_p = sum_q G[p][q] * w_q, formed in fp64 and rounded once, written as [chunk = ci / 8][column tile = co / 64][p][cth][kq][n16][ctl][s]:
+// channel ci = 8 chunk + 2 kq + s, column co = 64 tile + 16 (2 cth + ctl) + n16 -- the order in which the lanes of conv_wino_kernel read a stage.
+__global__ void wino_u_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout, WinoTaps t) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t cc = (size_t)Cin * Cout;
   if (i >= cc) return;
+  const int ci = (int)(i / Cout), co = (int)(i % Cout);
   double g[5];
 #pragma unroll
   for (int q = 0; q < 5; ++q) g[q] = (double)w[(size_t)t.wq[q] * cc + i];
-  U[i] = (float)(0.5 * g[0]);
-  U[cc + i] = (float)((g[0] + g[1] + g[2] + g[3] + g[4]) * (1.0 / 6.0));
-  U[2 * cc + i] = (float)((g[0] - g[1] + g[2] - g[3] + g[4]) * (1.0 / 6.0));
-  U[3 * cc + i] = (float)((16.0 * g[0] + 8.0 * g[1] + 4.0 * g[2] + 2.0 * g[3] + g[4]) * (1.0 / 15.0));
-  U[4 * cc + i] = (float)((g[0] - 2.0 * g[1] + 4.0 * g[2] - 8.0 * g[3] + 16.0 * g[4]) * (1.0 / 30.0));
-  U[5 * cc + i] = (float)(0.5 * g[4]);
+  float u[6];
+  u[0] = (float)(0.5 * g[0]);
+  u[1] = (float)((g[0] + g[1] + g[2] + g[3] + g[4]) * (1.0 / 6.0));
+  u[2] = (float)((g[0] - g[1] + g[2] - g[3] + g[4]) * (1.0 / 6.0));
+  u[3] = (float)((16.0 * g[0] + 8.0 * g[1] + 4.0 * g[2] + 2.0 * g[3] + g[4]) * (1.0 / 15.0));
+  u[4] = (float)((g[0] - 2.0 * g[1] + 4.0 * g[2] - 8.0 * g[3] + 16.0 * g[4]) * (1.0 / 30.0));
+  u[5] = (float)(0.5 * g[4]);
+  const int chunk = ci >> 3, c = ci & 7, kq = c >> 1, s = c & 1;
+  const int tile = co >> 6, nn = co & 63, ct = nn >> 4, n16 = nn & 15, cth = ct >> 1, ctl = ct & 1;
+  const size_t base = ((size_t)chunk * (Cout >> 6) + tile) * 3072 + ((cth * 4 + kq) * 16 + n16) * 4 + ctl * 2 + s;
+#pragma unroll
+  for (int p = 0; p < 6; ++p) U[base + p * 512] = u[p];
 }
 
 // ---------------------------------------------------------------------------------------------
-// Hand-scheduled chunk (the reason is conv_pipe.hip's: hipcc sinks the LDS reads next to their use and drains lgkmcnt in front of every short
-// MFMA group; here it also put the whole transform behind the chunk's last MFMA).  A chunk of a wave = 24 MFMA slots (point p = slot / 4,
-// k-step s = slot % 4), each one asm statement:
-//   slot 4p     issues the two paired reads of the NEXT group's four U values (ds_read2st64_b32: rows s, s+1 of a point are 256 bytes apart; after
-//               the last group: group 0 of the next chunk, whose stage has been complete since the previous barrier), slot 0 also this lane's six
-//               raw row fragments of the NEXT chunk; a counted lgkmcnt retires exactly what the slot consumes (LDS returns in order);
-//   slots >= 4  are followed by one or two of the 24 (point, channel) values of the next chunk's transformed fragments: ~5 VALU per MFMA, under it;
-//   the staging pieces of chunk + 2 go behind the first slots.
+// BT of F(2,5) on {0, 1, -1, 1/2, -2, inf}, rows scaled to integers (the inverse factors sit in G above), on a channel PAIR per lane:
+//   a = d1 - d3, b = d2 - d4
+//   v0 = 2 d0 - 3 a - 4 d2 + 2 d4        v1 = -2 d1 + d2 + 5 d3 + 2 d4       v2 = -2 d1 + 5 d2 - d3 - 2 d4
+//   v3 = 2 a + b                         v4 = a - 2 b                        v5 = 2 d5 + 2 a - 2 d3 - 3 b
+// 18 packed instructions, written as asm: hipcc moves plain fma code away from the MFMA slots it is meant to sit between.  3 and 5 are not inline
+// constants: SGPR pairs.  Piece K of wino_piece is one instruction; the order interleaves the six dependency chains.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wino_slot(f32x16& c, float a, float b) {
-  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "memory");
+struct WinoT {
+  f32x2 a, b;
+};
+#define GN_PK_SUB(o, x, y) asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=&v"(o) : "v"(x), "v"(y))
+#define GN_PK_DBL(o, x) asm volatile("v_pk_add_f32 %0, %1, %1" : "=&v"(o) : "v"(x))
+#define GN_PK_FMA_NEW(o, x, c, z) asm volatile("v_pk_fma_f32 %0, %1, " c ", %2 op_sel_hi:[1,0,1]" : "=&v"(o) : "v"(x), "v"(z))
+#define GN_PK_FMA_NEWNEG(o, x, c, z) asm volatile("v_pk_fma_f32 %0, %1, " c ", %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=&v"(o) : "v"(x), "v"(z))
+#define GN_PK_FMA_ACC(o, x, c) asm volatile("v_pk_fma_f32 %0, %1, " c ", %0 op_sel_hi:[1,0,1]" : "+v"(o) : "v"(x))
+#define GN_PK_FMA_ACCS(o, x, k) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(o) : "v"(x), "s"(k))
+template <int K>
+__device__ __forceinline__ void wino_piece(const f32x2 (&d)[6], f32x2 (&v)[6], WinoT& t, unsigned long long k5, unsigned long long km3) {
+  if constexpr (K == 0) GN_PK_SUB(t.a, d[1], d[3]);
+  else if constexpr (K == 1) GN_PK_SUB(t.b, d[2], d[4]);
+  else if constexpr (K == 2) GN_PK_FMA_NEW(v[1], d[4], "2.0", d[2]);
+  else if constexpr (K == 3) GN_PK_FMA_NEWNEG(v[2], d[4], "-2.0", d[3]);
+  else if constexpr (K == 4) GN_PK_DBL(v[0], d[0]);
+  else if constexpr (K == 5) GN_PK_DBL(v[5], d[5]);
+  else if constexpr (K == 6) GN_PK_FMA_NEW(v[3], t.a, "2.0", t.b);
+  else if constexpr (K == 7) GN_PK_FMA_NEW(v[4], t.b, "-2.0", t.a);
+  else if constexpr (K == 8) GN_PK_FMA_ACCS(v[1], d[3], k5);
+  else if constexpr (K == 9) GN_PK_FMA_ACCS(v[2], d[2], k5);
+  else if constexpr (K == 10) GN_PK_FMA_ACCS(v[0], t.a, km3);
+  else if constexpr (K == 11) GN_PK_FMA_ACC(v[5], t.a, "2.0");
+  else if constexpr (K == 12) GN_PK_FMA_ACC(v[1], d[1], "-2.0");
+  else if constexpr (K == 13) GN_PK_FMA_ACC(v[2], d[1], "-2.0");
+  else if constexpr (K == 14) GN_PK_FMA_ACC(v[0], d[2], "-4.0");
+  else if constexpr (K == 15) GN_PK_FMA_ACC(v[5], d[3], "-2.0");
+  else if constexpr (K == 16) GN_PK_FMA_ACC(v[0], d[4], "2.0");
+  else GN_PK_FMA_ACCS(v[5], t.b, km3);
+}
+template <int K = 0>
+__device__ __forceinline__ void wino_bt_all(const f32x2 (&d)[6], f32x2 (&v)[6], WinoT& t, unsigned long long k5, unsigned long long km3) {
+  if constexpr (K < 18) {
+    wino_piece<K>(d, v, t, k5, km3);
+    wino_bt_all<K + 1>(d, v, t, k5, km3);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A chunk of a wave = 48 MFMA slots (point p = slot / 8, k-step s = (slot / 4) % 2, column tile ct = slot % 4), each one asm statement:
+//   slot 8p     issues the two reads of the NEXT point's U values (after the last point: point 0 of the next chunk, whose stage has been complete since
+//               the previous barrier), slot 0 also this lane's six raw row fragments of the NEXT chunk; a counted lgkmcnt retires exactly what the slot
+//               consumes (LDS returns in order);
+//   slots >= 8  carry the 18 transform instructions of the next chunk, one every other slot; the staging pieces of chunk + 2 sit behind slots 1, 3, ...
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wino_slot(f32x4& c, float a, float b) {
+  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "memory");
 }
 template <int O, int WAIT>
-__device__ __forceinline__ void wino_slot_rb(f32x16& c, float a, float b, f32x2& nb01, f32x2& nb23, unsigned addr_b) {
+__device__ __forceinline__ void wino_slot_rb(f32x4& c, float a, float b, f32x4& nb0, f32x4& nb1, unsigned addr_b) {
   asm volatile(
-      "ds_read2st64_b32 %1, %5 offset0:%6 offset1:%7\n\t"
-      "ds_read2st64_b32 %2, %5 offset0:%8 offset1:%9\n\t"
-      "s_waitcnt lgkmcnt(%10)\n\t"
-      "v_mfma_f32_32x32x2_f32 %0, %3, %4, %0"
-      : "+v"(c), "=&v"(nb01), "=&v"(nb23)
-      : "v"(a), "v"(b), "v"(addr_b), "i"(O), "i"(O + 1), "i"(O + 2), "i"(O + 3), "i"(WAIT)
+      "ds_read_b128 %1, %5 offset:%6\n\t"
+      "ds_read_b128 %2, %5 offset:%7\n\t"
+      "s_waitcnt lgkmcnt(%8)\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, %3, %4, %0"
+      : "+v"(c), "=&v"(nb0), "=&v"(nb1)
+      : "v"(a), "v"(b), "v"(addr_b), "i"(O), "i"(O + 1024), "i"(WAIT)
       : "memory");
 }
-// ... and the raw fragments of the next chunk (slot 0)
-template <int O>
-__device__ __forceinline__ void wino_slot_rba(f32x16& c, float a, float b, f32x2& nb01, f32x2& nb23, unsigned addr_b, f32x4 (&d)[6], const unsigned (&addr_a)[6]) {
+// ... and the raw fragments of the next chunk (slot 0); this point's U values were read across the barrier: the wait retires them
+template <int O, int OP1>
+__device__ __forceinline__ void wino_slot_rba(f32x4& c, float a, float b, f32x4& nb0, f32x4& nb1, unsigned addr_b, f32x2 (&d)[6], unsigned addr_a) {
   asm volatile(
-      "ds_read2st64_b32 %1, %11 offset0:%18 offset1:%19\n\t"
-      "ds_read2st64_b32 %2, %11 offset0:%20 offset1:%21\n\t"
-      "ds_read_b128 %3, %12\n\t"
-      "ds_read_b128 %4, %13\n\t"
-      "ds_read_b128 %5, %14\n\t"
-      "ds_read_b128 %6, %15\n\t"
-      "ds_read_b128 %7, %16\n\t"
-      "ds_read_b128 %8, %17\n\t"
-      "s_waitcnt lgkmcnt(8)\n\t"                        // this group's U values were read across the barrier: nothing else retires them
-      "v_mfma_f32_32x32x2_f32 %0, %9, %10, %0"
-      : "+v"(c), "=&v"(nb01), "=&v"(nb23), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5])
-      : "v"(a), "v"(b), "v"(addr_b), "v"(addr_a[0]), "v"(addr_a[1]), "v"(addr_a[2]), "v"(addr_a[3]), "v"(addr_a[4]), "v"(addr_a[5]), "i"(O), "i"(O + 1), "i"(O + 2),
-        "i"(O + 3)
+      "ds_read_b128 %1, %11 offset:%13\n\t"
+      "ds_read_b128 %2, %11 offset:%14\n\t"
+      "ds_read_b64 %3, %12\n\t"
+      "ds_read_b64 %4, %12 offset:%15\n\t"
+      "ds_read_b64 %5, %12 offset:32\n\t"
+      "ds_read_b64 %6, %12 offset:%16\n\t"
+      "ds_read_b64 %7, %12 offset:64\n\t"
+      "ds_read_b64 %8, %12 offset:%17\n\t"
+      "s_waitcnt lgkmcnt(8)\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, %9, %10, %0"
+      : "+v"(c), "=&v"(nb0), "=&v"(nb1), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5])
+      : "v"(a), "v"(b), "v"(addr_b), "v"(addr_a), "i"(O), "i"(O + 1024), "i"(OP1), "i"(OP1 + 32), "i"(OP1 + 64)
       : "memory");
 }
-// ... slot 4: its wait also retires the raw fragments (issued before the reads this slot adds); they are operands so that their readers depend on it
+// ... slot 8: its wait also retires the raw fragments (issued before the reads this slot adds); they are operands so that their readers depend on it
 template <int O>
-__device__ __forceinline__ void wino_slot_rbw(f32x16& c, float a, float b, f32x2& nb01, f32x2& nb23, unsigned addr_b, f32x4 (&d)[6]) {
+__device__ __forceinline__ void wino_slot_rbw(f32x4& c, float a, float b, f32x4& nb0, f32x4& nb1, unsigned addr_b, f32x2 (&d)[6]) {
   asm volatile(
-      "ds_read2st64_b32 %1, %11 offset0:%12 offset1:%13\n\t"
-      "ds_read2st64_b32 %2, %11 offset0:%14 offset1:%15\n\t"
+      "ds_read_b128 %1, %11 offset:%12\n\t"
+      "ds_read_b128 %2, %11 offset:%13\n\t"
       "s_waitcnt lgkmcnt(2)\n\t"
-      "v_mfma_f32_32x32x2_f32 %0, %9, %10, %0"
-      : "+v"(c), "=&v"(nb01), "=&v"(nb23), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5])
-      : "v"(a), "v"(b), "v"(addr_b), "i"(O), "i"(O + 1), "i"(O + 2), "i"(O + 3)
+      "v_mfma_f32_16x16x4_f32 %0, %9, %10, %0"
+      : "+v"(c), "=&v"(nb0), "=&v"(nb1), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5])
+      : "v"(a), "v"(b), "v"(addr_b), "i"(O), "i"(O + 1024)
       : "memory");
 }
 
-// one (point, channel) value of the transformed fragment, as asm: hipcc moves plain fma code away from the MFMA slots it is meant to sit under
-// (all of it in front of the chunk or behind it) and packs channel pairs into v_pk_fma_f32, which costs the matrix pipe more than two v_fma_f32
-// (MI355X_MICROARCH.md, cycle constants).  3 and 5 are not inline constants: VOP2 literals.
-template <int P>
-__device__ __forceinline__ void wino_piece(float& o, float d0, float d1, float d2, float d3, float d4, float d5) {
-  if constexpr (P == 0)
-    asm volatile("v_add_f32 %0, %5, %5\n\tv_fmac_f32 %0, 0x40400000, %4\n\tv_fmac_f32 %0, -4.0, %3\n\tv_fmac_f32 %0, 0xc0400000, %2\n\tv_fmac_f32 %0, 2.0, %1"
-                 : "=&v"(o) : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(d4));
-  else if constexpr (P == 1)
-    asm volatile("v_fma_f32 %0, %4, 2.0, %2\n\tv_fmac_f32 %0, 0x40a00000, %3\n\tv_fmac_f32 %0, -2.0, %1" : "=&v"(o) : "v"(d1), "v"(d2), "v"(d3), "v"(d4));
-  else if constexpr (P == 2)
-    asm volatile("v_fma_f32 %0, %4, -2.0, -%3\n\tv_fmac_f32 %0, 0x40a00000, %2\n\tv_fmac_f32 %0, -2.0, %1" : "=&v"(o) : "v"(d1), "v"(d2), "v"(d3), "v"(d4));
-  else if constexpr (P == 3)
-    asm volatile("v_sub_f32 %0, %2, %4\n\tv_fmac_f32 %0, -2.0, %3\n\tv_fmac_f32 %0, 2.0, %1" : "=&v"(o) : "v"(d1), "v"(d2), "v"(d3), "v"(d4));
-  else if constexpr (P == 4)
-    asm volatile("v_sub_f32 %0, %1, %3\n\tv_fmac_f32 %0, 2.0, %4\n\tv_fmac_f32 %0, -2.0, %2" : "=&v"(o) : "v"(d1), "v"(d2), "v"(d3), "v"(d4));
-  else
-    asm volatile("v_add_f32 %0, %5, %5\n\tv_fmac_f32 %0, 0x40400000, %4\n\tv_fmac_f32 %0, -4.0, %3\n\tv_fmac_f32 %0, 0xc0400000, %2\n\tv_fmac_f32 %0, 2.0, %1"
-                 : "=&v"(o) : "v"(d1), "v"(d2), "v"(d3), "v"(d4), "v"(d5));
-}
-__device__ __forceinline__ void wino_bt_all(const f32x4 (&d)[6], float (&v)[6][4]) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    wino_piece<0>(v[0][e], d[0][e], d[1][e], d[2][e], d[3][e], d[4][e], d[5][e]);
-    wino_piece<1>(v[1][e], d[0][e], d[1][e], d[2][e], d[3][e], d[4][e], d[5][e]);
-    wino_piece<2>(v[2][e], d[0][e], d[1][e], d[2][e], d[3][e], d[4][e], d[5][e]);
-    wino_piece<3>(v[3][e], d[0][e], d[1][e], d[2][e], d[3][e], d[4][e], d[5][e]);
-    wino_piece<4>(v[4][e], d[0][e], d[1][e], d[2][e], d[3][e], d[4][e], d[5][e]);
-    wino_piece<5>(v[5][e], d[0][e], d[1][e], d[2][e], d[3][e], d[4][e], d[5][e]);
-  }
-}
-
-template <int TN, int ABL = 0>
+template <int RPER, int ABL = 0>
 struct WinoChunk {
-  static_assert(TN == 64, "ds_read2st64_b32 pairs two U rows 256 bytes apart");
-  // transform pieces of the next chunk behind slot I: the 24 (point, channel) values over slots 4 .. 23
-  template <int I>
-  static __device__ __forceinline__ void pieces(const f32x4 (&d)[6], float (&vn)[6][4]) {
-    if constexpr (I >= 4) {
-      constexpr int lo = (I - 4) * 24 / 20, hi = (I - 3) * 24 / 20;
-      if constexpr (lo < hi) piece<lo>(d, vn);
-      if constexpr (lo + 1 < hi) piece<lo + 1>(d, vn);
-    }
-  }
-  template <int K>
-  static __device__ __forceinline__ void piece(const f32x4 (&d)[6], float (&vn)[6][4]) {
-    constexpr int P = K / 4, E = K % 4;
-    wino_piece<P>(vn[P][E], d[0][E], d[1][E], d[2][E], d[3][E], d[4][E], d[5][E]);
-  }
   template <int NPIECES, int I = 0, class D>
-  static __device__ __forceinline__ void run(f32x16 (&acc)[6], const float (&v)[6][4], float (&vn)[6][4], f32x4 (&d)[6], f32x2 (&B)[2][2], unsigned addr_b,
-                                             unsigned addr_b_next, const unsigned (&addr_a)[6], D& dma) {
-    if constexpr (I < 24) {
-      constexpr int P = I / 4, S = I % 4;
-      f32x2(&bc)[2] = B[P & 1];
-      f32x2(&bn)[2] = B[(P + 1) & 1];
-      const float bv = bc[S >> 1][S & 1];
-      if constexpr ((ABL & 8) != 0) wino_slot(acc[P], v[P][S], bv);
-      else if constexpr (I == 0) wino_slot_rba<8>(acc[0], v[0][0], bv, bn[0], bn[1], addr_b, d, addr_a);
-      else if constexpr (I == 4) wino_slot_rbw<16>(acc[1], v[1][0], bv, bn[0], bn[1], addr_b, d);
-      else if constexpr (I == 20) wino_slot_rb<0, 2>(acc[5], v[5][0], bv, bn[0], bn[1], addr_b_next);
-      else if constexpr (S == 0) wino_slot_rb<(P + 1) * 8, 2>(acc[P], v[P][0], bv, bn[0], bn[1], addr_b);
-      else wino_slot(acc[P], v[P][S], bv);
-      if constexpr (I >= 1 && I - 1 < NPIECES) dma(std::integral_constant<int, I - 1>{});
-      if constexpr (!(ABL & 2)) pieces<I>(d, vn);
-      run<NPIECES, I + 1>(acc, v, vn, d, B, addr_b, addr_b_next, addr_a, dma);
+  static __device__ __forceinline__ void run(f32x4 (&acc)[6][4], const f32x2 (&v)[6], f32x2 (&vn)[6], f32x2 (&d)[6], WinoT& t, f32x4 (&B)[2][2], unsigned addr_b,
+                                             unsigned addr_b_next, unsigned addr_a, unsigned long long k5, unsigned long long km3, D& dma) {
+    if constexpr (I < 48) {
+      constexpr int P = I / 8, S = (I / 4) % 2, CT = I % 4;
+      f32x4(&bc)[2] = B[P & 1];
+      f32x4(&bn)[2] = B[(P + 1) & 1];
+      const float bv = bc[CT >> 1][2 * (CT & 1) + S];
+      const float av = v[P][S];
+      if constexpr ((ABL & 8) != 0) wino_slot(acc[P][CT], av, bv);
+      else if constexpr (I == 0) wino_slot_rba<2048, RPER * 32>(acc[0][0], av, bv, bn[0], bn[1], addr_b, d, addr_a);
+      else if constexpr (I == 8) wino_slot_rbw<2 * 2048>(acc[1][0], av, bv, bn[0], bn[1], addr_b, d);
+      else if constexpr (I == 40) wino_slot_rb<0, 2>(acc[5][0], av, bv, bn[0], bn[1], addr_b_next);
+      else if constexpr (I % 8 == 0) wino_slot_rb<(P + 1) * 2048, 2>(acc[P][0], av, bv, bn[0], bn[1], addr_b);
+      else wino_slot(acc[P][CT], av, bv);
+      if constexpr ((I & 1) && (I >> 1) < NPIECES) dma(std::integral_constant<int, (I >> 1)>{});
+      if constexpr (!(ABL & 2) && I >= 8) {
+        constexpr int lo = (I - 8) * 18 / 40, hi = (I - 7) * 18 / 40;
+        if constexpr (lo < hi) wino_piece<lo>(d, vn, t, k5, km3);
+      }
+      run<NPIECES, I + 1>(acc, v, vn, d, t, B, addr_b, addr_b_next, addr_a, k5, km3, dma);
     }
   }
 };
 
 // ABL: timing ablations, compiled only under -DGN_ABLATION (never into the shipped library; results are wrong for ABL != 0): bit 0 = no staging in the
 // loop, bit 1 = no transform, bit 2 = no barrier, bit 3 = no LDS reads in the loop
-template <int WAVES_M, int WAVES_N, int ABL = 0>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 256 ? 1 : 2)) void conv_wino_kernel(ConvArgs a, const float* __restrict__ U, int off0,
-                                                                                                                   int m_tiles, int n_tiles, int patch) {
+template <int WAVES_M, int ABL = 0>
+__global__ __launch_bounds__(64 * WAVES_M, (WAVES_M > 4 ? 1 : 2)) void conv_wino_kernel(ConvArgs a, const float* __restrict__ U, int off0, int m_tiles, int n_tiles,
+                                                                                        int patch) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int KC = 8, NP = 6;
-  constexpr int TT = WAVES_M * 32;                 // tiles (output row pairs) per block
-  constexpr int TN = WAVES_N * 32;
-  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int TT = WAVES_M * 16;                 // tiles (output row pairs) per block
+  constexpr int TN = 64;
+  constexpr int NT = 64 * WAVES_M;
   constexpr int RPER = TT + 2;                     // rows per parity plane: the block reads input rows 0 .. 2 TT + 3 of its window
   constexpr int SLAB = 2 * RPER * KC;              // floats
-  constexpr int BUF = SLAB + NP * KC * TN;
+  constexpr int UT = NP * KC * TN;                 // 3072 floats
+  constexpr int BUF = SLAB + UT;
   constexpr int STAGE_BYTES = BUF * 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef __attribute__((address_space(3))) void* lptr_t;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int i32 = lane & 31, h = lane >> 5;
+  const int n16 = lane & 15, kq = lane >> 4;
   // block -> tile: the XCD patch order of conv_pipe.hip
   const int bid = blockIdx.x;
   int n_lin, slab;
@@ -207,11 +221,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
   const int b = __builtin_amdgcn_readfirstlane(slab / m_tiles);
   const int t0 = m_tile * TT, n0 = n_tile * TN;
 
-  f32x16 acc[NP];
+  f32x4 acc[NP][4];
 #pragma unroll
   for (int p = 0; p < NP; ++p)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[p][ct][r] = 0.f;
 
   const int t_base = 2 * t0 + off0;                // input row of slab row 0
   const uintptr_t xbp = (uintptr_t)(a.x + (size_t)b * a.Lin * a.Cin);
@@ -221,13 +237,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
 
   constexpr int S_COUNT = SLAB / 4;                // 16-byte granules of one slab stage, in LDS order
   constexpr int S_ITEMS = (S_COUNT + NT - 1) / NT;
-  constexpr int W_TOTAL = NP * KC * (TN / 4);
+  constexpr int W_TOTAL = UT / 4;
   constexpr int W_ITEMS = (W_TOTAL + NT - 1) / NT;
   int soff[S_ITEMS];
 #pragma unroll
   for (int it = 0; it < S_ITEMS; ++it) {
     const int id = tid + it * NT;
-    const int lr = id / 2, c4 = (id % 2) ^ ((lr >> 3) & 1);                // the row's two granules swapped in LDS rows 8..15 mod 16
+    const int lr = id >> 1, c4 = id & 1;
     const int r = lr < RPER ? 2 * lr : 2 * (lr - RPER) + 1;                // plane 0: even rows, plane 1: odd rows
     soff[it] = (id < S_COUNT) ? ((t_base + r) * a.Cin + 4 * c4) * 4 : 0x40000000;   // rows outside [0, Lin): the descriptor returns 0
   }
@@ -235,16 +251,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
   const unsigned wb_lo = __builtin_amdgcn_readfirstlane((unsigned)wbp), wb_hi = __builtin_amdgcn_readfirstlane((unsigned)(wbp >> 32));
   const int wbytes = __builtin_amdgcn_readfirstlane(NP * a.Cin * a.Cout * 4);
   const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)wb_hi << 32) | wb_lo), 0, wbytes, 0x00020000);
-  int woff[W_ITEMS];
-#pragma unroll
-  for (int it = 0; it < W_ITEMS; ++it) {
-    const int id = min(tid + it * NT, W_TOTAL - 1);
-    const int n4 = id % (TN / 4);
-    const int kk = (id / (TN / 4)) % KC;
-    const int p = id / ((TN / 4) * KC);
-    woff[it] = ((p * a.Cin + kk) * a.Cout + n0 + 4 * n4) * 4;
-  }
-  int c0_next = 0, st_next = 0;
+  const int w_chunk_bytes = n_tiles * UT * 4;      // the U tiles of one channel chunk
+  int c_next = 0, st_next = 0;
   bool in_loop = false;
   auto dma_piece = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
@@ -252,14 +260,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
     float* stg = smem + st_next * BUF;
     if constexpr (k < S_ITEMS) {
       if ((k + 1) * NT <= S_COUNT || tid + k * NT < S_COUNT)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stg + (k * NT + (tid & ~63)) * 4), 16, soff[k], c0_next * 4, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stg + (k * NT + (tid & ~63)) * 4), 16, soff[k], c_next * KC * 4, 0, 0);
     } else {
       constexpr int it = k - S_ITEMS;
       if ((it + 1) * NT <= W_TOTAL || (tid & ~63) + it * NT < W_TOTAL)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(stg + SLAB + (it * NT + (tid & ~63)) * 4), 16, woff[it], c0_next * a.Cout * 4, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(stg + SLAB + (it * NT + (tid & ~63)) * 4), 16, (n_tile * UT + (tid + it * NT) * 4) * 4,
+                                                 c_next * w_chunk_bytes, 0, 0);
     }
   };
   constexpr int NPIECES = S_ITEMS + W_ITEMS;
+  static_assert(NPIECES <= 6, "staging pieces");
   auto dma_all = [&]() {
     dma_piece(std::integral_constant<int, 0>{});
     if constexpr (NPIECES > 1) dma_piece(std::integral_constant<int, 1>{});
@@ -267,34 +277,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
     if constexpr (NPIECES > 3) dma_piece(std::integral_constant<int, 3>{});
     if constexpr (NPIECES > 4) dma_piece(std::integral_constant<int, 4>{});
     if constexpr (NPIECES > 5) dma_piece(std::integral_constant<int, 5>{});
-    static_assert(NPIECES <= 6, "staging pieces");
   };
 
   // chunk-invariant byte addresses of this lane's operands in stage 0
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  unsigned base_a[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int row = (j & 1) * RPER + (j >> 1) + wm * 32 + i32;
-    base_a[j] = lds0 + (row * 2 + (h ^ ((row >> 3) & 1))) * 16;            // granule h of the row: channels 4h .. 4h+3
-  }
-  const unsigned base_b = lds0 + (SLAB + 4 * h * TN + wn * 32 + i32) * 4;  // U rows 4h + s of a point, s = k-step
+  const unsigned base_a = lds0 + (wave * 16 + n16) * 32 + kq * 8;           // row (tile) of plane 0, channel pair kq
+  const unsigned base_b = lds0 + SLAB * 4 + (kq * 16 + n16) * 16;           // + (2 p + cth) * 1024
+  const unsigned long long k5 = 0x40a0000040a00000ull, km3 = 0xc0400000c0400000ull;
 
   const int n_chunks = a.Cin / KC;
-  c0_next = 0; st_next = 0; dma_all();
-  c0_next = min(1, n_chunks - 1) * KC; st_next = 1; dma_all();
+  c_next = 0; st_next = 0; dma_all();
+  c_next = min(1, n_chunks - 1); st_next = 1; dma_all();
   __syncthreads();                                  // drains the LDS-DMA (vmcnt(0)) in front of the barrier
 
-  float V0[6][4], V1[6][4];
-  f32x4 d[6];
-  f32x2 Bq[2][2];
+  f32x2 V0[6], V1[6], d[6];
+  f32x4 Bq[2][2];
+  WinoT tt;
   {
     const char* sb = reinterpret_cast<const char*>(smem);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) d[j] = *reinterpret_cast<const f32x4*>(sb + (base_a[j] - lds0));
-    wino_bt_all(d, V0);
-    const float* bp = reinterpret_cast<const float*>(sb + (base_b - lds0));
-    Bq[0][0][0] = bp[0]; Bq[0][0][1] = bp[TN]; Bq[0][1][0] = bp[2 * TN]; Bq[0][1][1] = bp[3 * TN];
+    for (int j = 0; j < 6; ++j) d[j] = *reinterpret_cast<const f32x2*>(sb + (base_a - lds0) + (j & 1) * RPER * 32 + (j >> 1) * 32);
+    wino_bt_all(d, V0, tt, k5, km3);
+    Bq[0][0] = *reinterpret_cast<const f32x4*>(sb + (base_b - lds0));
+    Bq[0][1] = *reinterpret_cast<const f32x4*>(sb + (base_b - lds0) + 1024);
   }
   int st = 0;
   in_loop = true;
@@ -303,54 +308,57 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
     for (int half = 0; half < 2; ++half) {
       if (half == 1 && ch + 1 >= n_chunks) break;
       const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
-      c0_next = min(ch + half + 2, n_chunks - 1) * KC;                      // stage st2 held chunk - 1: every wave is past its last read of it
+      c_next = min(ch + half + 2, n_chunks - 1);                            // stage st2 held chunk - 1: every wave is past its last read of it
       st_next = st2;
-      unsigned addr_a[6];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) addr_a[j] = base_a[j] + st1 * STAGE_BYTES;     // chunk + 1 landed before the previous barrier
+      const unsigned addr_a = base_a + st1 * STAGE_BYTES;                   // chunk + 1 landed before the previous barrier
       const unsigned addr_b = base_b + st * STAGE_BYTES, addr_b_next = base_b + st1 * STAGE_BYTES;
-      if (half == 0) WinoChunk<TN, ABL>::template run<NPIECES>(acc, V0, V1, d, Bq, addr_b, addr_b_next, addr_a, dma_piece);
-      else WinoChunk<TN, ABL>::template run<NPIECES>(acc, V1, V0, d, Bq, addr_b, addr_b_next, addr_a, dma_piece);
+      if (half == 0) WinoChunk<RPER, ABL>::template run<NPIECES>(acc, V0, V1, d, tt, Bq, addr_b, addr_b_next, addr_a, k5, km3, dma_piece);
+      else WinoChunk<RPER, ABL>::template run<NPIECES>(acc, V1, V0, d, tt, Bq, addr_b, addr_b_next, addr_a, k5, km3, dma_piece);
       if constexpr (!(ABL & 4)) __syncthreads();
       st = st1;
     }
   }
   // MFMA results written inside asm: the compiler inserts no wait states for its own readers of acc
-  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]));
+  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[5][0]), "+v"(acc[5][1]), "+v"(acc[5][2]), "+v"(acc[5][3]));
 
   // AT: even rows = p0 + p1 + p2 + p3 + p4, odd rows = p1 - p2 + p3 / 2 - 2 p4 + p5
-  f32x16 out[2][1][1];
+  f32x4 out[2][4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    out[0][0][0][r] = (((acc[0][r] + acc[1][r]) + acc[2][r]) + acc[3][r]) + acc[4][r];
-    out[1][0][0][r] = __builtin_fmaf(-2.f, acc[4][r], __builtin_fmaf(0.5f, acc[3][r], acc[1][r] - acc[2][r])) + acc[5][r];
-  }
-  const int m_base = t0 + __builtin_amdgcn_readfirstlane(wm) * 32, n_base = n0 + wn * 32;
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      out[0][ct][r] = (((acc[0][ct][r] + acc[1][ct][r]) + acc[2][ct][r]) + acc[3][ct][r]) + acc[4][ct][r];
+      out[1][ct][r] = __builtin_fmaf(-2.f, acc[4][ct][r], __builtin_fmaf(0.5f, acc[3][ct][r], acc[1][ct][r] - acc[2][ct][r])) + acc[5][ct][r];
+    }
+  const int m_base = t0 + __builtin_amdgcn_readfirstlane(wave) * 16;
   const int mode = a.gy ? (a.gmask ? 3 : 2) : (a.mask ? 1 : 0);
   ConvArgs a2 = a;
   a2.t.out_stride = 2;
-  pipe_epilogue_dispatch<1, 1>(a2, out[0], b, m_base, n_base, i32, h, a.t.out_off, mode);
-  pipe_epilogue_dispatch<1, 1>(a2, out[1], b, m_base, n_base, i32, h, a.t.out_off + 1, mode);
+  tile16_epilogue_dispatch<4>(a2, out[0], b, m_base, n0, n16, kq, a.t.out_off, mode);
+  tile16_epilogue_dispatch<4>(a2, out[1], b, m_base, n0, n16, kq, a.t.out_off + 1, mode);
 
   if (a.stat_part) {                                 // BatchNorm statistics of the output on the way, as in conv_pipe.hip
-    double* red = reinterpret_cast<double*>(smem);
-    const int n = n_base + i32;
-    const float bias = a.bias ? a.bias[n] : 0.f;
-    double s1 = 0.0, s2 = 0.0;
+    double* red = reinterpret_cast<double*>(smem);   // (every wave is past the loop's last barrier and the DMA is drained: the stages are free)
 #pragma unroll
-    for (int ph = 0; ph < 2; ++ph)
+    for (int ct = 0; ct < 4; ++ct) {
+      const float bias = a.bias ? a.bias[n0 + ct * 16 + n16] : 0.f;
+      double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 2 * (m_base + (r & 3) + 8 * (r >> 2) + 4 * h) + ph;
-        if (row < a.M) {
-          const double v = (double)(out[ph][0][0][r] + bias);
-          s1 += v; s2 += v * v;
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 2 * (m_base + 4 * kq + r) + ph;
+          if (row < a.M) {
+            const double v = (double)(out[ph][ct][r] + bias);
+            s1 += v; s2 += v * v;
+          }
         }
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (kq == 0) {
+        const int slot = (wave * TN + ct * 16 + n16) * 2;
+        red[slot] = s1; red[slot + 1] = s2;
       }
-    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-    if (h == 0) {
-      const int slot = (wm * TN + wn * 32 + i32) * 2;
-      red[slot] = s1; red[slot + 1] = s2;
     }
     __syncthreads();
     if (tid < TN) {
@@ -365,14 +373,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (64 * WAVES_M * WAVES_N > 2
 #endif
 }
 
-template <int WAVES_M, int WAVES_N, int ABL = 0>
+template <int WAVES_M, int ABL = 0>
 static int launch_conv_wino(const ConvArgs& a, const float* U, int off0, hipStream_t s) {
-  constexpr int TT = WAVES_M * 32, TN = WAVES_N * 32;
+  constexpr int TT = WAVES_M * 16, TN = 64;
   constexpr size_t lds = 3 * sizeof(float) * ((size_t)2 * (TT + 2) * 8 + (size_t)6 * 8 * TN);
   static_assert(lds <= 160 * 1024, "stages too large");
   if (lds > 64 * 1024) {
     static unsigned long long lds_done = 0;
-    allow_big_lds((const void*)conv_wino_kernel<WAVES_M, WAVES_N, ABL>, &lds_done);
+    allow_big_lds((const void*)conv_wino_kernel<WAVES_M, ABL>, &lds_done);
   }
   const int tiles = (a.M + 1) / 2;
   const int m_tiles = (tiles + TT - 1) / TT, n_tiles = a.Cout / TN;
@@ -388,9 +396,9 @@ static int launch_conv_wino(const ConvArgs& a, const float* U, int off0, hipStre
     if (pn >= 0 && ng <= 8 && (ng & (ng - 1)) == 0) patch = __builtin_ctz(ng) | (pn << 8);
   }
   prof_begin(s);
-  hipLaunchKernelGGL((conv_wino_kernel<WAVES_M, WAVES_N, ABL>), dim3((unsigned)blocks), dim3(64 * WAVES_M * WAVES_N), lds, s, a, U, off0, m_tiles, n_tiles, patch);
-  // flop = the ALGORITHMIC count of the convolution (10 multiplies per output pair and channel pair); the kernel executes 0.6 of it
-  prof_end(s, 2.0 * a.B * (double)a.M * 5 * a.Cin * a.Cout, 5, 4.0 * ((double)a.B * a.Lin * a.Cin + 5.0 * a.Cin * a.Cout + (double)a.B * a.M * a.Cout));
+  hipLaunchKernelGGL((conv_wino_kernel<WAVES_M, ABL>), dim3((unsigned)blocks), dim3(64 * WAVES_M), lds, s, a, U, off0, m_tiles, n_tiles, patch);
+  // flop = what the kernel EXECUTES on the matrix pipe: 6 multiplies per output pair and channel pair, 0.6 of the convolution's algorithmic count
+  prof_end(s, 0.6 * 2.0 * a.B * (double)a.M * 5 * a.Cin * a.Cout, 5, 4.0 * ((double)a.B * a.Lin * a.Cin + 5.0 * a.Cin * a.Cout + (double)a.B * a.M * a.Cout));
   int rc = check_launch("conv_wino");
   if (rc || !a.stat_part) return rc;
   *a.stat_done = 1;
@@ -430,30 +438,27 @@ int conv_wino_run(const ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s) {
   WinoTaps t;
   for (int j = 0; j < 5; ++j) t.wq[a.t.off[j] - minoff] = a.t.widx[j];
   const size_t cc = (size_t)a.Cin * a.Cout;
-  hipLaunchKernelGGL(wino_u_kernel, dim3(cdiv(cc, 256)), dim3(256), 0, s, a.w, (float*)ws, cc, t);
+  hipLaunchKernelGGL(wino_u_kernel, dim3(cdiv(cc, 256)), dim3(256), 0, s, a.w, (float*)ws, a.Cin, a.Cout, t);
   int rc = check_launch("wino_u");
   if (rc) return rc;
-  const int tiles = (a.M + 1) / 2;
-  static const int force = getenv("GN_WINO_TILE") ? atoi(getenv("GN_WINO_TILE")) : 0;      // A/B switch: 1 = 2x2 waves, 2 = 4x2, 3 = 4x1... (development)
+  const float* Up = (const float*)ws;
 #ifdef GN_ABLATION
   {
     static const int abl = getenv("GN_WINO_ABL") ? atoi(getenv("GN_WINO_ABL")) : 0;
-    const float* Up = (const float*)ws;
     switch (abl) {
-      case 1: return launch_conv_wino<2, 2, 1>(a, Up, minoff, s);
-      case 2: return launch_conv_wino<2, 2, 2>(a, Up, minoff, s);
-      case 3: return launch_conv_wino<2, 2, 3>(a, Up, minoff, s);
-      case 4: return launch_conv_wino<2, 2, 4>(a, Up, minoff, s);
-      case 5: return launch_conv_wino<2, 2, 5>(a, Up, minoff, s);
-      case 7: return launch_conv_wino<2, 2, 7>(a, Up, minoff, s);
-      case 8: return launch_conv_wino<2, 2, 8>(a, Up, minoff, s);
-      case 15: return launch_conv_wino<2, 2, 15>(a, Up, minoff, s);
+      case 1: return launch_conv_wino<4, 1>(a, Up, minoff, s);
+      case 2: return launch_conv_wino<4, 2>(a, Up, minoff, s);
+      case 3: return launch_conv_wino<4, 3>(a, Up, minoff, s);
+      case 4: return launch_conv_wino<4, 4>(a, Up, minoff, s);
+      case 8: return launch_conv_wino<4, 8>(a, Up, minoff, s);
+      case 15: return launch_conv_wino<4, 15>(a, Up, minoff, s);
       default: break;
     }
   }
 #endif
-  if (force == 1 || (force == 0 && tiles < 128)) return launch_conv_wino<2, 2>(a, (const float*)ws, minoff, s);
-  return launch_conv_wino<4, 2>(a, (const float*)ws, minoff, s);
+  static const int force = getenv("GN_WINO_TILE") ? atoi(getenv("GN_WINO_TILE")) : 0;      // A/B switch (development): waves per block
+  if (force == 8) return launch_conv_wino<8>(a, Up, minoff, s);
+  return launch_conv_wino<4>(a, Up, minoff, s);
 }
 
 }  // namespace gn

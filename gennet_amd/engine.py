@@ -37,8 +37,9 @@ def device():
         idx = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(idx)
         _DEVICE = torch.device('cuda', idx)
-        if os.environ.get('GENNET_CONV_MATH', 'fp32') != 'fp32':       # opt-in experiment (ops.set_conv_math); default: exact fp32
-            ops.set_conv_math(os.environ['GENNET_CONV_MATH'], float(os.environ.get('GENNET_CONV_WS_GB', '7')), _DEVICE)
+        # conv arithmetic (ops.set_conv_math): transform-domain fp32 for the unit-stride 5-tap layers by default; GENNET_CONV_MATH=fp32 keeps every
+        # launch on the direct kernels, =bf16x3 is the opt-in operand-split experiment
+        ops.set_conv_math(ops.default_conv_math(), float(os.environ.get('GENNET_CONV_WS_GB', '7')), _DEVICE)
     return _DEVICE
 
 

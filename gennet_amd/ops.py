@@ -289,19 +289,38 @@ def conv_fold_bn(w, b, scale, shift):
 _CONV_MATH_WS = [None]
 
 
-def set_conv_math(mode='fp32', workspace_gb=7.0, device=None):
-    """'fp32' (default): exact-fp32 MFMA everywhere.  'bf16x3': opt-in -- the Conv1D forward, data-gradient and weight-gradient launches with at least
-    256 channels on either side run on the bf16 matrix cores with 3-way split operands (csrc/conv_bf16x3.hip, csrc/wgrad_bf16x3.hip; fp32-grade results,
-    see tests/test_bf16x3_gpu.py).  workspace_gb must hold the split operands of the largest such launch -- 6 * (B * (L + 2) * Cin + k * Cin * Cout) bytes
-    for a forward / data gradient, 6 * B * ceil(Lout / 32) * (40 * stride * Cin + 32 * Cout) for a weight gradient; a launch that does not fit runs on
-    the exact kernel."""
+def default_conv_math():
+    """What the engine sets at start-up: GENNET_CONV_MATH, 'wino' when unset."""
+    import os
+    return os.environ.get('GENNET_CONV_MATH', 'wino')
+
+
+WINO_WS_BYTES = 64 << 20       # transformed kernel of one launch: 6 * Cin * Cout * 4 bytes (25 MB for the generator's 512 -> 1024 layer)
+
+
+def set_conv_math(mode=None, workspace_gb=7.0, device=None):
+    """How the MFMA convolutions compute (process-wide, csrc/capi.hip conv_dispatch):
+    'wino' (the engine's default): the unit-stride 5-tap Conv1D forward / data-gradient launches with Cin >= 32, Cin % 8 == 0 and Cout % 64 == 0 run in the
+        transform domain (Cook-Toom F(2,5), csrc/conv_wino.hip: 6 fp32 multiplies per two outputs instead of 10, every product an exact fp32 fma on the fp32
+        matrix instruction); everything else on the direct kernels.  Chosen by the layer's shape alone (never the batch size).
+    'fp32': the direct exact-fp32 MFMA kernels everywhere (results bit-identical to a k-ordered fmaf chain).
+    'bf16x3': opt-in experiment -- the launches with at least 256 channels on either side run on the bf16 matrix cores with 3-way split operands
+        (csrc/conv_bf16x3.hip, csrc/wgrad_bf16x3.hip); workspace_gb must hold the split operands of the largest such launch."""
+    dev = device or torch.device('cuda', torch.cuda.current_device())
+    if mode is None:
+        mode = default_conv_math()
     if mode == 'fp32':
         _lib.call('gn_set_conv_math', 0, None, 0)
         _CONV_MATH_WS[0] = None
         return
+    if mode == 'wino':
+        ws = torch.empty(WINO_WS_BYTES, dtype=torch.uint8, device=dev)
+        _lib.call('gn_set_conv_math', 2, _p(ws), ws.numel())
+        _CONV_MATH_WS[0] = ws
+        return
     if mode != 'bf16x3':
-        raise ValueError('conv math %r (fp32 | bf16x3)' % (mode,))
-    ws = torch.empty(int(workspace_gb * (1 << 30)), dtype=torch.uint8, device=device or torch.device('cuda', torch.cuda.current_device()))
+        raise ValueError('conv math %r (wino | fp32 | bf16x3)' % (mode,))
+    ws = torch.empty(int(workspace_gb * (1 << 30)), dtype=torch.uint8, device=dev)
     _lib.call('gn_set_conv_math', 1, _p(ws), ws.numel())
     _CONV_MATH_WS[0] = ws
 

@@ -103,7 +103,7 @@ def _s2_dgrad(B, L, Cin, Cout, padding):
         got = ops.conv1d_dgrad(dyt, wt, L, 2, pl).cpu().numpy()
         used = ops.prof_collect(2)['launches']
     finally:
-        ops.set_conv_math('fp32')
+        ops.set_conv_math()
         ops.prof_enable(False)
     return got, used, exact, ref
 
@@ -169,7 +169,7 @@ def test_weight_gradient_under_the_opt_in_split(B, L, Cin, Cout, padding, stride
         dw, db = dw.cpu().numpy(), db.cpu().numpy()
         used = ops.prof_collect(2)['launches']
     finally:
-        ops.set_conv_math('fp32')
+        ops.set_conv_math()
         ops.prof_enable(False)
     assert used == 1, used
     scale = np.abs(ref).max()
@@ -215,7 +215,7 @@ def test_gan_iteration_under_the_opt_in_split_meets_the_fp32_path_tolerances():
             assert np.abs(gq - gr).max() <= 3e-4 * np.abs(gr).max() + 1e-6 * gmax, (k, T.rel(gq, gr))
         used = ops.prof_collect(2)['launches']
     finally:
-        ops.set_conv_math('fp32')
+        ops.set_conv_math()
         ops.prof_enable(False)
     assert used >= 4, used              # predict (2 layers) + train forward (2) + data gradients: the split kernels really ran
 
@@ -272,7 +272,7 @@ def test_discriminator_step_under_the_opt_in_split_meets_the_fp32_path_tolerance
             assert T.rel(gq, gr) < 2e-4
         used = ops.prof_collect(2)['launches']
     finally:
-        ops.set_conv_math('fp32')
+        ops.set_conv_math()
         ops.prof_enable(False)
     assert used >= 1, used              # the stride-2 forward really ran on the split kernel
 
@@ -307,7 +307,7 @@ def test_random_shapes_under_the_opt_in_split_agree_with_the_exact_kernels():
             got = [t.cpu().numpy().astype(np.float64) for t in run()]
             taken += ops.prof_collect(2)['launches']
         finally:
-            ops.set_conv_math('fp32')
+            ops.set_conv_math()
             ops.prof_enable(False)
         for name, g_, e_ in zip(('fwd', 'dgrad', 'wgrad'), got, exact):
             scale = max(np.abs(e_).max(), 1e-30)
@@ -342,5 +342,5 @@ def test_split_kernels_are_deterministic_at_bench_like_sizes(stride):
                     assert torch.equal(t, f), (rep, name, float((t - f).abs().max()))
         assert ops.prof_collect(2)['launches'] == 15
     finally:
-        ops.set_conv_math('fp32')
+        ops.set_conv_math()
         ops.prof_enable(False)

@@ -458,3 +458,47 @@ def test_every_profile_the_readme_lists_is_committed():
     assert len(names) > 40
     missing = sorted(n for n in names if not os.path.exists(os.path.join(ROOT, 'profiles', n)))
     assert not missing, missing
+
+
+def test_opt_in_leg_is_a_child_that_cannot_cost_the_headline():
+    """bench.py --opt-in (VERDICT r4 #4 / ADVICE r4): the experimental leg runs in a child process AFTER the headline line has been printed; a child that
+    fails, prints garbage or hangs comes back as an error string."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    env = dict(os.environ)
+    r = bench.run_opt_in_child([sys.executable, '-c', 'import sys; sys.stderr.write("boom\\n"); sys.exit(3)'], env, 30)
+    assert 'error' in r and 'code 3' in r['error'] and 'boom' in r['error']
+    r = bench.run_opt_in_child([sys.executable, '-c', 'import time; time.sleep(30)'], env, 1)
+    assert 'error' in r and 'killed' in r['error']
+    r = bench.run_opt_in_child([sys.executable, '-c', 'print("not json")'], env, 30)
+    assert 'error' in r
+    r = bench.run_opt_in_child(['/nonexistent/binary'], env, 5)
+    assert 'error' in r
+    r = bench.run_opt_in_child([sys.executable, '-c', 'print("noise"); print(\'{"value": 2.5, "unit": "waveforms/s"}\')'], env, 30)
+    assert r == {'value': 2.5, 'unit': 'waveforms/s'}
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert src.index("print(json.dumps(out), flush=True)") < src.index("child = run_opt_in_child(")      # the line is out before the child starts
+    assert 'set_conv_math(' not in src                                                                      # no experimental kernels in the bench process
+
+
+def test_pmc_traffic_file_is_refused_when_its_launch_mix_is_not_the_runs(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed PMC file; a file from another kernel generation (different ratio of direct to transform-domain
+    conv launches) must give traffic: null and a note, not a stale number (VERDICT r4 weak #10)."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    ks = {'void gn::conv_mfma_pipe_kernel<4, 1, 5, 2>(gn::ConvArgs, int, int, int)': {'launches': 80, 'hbm_bytes_per_launch': 3.0e9},
+          'void gn::conv_wino_kernel<4, 0>(gn::ConvArgs, float const*, int, int, int, int)': {'launches': 40, 'hbm_bytes_per_launch': 2.0e9},
+          'gn::adam_kernel': {'launches': 16, 'hbm_bytes_per_launch': 1.0e8}}
+    json.dump({'kernels': ks}, open(str(prof / 'r05_pmc_traffic.json'), 'w'))
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    t, src, why = bench.pmc_traffic_per_launch((160, 80))            # same 2 : 1 mix, other step count
+    assert why is None and src == 'profiles/r05_pmc_traffic.json' and abs(t - (80 * 3.0e9 + 40 * 2.0e9) / 120) < 1.0
+    t, src, why = bench.pmc_traffic_per_launch((244, 0))             # a run without the transform-domain kernel: not this file's mix
+    assert t is None and 'launch mix' in why
+    t, src, why = bench.pmc_traffic_per_launch((0, 0))
+    assert t is None

@@ -49,7 +49,7 @@ def _conv_math(mode):
         yield
         assert ops.prof_collect(2)['launches'] > 0          # the split kernels really ran
     finally:
-        ops.set_conv_math('fp32')
+        ops.set_conv_math()
         ops.prof_enable(False)
 
 
