@@ -325,6 +325,19 @@ def set_conv_math(mode=None, workspace_gb=7.0, device=None):
     _CONV_MATH_WS[0] = ws
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def conv_math(mode):
+    """`with ops.conv_math('fp32'):` -- the given conv arithmetic for the duration of the block, the process default (default_conv_math) afterwards."""
+    set_conv_math(mode)
+    try:
+        yield
+    finally:
+        set_conv_math()
+
+
 def prelu_fwd(x, alpha):
     """x (B, ...), alpha with the shape of one sample."""
     _chk(x, alpha)

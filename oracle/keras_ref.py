@@ -279,16 +279,43 @@ def dropout_fwd(x, mask, rate):
 # ----------------------------------------------------------------------------------------------
 # losses / metrics  
 # ----------------------------------------------------------------------------------------------
-def bce_loss(p, y):
-    """keras binary_crossentropy (TF backend, from probabilities). p,y: (B,1). Returns (loss, dL/dp)."""
+SAT_BAND = 1e-4        # min(p, 1 - p) below this: the sample is in the regime where fp32 cannot represent 1 - p to more than a few bits
+
+
+def bce_loss(p, y, p_impl=None):
+    """keras binary_crossentropy (TF backend, from probabilities). p,y: (B,1). Returns (loss, dL/dp).
+
+    p_impl (optional, (B,1) float32): the probabilities the fp32 implementation under test produced.  TF evaluates this loss in the tensor dtype,
+    float32: for a sample the discriminator has (nearly) saturated, 1 - p has one or two significant bits there, the clip bound 1 - 1e-7 is ONE fp32
+    step below 1, and dL/dp = (sigma(z) - y) / (p (1 - p)) is what fp32 makes of it -- an fp64 evaluation of the same expression differs from it by tens
+    of per cent, in a quantity Adam then normalises to a full step.  Like the branch of a ReLU at its kink (nets_ref.Stack.forward `decisions`), that
+    is not something a higher-precision oracle can decide: for the samples with min(p, 1 - p) < SAT_BAND the loss term and its gradient are evaluated
+    in float32 AT the implementation's p, after checking that this p is the oracle's to two fp32 steps; all other samples stay fp64.
+    self-check result in bce_loss.last = (samples in the saturated band, largest |p_impl - p| among them in units of 2^-24)."""
     B = p.shape[0]
     pc = np.clip(p, CLIP_LO, CLIP_HI)
     z = np.log(pc / (1 - pc))
     per = np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z)))
-    loss = per.mean(axis=-1).mean()
     inside = (p >= CLIP_LO) & (p <= CLIP_HI)
     dz = (1.0 / (1.0 + np.exp(-z)) - y) / (B * p.shape[-1])
     dp = np.where(inside, dz / (pc * (1 - pc)), 0.0)
+    bce_loss.last = (0, 0.0)
+    if p_impl is not None:
+        sat = np.minimum(p, 1 - p) < SAT_BAND
+        if sat.any():
+            p32 = np.asarray(p_impl, np.float32).reshape(p.shape)
+            y32 = np.asarray(y, np.float32).reshape(p.shape)
+            bce_loss.last = (int(sat.sum()), float(np.abs(p32.astype(np.float64) - p)[sat].max() / 2.0 ** -24))
+            one, eps = np.float32(1.0), np.float32(K_EPS)
+            pc32 = np.minimum(np.maximum(p32, eps), one - eps)
+            z32 = np.log(pc32 / (one - pc32))
+            per32 = np.maximum(z32, np.float32(0)) - z32 * y32 + np.log1p(np.exp(-np.abs(z32)))
+            sg32 = one / (one + np.exp(-z32))
+            in32 = (p32 >= eps) & (p32 <= one - eps)
+            dp32 = np.where(in32, (sg32 - y32) / (pc32 * (one - pc32)) / np.float32(B * p.shape[-1]), np.float32(0))
+            per = np.where(sat, per32.astype(np.float64), per)
+            dp = np.where(sat, dp32.astype(np.float64), dp)
+    loss = per.mean(axis=-1).mean()
     return loss, dp
 
 

@@ -81,10 +81,10 @@ def run_gpu(out, backend='gloo'):
     from gennet_amd.layers import Dropout
     dp = dist.init(backend, allow_single=(backend == 'nccl'))
     rank, world = (dp.rank, dp.world_size) if dp else (0, 1)
-    engine.set_init_seed(3)
+    engine.set_init_seed(3 + int(os.environ.get('GN_TEST_SEED', '0')))
     n_pix, B = 64, 8
     lo, hi = rank * B // world, (rank + 1) * B // world
-    rng = np.random.RandomState(11)
+    rng = np.random.RandomState(11 + int(os.environ.get('GN_TEST_SEED', '0')))
     event = f32(rng.randn(n_pix, 1))
     nets = bbh.build_and_compile(event, n_pix, data_parallel=dp)
     G, D, DG, PE = nets.generator, nets.signal_discriminator, nets.signal_discriminator_on_generator, nets.signal_pe

@@ -189,8 +189,15 @@ def test_wgrad_split_k_reduction_inside_the_kernel_is_bit_identical_to_the_reduc
 
 
 def test_conv1d_mfma_exact_integers():
-    """A = small integers, B asymmetric integers: fp32 MFMA must be bit-exact (catches row/col swaps, tap mix-ups)."""
+    """A = small integers, B asymmetric integers: fp32 MFMA must be bit-exact (catches row/col swaps, tap mix-ups).  This is a statement about the
+    DIRECT kernels (a k-ordered fmaf chain of integers is exact); the transform-domain kernel multiplies by G's sixths and fifteenths and is checked
+    against the oracle in tests/test_wino_gpu.py, so the unit-stride case runs with the direct kernels switched in."""
     from gennet_amd import ops
+    with ops.conv_math('fp32'):
+        _exact_integers(ops)
+
+
+def _exact_integers(ops):
     rng = np.random.RandomState(7)
     B, L, Cin, Cout, k = 2, 140, 32, 128, 5
     x = rng.randint(-3, 4, (B, L, Cin)).astype(np.float64)

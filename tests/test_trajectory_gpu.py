@@ -12,6 +12,8 @@ removes it again from everything downstream, which the loss / predict / statisti
 """
 import contextlib
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -65,13 +67,15 @@ def test_gan_100_iterations_follow_the_oracle(n_pix, B, iters, math):
 def _gan_iterations(n_pix, B, iters):
     from gennet_amd import bbh
     from gennet_amd.engine import to_device
-    rng = np.random.RandomState(31)
+    rng = np.random.RandomState(31 + int(os.environ.get('GN_TEST_SEED', '0')))
     ref, nets, event = _build_gan(n_pix, rng)
     ev_dev = to_device(event.reshape(-1))
     G, D, DG = nets.generator, nets.signal_discriminator, nets.signal_discriminator_on_generator
     bank = f32(rng.randn(64, n_pix))
     worst = {'sd': 0.0, 'sg': 0.0, 'fake': 0.0}
     flips = 0
+    saturated = 0
+    p_layer = [l for l in D.layers if l.weights][-1].name          # Dense(1) with its sigmoid in the epilogue: the captured output is the probability
     for it in range(iters):
         # ---- discriminator step on [real | fake] (:1243-1292)
         rows = rng.choice(64, B, replace=False)
@@ -90,7 +94,10 @@ def _gan_iterations(n_pix, B, iters):
         d_masks = stack_masks(ref.D, sX_ref, rng)
         cap = {}
         out = D.train_on_batch(sX, sy, dropout_masks=masks_by_name(ref.D, d_masks, D.layers), capture=cap)
-        out_ref = ref.d_train_on_batch(sX_ref, sy, d_masks, decisions_for(ref.D, D.layers, cap))
+        # a sample the discriminator has saturated: the oracle evaluates its loss term at the GPU's own fp32 probability (K.bce_loss), after checking it
+        out_ref = ref.d_train_on_batch(sX_ref, sy, d_masks, decisions_for(ref.D, D.layers, cap), p_impl=cap[p_layer].detach().cpu().numpy())
+        assert ref.bce_sat[1] <= 4.0, (it, ref.bce_sat)
+        saturated += ref.bce_sat[0]
         flips += assert_decisions_consistent(ref.D)
         e = abs(out[0] - out_ref[0]) / abs(out_ref[0])
         worst['sd'] = max(worst['sd'], e)
@@ -103,7 +110,9 @@ def _gan_iterations(n_pix, B, iters):
         d_before = [p.data.clone() for l in D.layers for p in l.params]
         cap = {}
         out = DG.train_on_batch(z2, [1] * B, dropout_masks=names, capture=cap)
-        out_ref = ref.g_train_on_batch(z2, [1] * B, g_masks, d_masks2, decisions_for(ref.D, D.layers, cap))
+        out_ref = ref.g_train_on_batch(z2, [1] * B, g_masks, d_masks2, decisions_for(ref.D, D.layers, cap), p_impl=cap[p_layer].detach().cpu().numpy())
+        assert ref.bce_sat[1] <= 4.0, (it, ref.bce_sat)
+        saturated += ref.bce_sat[0]
         del cap
         flips += assert_decisions_consistent(ref.D)
         e = abs(out[0] - out_ref[0]) / abs(out_ref[0])
@@ -111,8 +120,8 @@ def _gan_iterations(n_pix, B, iters):
         assert e <= 1e-4 and out[1] == pytest.approx(out_ref[1]), (it, out, out_ref)
         for a, b in zip(d_before, [p.data for l in D.layers for p in l.params]):
             assert torch.equal(a, b)                                  # D frozen as of compile time, at every one of the 100 generator updates
-    print('GAN trajectory, %d iterations: worst relative error sd_loss %.2e, sg_loss %.2e, generator.predict %.2e; %d in-band LeakyReLU flips injected'
-          % (iters, worst['sd'], worst['sg'], worst['fake'], flips))
+    print('GAN trajectory, %d iterations: worst relative error sd_loss %.2e, sg_loss %.2e, generator.predict %.2e; %d in-band LeakyReLU flips injected; '
+          '%d loss terms evaluated at the saturated-sample precision' % (iters, worst['sd'], worst['sg'], worst['fake'], flips, saturated))
     assert DG.optimizer.iterations == iters and D.optimizer.iterations == iters and ref.opt_g.t == iters and ref.opt_d.t == iters
     # ---- end state: weights, moving statistics, predict
     for st, model in ((ref.G, G), (ref.D, D)):

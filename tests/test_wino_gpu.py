@@ -1,0 +1,201 @@
+"""GPU parity of the transform-domain fp32 convolution (csrc/conv_wino.hip: Cook-Toom F(2,5) for the unit-stride 5-tap layers of
+generator_model bbhMahoGANy.py:259-283 and of signal_pe_model's q branch :382-386) against the fp64 oracle and against the direct kernels.
+
+Bounds: the kernels' own 2e-5 of the largest oracle entry (tests/test_kernels_gpu.py RTOL), AND the gate of VERDICT r4 item 2 -- the error
+against fp64 may not exceed 4 x the direct k-ordered fp32 chain's on the same operands (measured 1.2-1.8 x; profiles/r05_winograd_gate1.txt).
+Everything goes through the C ABI (gn_conv1d_fwd*, gn_conv1d_dgrad*, gn_set_conv_math); the engine's default conv math is 'wino'.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import keras_ref as K
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5
+
+
+def g(a, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=torch.device('cuda:0'))
+
+
+def f32(a):
+    return np.asarray(a, np.float32).astype(np.float64)
+
+
+def errs(t, ref):
+    a = t.detach().cpu().numpy().astype(np.float64)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    d = np.abs(a - ref)
+    return d.max() / max(np.abs(ref).max(), 1e-30), np.sqrt(np.mean(d ** 2)) / max(np.sqrt(np.mean(ref ** 2)), 1e-30)
+
+
+def launches(kind):
+    from gennet_amd import ops
+    return ops.prof_collect(kind)['launches']
+
+
+WINO_CASES = [
+    # B, L, Cin, Cout, padding, act
+    (2, 64, 64, 64, 'same', 'linear'),          # one block of tiles
+    (3, 130, 128, 256, 'same', 'tanh'),         # ragged row tiles (65 output pairs), four column tiles
+    (2, 257, 64, 128, 'valid', 'relu'),         # odd output length: the last output pair has one row
+    (5, 37, 32, 64, 'same', 'leaky'),           # the smallest channel count the dispatcher sends here, odd lengths
+    (1, 1, 64, 64, 'same', 'linear'),           # a single output row
+    (2, 5, 40, 192, 'valid', 'linear'),         # one output row per element, Cin = 5 chunks, three column tiles
+    (1, 2048, 512, 1024, 'same', 'linear'),     # the generator's largest layer (bbhMahoGANy.py:279), one element
+    (2, 2044, 128, 256, 'valid', 'relu'),       # the q branch's Conv1D(256, 5) (:384)
+    (1, 300, 1024, 64, 'same', 'linear'),       # 128 channel chunks
+]
+
+
+@pytest.mark.parametrize("B,L,Cin,Cout,padding,act", WINO_CASES)
+def test_forward_against_oracle_and_direct_kernel(B, L, Cin, Cout, padding, act):
+    from gennet_amd import ops
+    rng = np.random.RandomState(B * 1000 + L)
+    x = f32(np.tanh(rng.randn(B, L, Cin)) * (rng.rand(B, L, Cin) > 0.2) / 0.8)          # what the generator's layers see: tanh outputs through Dropout(0.2)
+    lim = np.sqrt(6.0 / (5 * (Cin + Cout)))
+    w = f32(rng.uniform(-lim, lim, (5, Cin, Cout))); b = f32(rng.randn(Cout) * 0.1)
+    Lout, pl = ops.conv_geometry(L, 5, 1, padding)
+    ref = K.act_fwd(K.conv1d_fwd(x, w, b, 1, padding), act, 0.2)
+    ops.prof_enable(True); ops.prof_reset()
+    try:
+        with ops.conv_math('wino'):
+            yw = ops.conv1d_fwd(g(x), g(w), g(b), 1, pl, Lout, act, 0.2)
+            assert launches(5) == 1 and launches(0) == 0                              # the transform-domain kernel really took it
+            yw_direct_entry = ops.conv1d_fwd_wino(g(x), g(w), g(b), pl, Lout, act, 0.2)
+        with ops.conv_math('fp32'):
+            yd = ops.conv1d_fwd(g(x), g(w), g(b), 1, pl, Lout, act, 0.2)
+            assert launches(0) == 1
+    finally:
+        ops.prof_enable(False)
+    assert torch.equal(yw, yw_direct_entry)
+    mw, rw = errs(yw, ref); md, rd = errs(yd, ref)
+    assert mw <= RTOL, (mw, md)
+    if Lout >= 16:                                                                    # (a handful of outputs is no sample of an rms)
+        assert rw <= 4.0 * rd + 1e-8, (rw, rd)                                        # the gate: not more than 4 x the direct chain's error
+
+
+def test_every_baseline_layer_shape_meets_the_gate():
+    """The five layers the default dispatch sends to the kernel at BASELINE size (n_pix 2048), two elements each; error ratio to the direct kernel recorded."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(3)
+    for name, L, Cin, Cout, padding in (('G 128->256', 2048, 128, 256, 'same'), ('G 256->512', 2048, 256, 512, 'same'), ('G 512->1024', 2048, 512, 1024, 'same'),
+                                        ('PE q 64->128', 2048, 64, 128, 'valid'), ('PE q 128->256', 2044, 128, 256, 'valid')):
+        x = f32(rng.randn(2, L, Cin)); lim = np.sqrt(6.0 / (5 * (Cin + Cout)))
+        w = f32(rng.uniform(-lim, lim, (5, Cin, Cout)))
+        Lout, pl = ops.conv_geometry(L, 5, 1, padding)
+        ref = K.conv1d_fwd(x, w, None, 1, padding)
+        with ops.conv_math('wino'):
+            yw = ops.conv1d_fwd(g(x), g(w), None, 1, pl, Lout)
+        with ops.conv_math('fp32'):
+            yd = ops.conv1d_fwd(g(x), g(w), None, 1, pl, Lout)
+        (mw, rw), (md, rd) = errs(yw, ref), errs(yd, ref)
+        print('%-14s transform-domain max %.2e rms %.2e | direct max %.2e rms %.2e | rms ratio %.2f' % (name, mw, rw, md, rd, rw / rd))
+        assert mw <= RTOL and rw <= 4.0 * rd
+
+
+@pytest.mark.parametrize("B,L,Cin,Cout,padding", [(3, 133, 64, 128, 'valid'), (2, 64, 128, 64, 'same'), (2, 301, 256, 128, 'same'), (1, 2040, 256, 128, 'valid')])
+def test_data_gradient_plain_and_fused(B, L, Cin, Cout, padding):
+    """dx of a unit-stride 5-tap layer = a 5-tap correlation of dy with the flipped, transposed kernel: the same kernel, taps in descending order; with the
+    producer's activation / dropout backward in the epilogue (gn_conv1d_dgrad_fused) as the engine launches it."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(L)
+    x = f32(rng.randn(B, L, Cin)); w = f32(rng.randn(5, Cin, Cout) * 0.05)
+    Lout, pl = ops.conv_geometry(L, 5, 1, padding)
+    dy = f32(rng.randn(B, Lout, Cout))
+    dx_ref, _, _ = K.conv1d_bwd(x, w, dy, 1, padding)
+    wt = ops.conv1d_transpose_w(g(w))
+    ops.prof_enable(True); ops.prof_reset()
+    try:
+        with ops.conv_math('wino'):
+            dxw = ops.conv1d_dgrad(g(dy), wt, L, 1, pl)
+            assert launches(5) == 1 and launches(0) == 0
+        with ops.conv_math('fp32'):
+            dxd = ops.conv1d_dgrad(g(dy), wt, L, 1, pl)
+    finally:
+        ops.prof_enable(False)
+    (mw, rw), (md, rd) = errs(dxw, dx_ref), errs(dxd, dx_ref)
+    assert mw <= RTOL and rw <= 4.0 * rd + 1e-8, (mw, rw, md, rd)
+    # fused: through relu (the q branch) and through LeakyReLU + Dropout(0.4) -- the producer's output y_prev and keep-mask
+    y_prev = f32(np.maximum(rng.randn(B, L, Cin), 0.0))
+    ref_relu = dx_ref * (y_prev > 0)
+    keep = (rng.rand(B, L, Cin) >= 0.4)
+    pre = f32(rng.randn(B, L, Cin))
+    y_leaky = f32(np.where(pre > 0, pre, np.float32(0.2) * pre) * keep / np.float32(0.6))
+    ref_leaky = dx_ref * np.where(pre > 0, 1.0, float(np.float32(0.2))) * keep / float(np.float32(0.6))
+    with ops.conv_math('wino'):
+        dx1 = ops.conv1d_dgrad(g(dy), wt, L, 1, pl, prev=(g(y_prev), 'relu', 0.0, None, 0.0))
+        dx2 = ops.conv1d_dgrad(g(dy), wt, L, 1, pl, prev=(g(y_leaky), 'leaky', 0.2, g(keep, torch.uint8), 0.4))
+    assert errs(dx1, ref_relu)[0] <= RTOL and errs(dx2, ref_leaky)[0] <= 2 * RTOL
+
+
+def test_fused_dropout_epilogue_and_batchnorm_statistics():
+    from gennet_amd import ops
+    rng = np.random.RandomState(9)
+    B, L, Cin, Cout = 3, 150, 64, 128
+    x = f32(rng.randn(B, L, Cin)); w = f32(rng.randn(5, Cin, Cout) * 0.05); b = f32(rng.randn(Cout))
+    Lout, pl = ops.conv_geometry(L, 5, 1, 'same')
+    pre = K.conv1d_fwd(x, w, b, 1, 'same')
+    keep = rng.rand(B, Lout, Cout) >= 0.4
+    ref = np.where(pre > 0, pre, float(np.float32(0.2)) * pre) * keep / float(np.float32(0.6))
+    ops.prof_enable(True); ops.prof_reset()
+    try:
+        with ops.conv_math('wino'):
+            y = ops.conv1d_fwd_dropout(g(x), g(w), g(b), g(keep, torch.uint8), 1, pl, Lout, 'leaky', 0.2, 0.4)
+            ys, sums = ops.conv1d_fwd_stats(g(x), g(w), g(b), 1, pl, Lout)
+            assert launches(5) == 2 and launches(0) == 0
+        with ops.conv_math('fp32'):
+            _, sums_d = ops.conv1d_fwd_stats(g(x), g(w), g(b), 1, pl, Lout)
+    finally:
+        ops.prof_enable(False)
+    assert errs(y, ref)[0] <= 2 * RTOL
+    assert errs(ys, pre)[0] <= RTOL
+    # the statistics are fp64 sums of the fp32 outputs the kernel wrote: exact up to fp64 summation order
+    yh = ys.cpu().numpy().astype(np.float64).reshape(-1, Cout)
+    s = sums.cpu().numpy()
+    assert np.allclose(s[:Cout], yh.sum(0), rtol=1e-12, atol=1e-9) and np.allclose(s[Cout:], (yh * yh).sum(0), rtol=1e-12)
+    assert np.allclose(s, sums_d.cpu().numpy(), rtol=1e-5, atol=1e-4)
+    # odd length: the statistics skip the row past the end of the last output pair
+    x2 = f32(rng.randn(2, 77, Cin))
+    Lo2, pl2 = ops.conv_geometry(77, 5, 1, 'same')
+    with ops.conv_math('wino'):
+        y2, s2 = ops.conv1d_fwd_stats(g(x2), g(w), g(b), 1, pl2, Lo2)
+    yh2 = y2.cpu().numpy().astype(np.float64).reshape(-1, Cout)
+    assert np.allclose(s2.cpu().numpy()[:Cout], yh2.sum(0), rtol=1e-12, atol=1e-9)
+
+
+def test_a_batch_and_its_chunks_agree_bit_for_bit_and_runs_repeat():
+    """The dispatcher chooses by the layer's shape alone: any batch size takes the same kernel with the same per-output arithmetic."""
+    from gennet_amd import ops
+    torch.manual_seed(0)
+    dev = torch.device('cuda:0')
+    with ops.conv_math('wino'):
+        for (B, L, Cin, Cout, pl, Lout) in [(8, 64, 64, 128, 0, 60), (6, 2048, 128, 256, 2, 2048), (64, 300, 256, 128, 2, 300)]:
+            x = torch.randn(B, L, Cin, device=dev); w = torch.randn(5, Cin, Cout, device=dev) * 0.05; b = torch.randn(Cout, device=dev)
+            y = ops.conv1d_fwd(x, w, b, 1, pl, Lout, 'relu')
+            h = B // 2
+            y2 = torch.cat([ops.conv1d_fwd(x[:h].contiguous(), w, b, 1, pl, Lout, 'relu'), ops.conv1d_fwd(x[h:].contiguous(), w, b, 1, pl, Lout, 'relu')])
+            assert torch.equal(y, y2) and torch.equal(y, ops.conv1d_fwd(x, w, b, 1, pl, Lout, 'relu'))
+
+
+def test_dispatch_leaves_everything_else_on_the_direct_kernels():
+    """Strided, 2-4-tap, narrow or ragged-channel launches never reach the transform-domain kernel; GENNET_CONV_MATH=fp32 / ops.set_conv_math('fp32') takes it out."""
+    from gennet_amd import ops
+    dev = torch.device('cuda:0')
+    ops.prof_enable(True)
+    try:
+        with ops.conv_math('wino'):
+            for (Cin, Cout, k, s) in [(64, 128, 5, 2), (64, 128, 3, 1), (16, 128, 5, 1), (64, 96, 5, 1), (36, 64, 5, 1)]:
+                ops.prof_reset()
+                L = 80
+                Lout, pl = ops.conv_geometry(L, k, s, 'same')
+                ops.conv1d_fwd(torch.randn(2, L, Cin, device=dev), torch.randn(k, Cin, Cout, device=dev), None, s, pl, Lout)
+                assert launches(5) == 0 and launches(0) == 1, (Cin, Cout, k, s)
+        with ops.conv_math('fp32'):
+            ops.prof_reset()
+            ops.conv1d_fwd(torch.randn(2, 80, 64, device=dev), torch.randn(5, 64, 128, device=dev), None, 1, 2, 80)
+            assert launches(5) == 0 and launches(0) == 1
+    finally:
+        ops.prof_enable(False)
