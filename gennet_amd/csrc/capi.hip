@@ -1,6 +1,7 @@
 // extern "C" surface of libgennet_hip.so (see include/gennet_hip.h).  Argument checking, tap-table construction and
 // kernel-family dispatch live here; no torch types, no allocation, no synchronisation.
 #include <stdarg.h>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 #include <stdlib.h>
@@ -410,8 +411,9 @@ static int dgrad_impl(const float* dy, const float* wt, float* dx, int B, int L,
 }
 
 size_t gn_conv1d_wgrad_workspace(int B, int L, int Cin, int Cout, int k, int stride, int Lout) {
-  (void)L; (void)stride;
+  (void)L;
   size_t w = (Cin <= 4 || Cout <= 4) ? wgrad_small_workspace_bytes(B, Lout, Cin, Cout, k) : wgrad_workspace_bytes(B, Lout, Cin, Cout, k);
+  if (k == 5 && stride == 1 && Cin % 64 == 0 && Cout % 64 == 0) w = std::max(w, wgrad_wino_workspace_bytes(B, Lout, Cin, Cout));      // six point slabs per split
   size_t b = bias_grad_ws((size_t)B * Lout, Cout);
   return (w > b ? w : b) + 256;
 }
@@ -434,6 +436,11 @@ int gn_conv1d_wgrad(const float* x, const float* dy, float* dw, float* db, void*
     a.B = B; a.Lin = L; a.Cin = Cin; a.Cout = Cout; a.M = Lout; a.ntaps = k; a.in_stride = stride;
     for (int j = 0; j < k; ++j) a.off[j] = j - pad_left;
     a.db = db;
+    if (g_conv_math == 2 && wgrad_wino_supported(a) && ws_bytes >= wgrad_wino_workspace_bytes(B, Lout, Cin, Cout)) {
+      rc = wgrad_wino_run(a, dw, ws_bytes, s);                 // transform-domain weight gradient; the bias gradient takes the separate pass below
+      if (rc) return rc;
+      return db ? bias_grad(dy, db, (size_t)B * Lout, Cout, ws, ws_bytes, s) : GN_OK;
+    }
     static const int min_cin = getenv("GN_BF16X3_MIN_CIN") ? atoi(getenv("GN_BF16X3_MIN_CIN")) : 256;
     static const int min_cout = getenv("GN_BF16X3_MIN_COUT") ? atoi(getenv("GN_BF16X3_MIN_COUT")) : 256;
     static const bool no_wgrad = getenv("GN_BF16X3_NO_WGRAD") != nullptr;           // A/B switch

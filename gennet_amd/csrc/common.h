@@ -142,6 +142,11 @@ int conv_bf16x3_run_merged(const ConvArgs& a, void* ws, hipStream_t s);
 size_t conv_wino_workspace_bytes(int Cin, int Cout);
 bool conv_wino_supported(const ConvArgs& a);
 int conv_wino_run(const ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s);
+// wgrad_wino.hip (the transposed form for the weight gradient of the same layers)
+void wgrad_split_plan(int B, int M, int Cin, int Cout, int TC, int TN, int* splits, int* chunks_per_split);      // conv_mfma.hip: K-chunks of 32 rows
+bool wgrad_wino_supported(const WgradArgs& a);
+size_t wgrad_wino_workspace_bytes(int B, int M, int Cin, int Cout);
+int wgrad_wino_run(WgradArgs& a, float* dw, size_t ws_bytes, hipStream_t s);
 // wgrad_bf16x3.hip (the same split for the weight gradient, opt-in)
 size_t wgrad_bf16x3_workspace_bytes(int B, int M, int Cin, int Cout, int in_stride);
 bool wgrad_bf16x3_supported(const WgradArgs& a);

@@ -691,7 +691,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
 // even one split per batch element leaves the chip idle (tiles * B < 256: the small layers at the script's own batch 8) are the elements cut
 // into ranges of at least 4 chunks, for about 512 blocks.  (Measured at batch 8, us per launch: G 128 -> 256 90 -> 54, PE q 128 -> 256 87 -> 51;
 // cutting layers that already had 256+ blocks was slower -- G 256 -> 512 99 -> 134 -- the extra partial slabs cost more than they buy.)
-static void wgrad_split_plan(int B, int M, int Cin, int Cout, int TC, int TN, int* splits, int* chunks_per_split) {
+void wgrad_split_plan(int B, int M, int Cin, int Cout, int TC, int TN, int* splits, int* chunks_per_split) {
   const int cpb = (M + 31) / 32;
   const int tiles = cdiv(Cin, TC) * cdiv(Cout, TN);
   // blocks per launch the K-splits aim at: two full rounds of the chip's 1024 block slots.  Measured (round 3, step in waveforms/s): 2048: 1437,

@@ -25,11 +25,9 @@
 #include <type_traits>
 #include "common.h"
 #include "conv_epilogue.h"
+#include "wino_common.h"
 
 namespace gn {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct WinoTaps {
   int wq[5];      // kernel index (into w's leading axis) of the tap at offset off0 + q
@@ -57,52 +55,6 @@ __global__ void wino_u_kernel(const float* __restrict__ w, float* __restrict__ U
   const size_t base = ((size_t)chunk * (Cout >> 6) + tile) * 3072 + ((cth * 4 + kq) * 16 + n16) * 4 + ctl * 2 + s;
 #pragma unroll
   for (int p = 0; p < 6; ++p) U[base + p * 512] = u[p];
-}
-
-// ---------------------------------------------------------------------------------------------
-// BT of F(2,5) on {0, 1, -1, 1/2, -2, inf}, rows scaled to integers (the inverse factors sit in G above), on a channel PAIR per lane:
-//   a = d1 - d3, b = d2 - d4
-//   v0 = 2 d0 - 3 a - 4 d2 + 2 d4        v1 = -2 d1 + d2 + 5 d3 + 2 d4       v2 = -2 d1 + 5 d2 - d3 - 2 d4
-//   v3 = 2 a + b                         v4 = a - 2 b                        v5 = 2 d5 + 2 a - 2 d3 - 3 b
-// 18 packed instructions, written as asm: hipcc moves plain fma code away from the MFMA slots it is meant to sit between.  3 and 5 are not inline
-// constants: SGPR pairs.  Piece K of wino_piece is one instruction; the order interleaves the six dependency chains.
-// ---------------------------------------------------------------------------------------------
-struct WinoT {
-  f32x2 a, b;
-};
-#define GN_PK_SUB(o, x, y) asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=&v"(o) : "v"(x), "v"(y))
-#define GN_PK_DBL(o, x) asm volatile("v_pk_add_f32 %0, %1, %1" : "=&v"(o) : "v"(x))
-#define GN_PK_FMA_NEW(o, x, c, z) asm volatile("v_pk_fma_f32 %0, %1, " c ", %2 op_sel_hi:[1,0,1]" : "=&v"(o) : "v"(x), "v"(z))
-#define GN_PK_FMA_NEWNEG(o, x, c, z) asm volatile("v_pk_fma_f32 %0, %1, " c ", %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=&v"(o) : "v"(x), "v"(z))
-#define GN_PK_FMA_ACC(o, x, c) asm volatile("v_pk_fma_f32 %0, %1, " c ", %0 op_sel_hi:[1,0,1]" : "+v"(o) : "v"(x))
-#define GN_PK_FMA_ACCS(o, x, k) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(o) : "v"(x), "s"(k))
-template <int K>
-__device__ __forceinline__ void wino_piece(const f32x2 (&d)[6], f32x2 (&v)[6], WinoT& t, unsigned long long k5, unsigned long long km3) {
-  if constexpr (K == 0) GN_PK_SUB(t.a, d[1], d[3]);
-  else if constexpr (K == 1) GN_PK_SUB(t.b, d[2], d[4]);
-  else if constexpr (K == 2) GN_PK_FMA_NEW(v[1], d[4], "2.0", d[2]);
-  else if constexpr (K == 3) GN_PK_FMA_NEWNEG(v[2], d[4], "-2.0", d[3]);
-  else if constexpr (K == 4) GN_PK_DBL(v[0], d[0]);
-  else if constexpr (K == 5) GN_PK_DBL(v[5], d[5]);
-  else if constexpr (K == 6) GN_PK_FMA_NEW(v[3], t.a, "2.0", t.b);
-  else if constexpr (K == 7) GN_PK_FMA_NEW(v[4], t.b, "-2.0", t.a);
-  else if constexpr (K == 8) GN_PK_FMA_ACCS(v[1], d[3], k5);
-  else if constexpr (K == 9) GN_PK_FMA_ACCS(v[2], d[2], k5);
-  else if constexpr (K == 10) GN_PK_FMA_ACCS(v[0], t.a, km3);
-  else if constexpr (K == 11) GN_PK_FMA_ACC(v[5], t.a, "2.0");
-  else if constexpr (K == 12) GN_PK_FMA_ACC(v[1], d[1], "-2.0");
-  else if constexpr (K == 13) GN_PK_FMA_ACC(v[2], d[1], "-2.0");
-  else if constexpr (K == 14) GN_PK_FMA_ACC(v[0], d[2], "-4.0");
-  else if constexpr (K == 15) GN_PK_FMA_ACC(v[5], d[3], "-2.0");
-  else if constexpr (K == 16) GN_PK_FMA_ACC(v[0], d[4], "2.0");
-  else GN_PK_FMA_ACCS(v[5], t.b, km3);
-}
-template <int K = 0>
-__device__ __forceinline__ void wino_bt_all(const f32x2 (&d)[6], f32x2 (&v)[6], WinoT& t, unsigned long long k5, unsigned long long km3) {
-  if constexpr (K < 18) {
-    wino_piece<K>(d, v, t, k5, km3);
-    wino_bt_all<K + 1>(d, v, t, k5, km3);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -50,7 +50,7 @@ def bench(B, L, Cin, Cout, reps=5):
     print('   speed-up %.3f' % (out['direct'] / out['wino']), flush=True)
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and '--wgrad' not in sys.argv:
     if '--abl' in sys.argv:        # timing only (ablation build: results are wrong)
         bench(512, 2048, 512, 1024)
         sys.exit(0)
@@ -62,3 +62,47 @@ if __name__ == '__main__':
         bench(512, 2048, 256, 512)
         bench(512, 2048, 128, 256)
         bench(256, 2048, 64, 128)
+
+
+def check_wgrad(B, L, Cin, Cout, padding, seed=0):
+    rng = np.random.RandomState(seed)
+    x = (np.tanh(rng.randn(B, L, Cin)) * (rng.rand(B, L, Cin) > 0.2) / 0.8).astype(np.float32)
+    Lout, pl = ops.conv_geometry(L, 5, 1, padding)
+    dy = rng.randn(B, Lout, Cout).astype(np.float32)
+    _, dw_ref, db_ref = K.conv1d_bwd(x.astype(np.float64), np.zeros((5, Cin, Cout)), dy.astype(np.float64), 1, padding)
+    xd, dyd = torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev)
+    with ops.conv_math('wino'):
+        dww, dbw = ops.conv1d_wgrad(xd, dyd, 5, 1, pl)
+    with ops.conv_math('fp32'):
+        dwd, dbd = ops.conv1d_wgrad(xd, dyd, 5, 1, pl)
+    s = np.sqrt(np.mean(dw_ref ** 2))
+    ew, ed = np.abs(dww.cpu().numpy() - dw_ref).max() / s, np.abs(dwd.cpu().numpy() - dw_ref).max() / s
+    rw, rd = np.sqrt(np.mean((dww.cpu().numpy() - dw_ref) ** 2)) / s, np.sqrt(np.mean((dwd.cpu().numpy() - dw_ref) ** 2)) / s
+    eb = np.abs(dbw.cpu().numpy() - db_ref).max() / np.abs(db_ref).max()
+    print('wgrad B %d L %d %d->%d %s: wino max %.2e rms %.2e | direct max %.2e rms %.2e | db %.1e' % (B, L, Cin, Cout, padding, ew, rw, ed, rd, eb), flush=True)
+    assert ew < 5e-5 and eb < 1e-5, 'wino wgrad wrong'
+
+
+def bench_wgrad(B, L, Cin, Cout, reps=5):
+    x = torch.randn(B, L, Cin, device=dev); dy = torch.randn(B, L, Cout, device=dev)
+    out = {}
+    for name in ('fp32', 'wino'):
+        with ops.conv_math(name):
+            fn = lambda: ops.conv1d_wgrad(x, dy, 5, 1, 2)
+            fn(); fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            out[name] = e0.elapsed_time(e1) / reps
+        print('wgrad %-5s B %d L %d %d->%d: %.3f ms  %.1f TFLOP/s algorithmic' % (name, B, L, Cin, Cout, out[name], 2.0 * B * L * 5 * Cin * Cout / out[name] / 1e9), flush=True)
+    print('   speed-up %.3f' % (out['fp32'] / out['wino']), flush=True)
+
+
+if __name__ == '__main__' and '--wgrad' in sys.argv:
+    for args in [(2, 64, 64, 64, 'same'), (3, 130, 128, 256, 'same'), (2, 257, 64, 128, 'valid'), (5, 37, 64, 64, 'same'), (1, 1, 64, 64, 'same'), (4, 2048, 128, 256, 'same'),
+                 (2, 2044, 128, 256, 'valid'), (16, 600, 256, 512, 'same')]:
+        check_wgrad(*args)
+    if '--bench' in sys.argv:
+        bench_wgrad(512, 2048, 512, 1024); bench_wgrad(512, 2048, 256, 512); bench_wgrad(512, 2048, 128, 256); bench_wgrad(256, 2048, 64, 128)
