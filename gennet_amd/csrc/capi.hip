@@ -110,26 +110,28 @@ static int conv_dispatch(const ConvArgs& a, hipStream_t s) {
   if (a.Cout <= 4) return conv_smallcout_dispatch(a, s);
   if (g_conv_math == 2 && a.Cin >= 32 && conv_wino_supported(a) && conv_wino_workspace_bytes(a.Cin, a.Cout) <= g_conv_ws_bytes)
     return conv_wino_run(a, g_conv_ws, g_conv_ws_bytes, s);
-  // size threshold of the opt-in split (A/B: GN_BF16X3_MIN_CIN / GN_BF16X3_MIN_COUT): the split pass costs ~10 bytes per input element per launch,
-  // the conv gains ~0.02 ps per element and output channel, so small-Cout layers gain little and small-Cin layers (few K chunks) lose to the prologue
-  static const int min_cin = getenv("GN_BF16X3_MIN_CIN") ? atoi(getenv("GN_BF16X3_MIN_CIN")) : 256;
-  static const int min_cout = getenv("GN_BF16X3_MIN_COUT") ? atoi(getenv("GN_BF16X3_MIN_COUT")) : 256;
+  // size threshold of the opt-in split: the split pass costs ~10 bytes per input element per launch, the conv gains ~0.02 ps per element and output
+  // channel, so small-Cout layers gain little and small-Cin layers (few K chunks) lose to the prologue
+  constexpr int min_cin = 256, min_cout = 256;
   if (g_conv_math == 1 && a.Cin >= min_cin && a.Cout >= min_cout && conv_bf16x3_supported(a) &&
       (g_phase_w_taps > 0 ? split_worth_it(a.B, (a.Ly + 1) / 2, g_phase_w_taps, a.Cin, a.Cout) :      // (every phase of one data gradient decides alike)
                             split_worth_it(a.B, a.M, a.t.ntaps, a.Cin, a.Cout))) {
     int w_taps = 0;
     for (int j = 0; j < a.t.ntaps; ++j) w_taps = std::max(w_taps, a.t.widx[j] + 1);
-    static const bool no_reuse = getenv("GN_BF16X3_NO_PHASE_REUSE") != nullptr;       // A/B switch
-    const bool phased = g_phase_w_taps > 0 && !no_reuse;
+    const bool phased = g_phase_w_taps > 0;
     if (phased) w_taps = g_phase_w_taps;
-    if (conv_bf16x3_workspace_bytes(a.B, a.Lin, a.Cin, a.Cout, w_taps) <= g_conv_ws_bytes) {
-      if (!(phased && g_phase_have_split)) {
-        int rc = conv_bf16x3_split(a, w_taps, g_conv_ws, g_conv_ws_bytes, true, true, s);
-        if (rc) return rc;
-        g_phase_have_split = phased;
-      }
-      return conv_bf16x3_run(a, w_taps, g_conv_ws, s);
+    // which kernel a launch takes depends on its shape alone: a workspace too small for it is an error, not a silent change of arithmetic
+    if (conv_bf16x3_workspace_bytes(a.B, a.Lin, a.Cin, a.Cout, w_taps) > g_conv_ws_bytes) {
+      set_error("conv (bf16x3 math): the split operands of this launch need %zu bytes, the workspace has %zu -- raise GENNET_CONV_WS_GB / ops.set_conv_math(workspace_gb=)",
+                conv_bf16x3_workspace_bytes(a.B, a.Lin, a.Cin, a.Cout, w_taps), g_conv_ws_bytes);
+      return GN_EWORKSPACE;
     }
+    if (!(phased && g_phase_have_split)) {
+      int rc = conv_bf16x3_split(a, w_taps, g_conv_ws, g_conv_ws_bytes, true, true, s);
+      if (rc) return rc;
+      g_phase_have_split = phased;
+    }
+    return conv_bf16x3_run(a, w_taps, g_conv_ws, s);
   }
   return conv_mfma_dispatch(a, s);
 }
@@ -368,11 +370,15 @@ static int dgrad_impl(const float* dy, const float* wt, float* dx, int B, int L,
     a.act = GN_ACT_LINEAR;
     a.gy = gy; a.gmask = gmask; a.gact = gact; a.gparam = gparam; a.gscale = 1.0f / (1.0f - grate);
     // opt-in split math: one launch for both phases where the 256-row blocks fill (the x fragments of tap pairs that read the same rows are read once)
-    static const int min_cin = getenv("GN_BF16X3_MIN_CIN") ? atoi(getenv("GN_BF16X3_MIN_CIN")) : 256;
-    static const int min_cout = getenv("GN_BF16X3_MIN_COUT") ? atoi(getenv("GN_BF16X3_MIN_COUT")) : 256;
-    static const bool no_merge = getenv("GN_BF16X3_NO_MERGE") != nullptr;            // A/B switch
+    constexpr int min_cin = 256, min_cout = 256;
+    static const bool no_merge = getenv("GN_BF16X3_NO_MERGE") != nullptr;            // A/B switch: the two phase launches (tests/test_bf16x3_gpu.py)
     const bool split_ok = g_conv_math == 1 && a.Cin >= min_cin && a.Cout >= min_cout && split_worth_it(a.B, a.M, 5, a.Cin, a.Cout);
-    if (split_ok && !no_merge && conv_bf16x3_merged_kind(a) && conv_bf16x3_workspace_bytes(a.B, a.Lin, a.Cin, a.Cout, 5) <= g_conv_ws_bytes) {
+    if (split_ok && !no_merge && conv_bf16x3_merged_kind(a)) {
+      if (conv_bf16x3_workspace_bytes(a.B, a.Lin, a.Cin, a.Cout, 5) > g_conv_ws_bytes) {
+        set_error("conv data gradient (bf16x3 math): the split operands need %zu bytes, the workspace has %zu", conv_bf16x3_workspace_bytes(a.B, a.Lin, a.Cin, a.Cout, 5),
+                  g_conv_ws_bytes);
+        return GN_EWORKSPACE;
+      }
       int rc = conv_bf16x3_split(a, 5, g_conv_ws, g_conv_ws_bytes, true, true, (hipStream_t)stream);
       if (rc) return rc;
       return conv_bf16x3_run_merged(a, g_conv_ws, (hipStream_t)stream);
@@ -441,10 +447,8 @@ int gn_conv1d_wgrad(const float* x, const float* dy, float* dw, float* db, void*
       if (rc) return rc;
       return db ? bias_grad(dy, db, (size_t)B * Lout, Cout, ws, ws_bytes, s) : GN_OK;
     }
-    static const int min_cin = getenv("GN_BF16X3_MIN_CIN") ? atoi(getenv("GN_BF16X3_MIN_CIN")) : 256;
-    static const int min_cout = getenv("GN_BF16X3_MIN_COUT") ? atoi(getenv("GN_BF16X3_MIN_COUT")) : 256;
-    static const bool no_wgrad = getenv("GN_BF16X3_NO_WGRAD") != nullptr;           // A/B switch
-    if (g_conv_math == 1 && !no_wgrad && Cin >= min_cin && Cout >= min_cout && split_worth_it(B, Lout, k, Cin, Cout)) {
+    constexpr int min_cin = 256, min_cout = 256;
+    if (g_conv_math == 1 && Cin >= min_cin && Cout >= min_cout && split_worth_it(B, Lout, k, Cin, Cout)) {
       a.split_ws = g_conv_ws;
       a.split_ws_bytes = g_conv_ws_bytes;
     }

@@ -72,17 +72,9 @@ struct WgradArgs {
   double* db_part;  // optional [splits][Cout]: per-split column sums of dy (the bias gradient), written by the blocks of Cin-tile 0
   float* db;        // optional: where wgrad_mfma_dispatch puts the bias gradient when the kernel it selects can sum it on the way
   int db_done;      // set by the dispatcher when db has been written
-  // wgrad_pipe_kernel, optional: the split-K reduction folded into the kernel.  tile_done[Cin tiles * Cout tiles] are zero between launches; the block
-  // that arrives LAST at a tile (atomic count == splits - 1) sums the tile's partial slabs in split order 0, 1, ... -- the order of
-  // wgrad_reduce_kernel, so dw comes out bit-identical -- writes dw and puts the counter back to zero.  NULL: the caller runs wgrad_reduce_kernel.
-  int* tile_done;
-  float* dw;
   // opt-in conv math (gn_set_conv_math 'bf16x3'): the workspace of the split planes; NULL on the default path (wgrad_bf16x3.hip)
   void* split_ws;
   size_t split_ws_bytes;
-  int xcd_order;    // wgrad_pipe_kernel: 1 = splits % 8 == 0 and every XCD (block i -> XCD i mod 8) takes whole K-splits; 2 = every XCD takes one patch of
-                    // (Cin tiles / patch_px) x (Cout tiles / (8 / patch_px)) tiles of each split (see the kernel)
-  int patch_px;
 };
 
 struct WgradSmallArgs {
@@ -130,7 +122,6 @@ int wgrad_mfma_dispatch(WgradArgs& a, float* dw, size_t ws_bytes, hipStream_t s)
 int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched);
 int conv_pipe_try_merged(const ConvArgs& a, hipStream_t s, bool* launched);
 void wgrad_pipe_launch(const WgradArgs& a, dim3 grid, bool narrow, hipStream_t s);
-int* wgrad_pipe_tile_counters(int* capacity);      // device array of zeroed per-tile arrival counters (module global of wgrad_pipe.hip)
 // conv_bf16x3.hip (experimental bf16 x 3 operand-split convolution, opt-in)
 size_t conv_bf16x3_workspace_bytes(int B, int Lin, int Cin, int Cout, int w_taps);
 bool conv_bf16x3_supported(const ConvArgs& a);

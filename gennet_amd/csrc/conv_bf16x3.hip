@@ -888,9 +888,8 @@ int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
     return GN_EINVAL;
   }
   if (a.t.in_stride == 2) return launch_bf16x3_wide<5, 0, 2>(a, w_taps, ws, s);
-  // 64 x 64 wave tiles in 256-row blocks for the 4- / 5-tap launches whose rows fill them (round 4); GN_BF16X3_NARROW keeps round 1's kernel
-  static const bool narrow = getenv("GN_BF16X3_NARROW") != nullptr;
-  if (!narrow && (a.t.ntaps == 2 || a.t.ntaps == 3) && a.M >= 192) {
+  // 64 x 64 wave tiles in 256-row blocks for the 4- / 5-tap launches whose rows fill them (round 4); shorter launches keep round 1's kernel
+  if ((a.t.ntaps == 2 || a.t.ntaps == 3) && a.M >= 192) {
     int minoff = a.t.off[0], maxoff = a.t.off[0];
     for (int j = 1; j < a.t.ntaps; ++j) {
       minoff = std::min(minoff, a.t.off[j]);
@@ -898,14 +897,15 @@ int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
     }
     if (maxoff - minoff + 1 <= 5) return a.t.ntaps == 2 ? launch_bf16x3_wide3<2>(a, w_taps, ws, s) : launch_bf16x3_wide3<3>(a, w_taps, ws, s);
   }
-  if (!narrow && a.t.ntaps >= 4 && a.M >= 192) {
+  if (a.t.ntaps >= 4 && a.M >= 192) {
     int minoff = a.t.off[0], maxoff = a.t.off[0];
     for (int j = 1; j < a.t.ntaps; ++j) {
       minoff = std::min(minoff, a.t.off[j]);
       maxoff = std::max(maxoff, a.t.off[j]);
     }
     if (maxoff - minoff + 1 <= 5) {
-      static const int abl = getenv("GN_BF16X3_ABL") ? atoi(getenv("GN_BF16X3_ABL")) : 0;      // timing experiments: wrong results
+#ifdef GN_ABLATION                  // timing experiments (wrong results): only in -DGN_ABLATION builds, never in the shipped library
+      static const int abl = getenv("GN_BF16X3_ABL") ? atoi(getenv("GN_BF16X3_ABL")) : 0;
       if (abl && a.t.ntaps == 5) {
         switch (abl) {
           case 1: return launch_bf16x3_wide<5, 1>(a, w_taps, ws, s);
@@ -915,6 +915,7 @@ int conv_bf16x3_run(const ConvArgs& a, int w_taps, void* ws, hipStream_t s) {
           default: return launch_bf16x3_wide<5, 7>(a, w_taps, ws, s);
         }
       }
+#endif
       return a.t.ntaps == 4 ? launch_bf16x3_wide<4>(a, w_taps, ws, s) : launch_bf16x3_wide<5>(a, w_taps, ws, s);
     }
   }

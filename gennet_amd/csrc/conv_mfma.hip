@@ -493,9 +493,8 @@ static int launch_conv_impl(const ConvArgs& a, hipStream_t s) {
 template <int WM, int WN, int WAVES_M, int WAVES_N, int KC, int NTAPS>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
   constexpr int TN = WAVES_N * WN * 32;
-  static const bool no_glds = getenv("GN_CONV_NOGLDS") != nullptr;      // A/B switches for benchmarking
-  static const bool no_dma = getenv("GN_CONV_NODMA") != nullptr;
-  const bool even = (a.Cout % TN == 0) && (a.Cin % KC == 0) && !no_glds;                       // no ragged channel edges
+  static const bool no_dma = getenv("GN_CONV_NODMA") != nullptr;       // A/B switch: the register-staged kernel everywhere (tests/test_switches_gpu.py)
+  const bool even = (a.Cout % TN == 0) && (a.Cin % KC == 0);                                   // no ragged channel edges
   const bool full = even && ((NTAPS * KC * (TN / 4)) % (64 * WAVES_M * WAVES_N) == 0);       // ... and whole weight items per thread
   if (even && (NTAPS * KC * (TN / 4)) % 64 == 0 && !no_dma && (size_t)a.Lin * a.Cin * 4 < 0x40000000ull) {
     if constexpr (KC == 8 && WM == 2 && WN == 2 && NTAPS >= 2) {
@@ -526,10 +525,8 @@ int conv_mfma_dispatch(const ConvArgs& a, hipStream_t s) {
   // stage, 37 KiB of LDS per block -> 4 blocks/CU against 3; for stride 2, 3 against 2) and wins on the 4-5-tap launches whenever
   // M fills it: measured 142 against 138 TFLOP/s on the dominant layer, 135.5 against 129.5 on the stride-2 forward; the 2-3-tap
   // data-gradient phases (130 against 136) and short sequences (M = 125: half a tile idle) keep the square tile.
-  static const bool force_wide = getenv("GN_CONV_WIDE") != nullptr;      // A/B switch
   auto fill = [&](int T) { return (double)a.M / ((double)((a.M + T - 1) / T) * T); };
-  static const int min_taps_tall = getenv("GN_CONV_TALL_TAPS") ? atoi(getenv("GN_CONV_TALL_TAPS")) : 4;      // A/B switch
-  const bool tall_ok = a.Cout % 64 == 0 && a.t.ntaps >= min_taps_tall && fill(256) >= 0.97 * fill(128) && !force_wide;
+  const bool tall_ok = a.Cout % 64 == 0 && a.t.ntaps >= 4 && fill(256) >= 0.97 * fill(128);
   const bool narrow = a.Cout <= 64 || tall_ok;
   // K-chunk: 8 channels for 2-5 taps (stages of 8-25 KiB -> 3-4 blocks/CU; measured on the stride-2 data-gradient phases of 3 and
   // 2 taps: 134 TFLOP/s against 122 with 16-channel chunks at 2 blocks/CU -- occupancy beats MFMAs-per-barrier); 16 for the
@@ -696,12 +693,11 @@ void wgrad_split_plan(int B, int M, int Cin, int Cout, int TC, int TN, int* spli
   const int tiles = cdiv(Cin, TC) * cdiv(Cout, TN);
   // blocks per launch the K-splits aim at: two full rounds of the chip's 1024 block slots.  Measured (round 3, step in waveforms/s): 2048: 1437,
   // 1024 (one round, half the partial slabs to write and reduce): 1436 -- the kernel loses what the reduce gains; 1536 / 3072: 1429 (ragged rounds)
-  static const int target_blocks = getenv("GN_WGRAD_BLOCKS") ? atoi(getenv("GN_WGRAD_BLOCKS")) : 2048;      // A/B switch
+  constexpr int target_blocks = 2048;
   int s = (target_blocks + tiles - 1) / tiles;
   if (s < 1) s = 1;
-  static const bool no_sub = getenv("GN_WGRAD_NOSUBSPLIT") != nullptr;       // A/B switch
   int cps;
-  if (s <= B || no_sub || (long)tiles * B >= 256) {
+  if (s <= B || (long)tiles * B >= 256) {
     if (s > B) s = B;
     const int bps = (B + s - 1) / s;
     cps = bps * cpb;
@@ -717,9 +713,8 @@ void wgrad_split_plan(int B, int M, int Cin, int Cout, int TC, int TN, int* spli
 
 static bool wgrad_square(int Cin, int Cout, int ntaps) {
   // 64 x 64 block tile (2 x 2 waves) wherever it divides: 34 KiB of LDS per block -> 4 blocks per CU against 3 for 32 x 128, and fewer
-  // staged bytes per flop: 145.8 against 143.9 TFLOP/s on G 512->1024, equal on the stride-2 layers.  GN_WGRAD_SQUARE=0: A/B switch.
-  static const int mode = getenv("GN_WGRAD_SQUARE") ? atoi(getenv("GN_WGRAD_SQUARE")) : 1;
-  return Cout <= 64 || (mode == 1 && ntaps == 5 && Cin % 64 == 0 && Cout % 64 == 0);
+  // staged bytes per flop: 145.8 against 143.9 TFLOP/s on G 512->1024, equal on the stride-2 layers.
+  return Cout <= 64 || (ntaps == 5 && Cin % 64 == 0 && Cout % 64 == 0);
 }
 static void wgrad_tile(int Cin, int Cout, int ntaps, int* TC, int* TN) {
   if (wgrad_square(Cin, Cout, ntaps)) { *TC = 64; *TN = 64; } else { *TC = 32; *TN = 128; }
@@ -747,11 +742,16 @@ static int launch_wgrad(WgradArgs& a, float* dw, hipStream_t s) {
   const int R = a.in_stride * (KT - 1) + (maxoff - minoff) + 1;
   const size_t lds = sizeof(float) * (((size_t)R * TC + 3 & ~(size_t)3) + (size_t)KT * TN);
   dim3 grid(cdiv(a.Cin, TC), cdiv(a.Cout, TN), splits);
-  static const bool no_pipe = getenv("GN_WGRAD_NOPIPE") != nullptr;      // A/B switch
+  static const bool no_pipe = getenv("GN_WGRAD_NOPIPE") != nullptr;      // A/B switch: the register-staged weight-gradient kernel everywhere (tests/test_switches_gpu.py)
   bool piped = false;
   if constexpr (NTAPS == 5 && WNT == 1) {
     // opt-in split math: six bf16 products per fp32 product (wgrad_bf16x3.hip); same K-split plan, partial slabs and reduce pass as the exact kernel
-    if (a.split_ws && wgrad_bf16x3_supported(a) && wgrad_bf16x3_workspace_bytes(a.B, a.M, a.Cin, a.Cout, a.in_stride) <= a.split_ws_bytes) {
+    if (a.split_ws && wgrad_bf16x3_supported(a)) {
+      if (wgrad_bf16x3_workspace_bytes(a.B, a.M, a.Cin, a.Cout, a.in_stride) > a.split_ws_bytes) {      // never a silent change of arithmetic
+        set_error("weight gradient (bf16x3 math): the split operands need %zu bytes, the workspace has %zu -- raise GENNET_CONV_WS_GB",
+                  wgrad_bf16x3_workspace_bytes(a.B, a.M, a.Cin, a.Cout, a.in_stride), a.split_ws_bytes);
+        return GN_EWORKSPACE;
+      }
       int rc = wgrad_bf16x3_run(a, splits, a.split_ws, a.split_ws_bytes, s);
       if (rc) return rc;
       const size_t n = (size_t)NTAPS * a.Cin * a.Cout;
@@ -765,37 +765,6 @@ static int launch_wgrad(WgradArgs& a, float* dw, hipStream_t s) {
         (size_t)a.M * a.Cout * 4 < 0x40000000ull) {
       // the bias gradient rides along: the blocks of Cin-tile 0 sum the columns of the dy tiles they stage anyway (no separate pass over dy)
       a.db_part = a.db ? reinterpret_cast<double*>(reinterpret_cast<char*>(a.part) + (size_t)splits * NTAPS * a.Cin * a.Cout * sizeof(float)) : nullptr;
-      // whole K-splits per XCD (wgrad_pipe_kernel): FETCH_SIZE -33 % but 1 % SLOWER on G 512 -> 1024 (143.8 against 145.5 TFLOP/s in
-      // the step): in grid order the 8 XCDs read the same dy tiles at about the same time and the Infinity Cache serves 7 of the 8;
-      // with private splits every XCD streams its own batch range from HBM.  Off unless GN_WGRAD_XCD is set.
-      static const bool xcd = getenv("GN_WGRAD_XCD") != nullptr;
-      a.xcd_order = xcd && splits % 8 == 0;
-      // patch order of the tile plane inside every split (GN_WGRAD_PATCH; measured in round 3): needs the tile
-      // plane to split into 8 patches, px x (8 / px) with px | Cin tiles and (8 / px) | Cout tiles, as square as possible
-      static const bool patch = getenv("GN_WGRAD_PATCH") != nullptr;
-      a.patch_px = 0;
-      if (patch && !a.xcd_order) {
-        int best = 0, best_cost = 1 << 30;
-        for (int px = 1; px <= 8; px <<= 1) {
-          const int py = 8 / px;
-          if ((int)grid.x % px || (int)grid.y % py) continue;
-          const int cost = (int)grid.x / px + (int)grid.y / py;       // tiles of x plus tiles of dy an XCD streams per split
-          if (cost < best_cost) { best_cost = cost; best = px; }
-        }
-        if (best) { a.xcd_order = 2; a.patch_px = best; }
-      }
-      // the split-K reduction inside the kernel (last-arriving block per tile, wgrad_pipe.hip): dw bit-identical to wgrad_reduce_kernel's.
-      // Measured in round 4 on the headline step (two boxes, profiles/r04_ab_wgrad_fold.json): 1440.5 / 1437.0 waveforms/s with the separate reduce
-      // pass, 1403-1407 folded.  The 21 reduce launches (0.4 % of the step) go, but every weight-gradient launch grows by 0.33-0.40 ms (0.93 -> 0.86
-      // of peak), the same with 4 or 16 slab loads in flight per thread of the last block: what costs is the device-scope release / acquire every
-      // block executes -- on gfx950 an L2 write-back and an L2 invalidate of an XCD-private L2 -- under the blocks still in their main loop.  Opt-in.
-      static const bool fold = getenv("GN_WGRAD_FOLD") != nullptr;             // A/B switch
-      a.tile_done = nullptr; a.dw = dw;
-      if (fold) {
-        int cap = 0;
-        int* cnt = wgrad_pipe_tile_counters(&cap);
-        if (cnt && (int)(grid.x * grid.y) <= cap) a.tile_done = cnt;
-      }
       wgrad_pipe_launch(a, grid, WAVES_C == 2, s);                       // wgrad_pipe.hip
       piped = true;
     }
@@ -806,8 +775,7 @@ static int launch_wgrad(WgradArgs& a, float* dw, hipStream_t s) {
   int rc = check_launch("wgrad_mfma");
   if (rc) return rc;
   const size_t n = (size_t)NTAPS * a.Cin * a.Cout;
-  if (!(piped && a.tile_done))
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a.part, dw, n / 4, splits, n / 4);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a.part, dw, n / 4, splits, n / 4);
   if (piped && a.db_part) {
     int rc2 = colred_finalize_f32(a.db_part, a.db, (size_t)a.Cout, splits, s);      // db[n] = sum over splits, fp64, fixed order
     if (rc2) return rc2;

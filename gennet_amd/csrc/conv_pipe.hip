@@ -513,13 +513,13 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
   // 128 or 64 rows -- so that a launch with fewer than two 64 x 64 wave tiles per SIMD gets at least one block per CU (256 blocks: 1.62 /
   // 4.28; requiring two, 512 blocks, 1.71 / 4.54; 128 blocks 1.78 / 4.67), and every block still spreads over the CU's SIMDs.
   static const bool no_narrow = getenv("GN_CONV_NONARROW") != nullptr;          // A/B switch
-  static const int narrow_below = getenv("GN_CONV_NARROW_BELOW") ? atoi(getenv("GN_CONV_NARROW_BELOW")) : 2048;
+  constexpr int narrow_below = 2048;
   const size_t wave_tiles = (size_t)a.B * (size_t)((a.M + 63) / 64) * (size_t)(a.Cout / 64);
   const bool narrow_wave = !no_narrow && a.Cout % 64 == 0 && wave_tiles < (size_t)narrow_below;
   int nwm = 4;
   if (narrow_wave) {
     auto blocks_of = [&](int wm_) { return (size_t)a.B * (size_t)((a.M + 64 * wm_ - 1) / (64 * wm_)) * (size_t)(a.Cout / 64); };
-    static const int min_blocks = getenv("GN_CONV_NARROW_BLOCKS") ? atoi(getenv("GN_CONV_NARROW_BLOCKS")) : 256;      // A/B switch
+    constexpr int min_blocks = 256;
     while (nwm > 1 && blocks_of(nwm) < (size_t)min_blocks) nwm >>= 1;
   }
 #define GN_PIPE(NT_, IS_)                                                                    \
@@ -529,14 +529,11 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
       if (nwm == 2) return launch_conv_pipe<2, 2, NT_, IS_, 8, 1>(a, s);                     \
       return launch_conv_pipe<1, 2, NT_, IS_, 8, 1>(a, s);                                   \
     }                                                                                        \
-    if constexpr (IS_ == 2)                                                                  \
-      if (tall && wide8 && a.Cout % 128 == 0) return launch_conv_pipe<4, 2, 5, 2>(a, s);     \
     return tall ? launch_conv_pipe<4, 1, NT_, IS_>(a, s) : launch_conv_pipe<2, 2, NT_, IS_>(a, s);                       \
   } while (0)
   // (256 x 128 blocks of 8 waves for the stride-2 forward -- 74 KiB of LDS, two blocks per CU = a fourth wave per SIMD -- measured in round 3:
   // -2.5 to -4 % per launch in the layer sweep, nothing on the step (1420.0 / 1420.6 against 1420.8 / 1419.1 waveforms/s); the same blocks on the
-  // stride-1 5-tap launches and on the 2- / 3-tap phases LOSE 0.3 % of the step.  Opt-in.)
-  static const bool wide8 = getenv("GN_CONV_WIDE8") != nullptr;
+  // stride-1 5-tap launches and on the 2- / 3-tap phases LOSE 0.3 % of the step.  Removed in round 5.)
   // (4-channel chunks for the stride-2 forward -- 27 instead of 53 KiB of LDS, a fourth block per CU, but a barrier per 40 MFMAs -- were
   // measured: 140.3 -> 135.5 TFLOP/s.  Eight channels per chunk is the optimum in both directions.)
   if (a.t.in_stride == 2) { GN_PIPE(5, 2); }
@@ -559,9 +556,8 @@ int conv_pipe_try(const ConvArgs& a, bool tall, hipStream_t s, bool* launched) {
 int conv_pipe_try_merged(const ConvArgs& a, hipStream_t s, bool* launched) {
   // A/B switches: the merged kernel is a member of the pipelined LDS-DMA family, so every switch that takes that family out (to run and test
   // the fallback kernels) takes it out too
-  static const bool off = getenv("GN_CONV_NOMERGE") != nullptr || getenv("GN_CONV_NOPIPE") != nullptr || getenv("GN_CONV_NODMA") != nullptr ||
-                          getenv("GN_CONV_NOGLDS") != nullptr;
-  static const int merge_below = getenv("GN_CONV_MERGE_BELOW") ? atoi(getenv("GN_CONV_MERGE_BELOW")) : 2048;
+  static const bool off = getenv("GN_CONV_NOMERGE") != nullptr || getenv("GN_CONV_NOPIPE") != nullptr || getenv("GN_CONV_NODMA") != nullptr;
+  constexpr int merge_below = 2048;
   *launched = false;
   if (off || a.t.ntaps != 5 || a.t.in_stride != 1 || a.t.out_stride != 2 || a.stat_part || a.mask || a.bias) return GN_OK;
   int minoff = a.t.off[0], maxoff = a.t.off[0];

@@ -53,13 +53,12 @@ static int launch_noise(const NoiseLaunch& a, hipStream_t s) {
 
 int noise_whitened(const NoiseLaunch& a, int N, hipStream_t s) {
   if (a.nb == 0) return GN_OK;
-  static const bool wide_threads = getenv("GN_SYNTH_WIDE_THREADS") != nullptr;      // A/B switch: 16 values per thread instead of 8
   switch (N) {
     case 1024: return launch_noise<9, 128>(a, s);
     case 2048: return launch_noise<10, 256>(a, s);
     case 4096: return launch_noise<11, 256>(a, s);
     case 8192: return launch_noise<12, 256>(a, s);
-    case 16384: return wide_threads ? launch_noise<13, 512>(a, s) : launch_noise<13, 1024>(a, s);
+    case 16384: return launch_noise<13, 1024>(a, s);
     default:
       set_error("noise_whitened: N %d unsupported (1024, 2048, 4096, 8192, 16384)", N);
       return GN_EINVAL;

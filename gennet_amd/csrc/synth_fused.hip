@@ -448,9 +448,8 @@ double noise_flops_per_row(int M);
 template <int LOGM, int NT, int OCC = 0>
 static int launch_synth(const SynthArgs& a, hipStream_t s) {
   constexpr int M = 1 << LOGM;
-  static const size_t lds_pad = getenv("GN_SYNTH_LDS_PAD") ? (size_t)atoi(getenv("GN_SYNTH_LDS_PAD")) : 0;      // experiment: force fewer blocks per CU
   const bool noise = a.nz.amp != nullptr;
-  const size_t lds = (size_t)((noise || LOGM > 11) ? M + M / 8 : M / 2 + M / 16) * sizeof(double2) + sizeof(ChirpCoeffsF) + 16 * sizeof(double) + 16 * sizeof(int) + lds_pad;
+  const size_t lds = (size_t)((noise || LOGM > 11) ? M + M / 8 : M / 2 + M / 16) * sizeof(double2) + sizeof(ChirpCoeffsF) + 16 * sizeof(double) + 16 * sizeof(int);
   if (noise && a.crop_len > M / 2) {
     set_error("synth_templates: noise mode needs crop_len <= N/4 (crop %d, N %d)", a.crop_len, 2 * M);
     return GN_EINVAL;
@@ -473,16 +472,15 @@ static int launch_synth(const SynthArgs& a, hipStream_t s) {
 
 int synth_templates(const SynthArgs& a, hipStream_t s) {
   if (a.nb == 0) return GN_OK;
-  static const bool wide_threads = getenv("GN_SYNTH_WIDE_THREADS") != nullptr;
   switch (a.N) {
     case 1024: return launch_synth<9, 128>(a, s);
     case 2048: return launch_synth<10, 256>(a, s);
     case 4096: return launch_synth<11, 256>(a, s);
-    // threads per block measured in round 3 (ms per 16 384 templates; GN_SYNTH_WIDE_THREADS = 16 values per thread at N 16384): N 8192: 256
+    // threads per block measured in round 3 (ms per 16 384 templates): N 8192: 256
     // threads 1.61, 512 threads 2.31 (two blocks per CU either way, the barriers of 8 waves cost more than their latency hiding buys);
     // N 16384 (one block per CU): 512 threads 8.26 (template + noise), 1024 threads 7.33
     case 8192: return launch_synth<12, 256>(a, s);
-    case 16384: return wide_threads ? launch_synth<13, 512>(a, s) : launch_synth<13, 1024>(a, s);
+    case 16384: return launch_synth<13, 1024>(a, s);
     default:
       set_error("synth_templates: N %d unsupported (1024, 2048, 4096, 8192, 16384)", a.N);
       return GN_EINVAL;

@@ -136,7 +136,7 @@ __device__ __forceinline__ bf16x8 shifted_rows(const u32x4& lo, const uint2& hi)
 // odd input rows), so the narrower x tile stages 54 instead of 73 KiB per chunk for the same MFMAs
 template <int IS, int PODD, int ABL = 0, int IB = 2, int WNN = 2>
 __global__ __launch_bounds__(512 / IB, 1) void wgrad_bf16x3_kernel(WgradArgs a, const unsigned short* __restrict__ xt, const unsigned short* __restrict__ dyt,
-                                                              size_t x_plane, size_t dy_plane) {
+                                                              size_t x_plane, size_t dy_plane, int xcd_order) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NTAPS = 5, KC = 32;
   constexpr int TN = 32 * WNN, TC = 32 * IB * ((8 / IB) / WNN);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512 / IB, 1) void wgrad_bf16x3_kernel(WgradArgs a, 
   // block -> (Cin tile, Cout tile, K-split).  xcd_order: block i runs on XCD i mod 8; every XCD takes whole K-splits (the splits k, k + 8, ...) with all
   // their tiles one after the other, so each x / dy chunk crosses the fabric once and its reuse by the tiles is served by that XCD's L2
   int ct = blockIdx.x, nt_ = blockIdx.y, split = blockIdx.z;
-  if (a.xcd_order) {
+  if (xcd_order) {
     const int tiles = gridDim.x * gridDim.y;
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     const int q = lin >> 3, tile = q % tiles;
@@ -364,9 +364,8 @@ size_t wgrad_bf16x3_workspace_bytes(int B, int M, int Cin, int Cout, int in_stri
 bool wgrad_bf16x3_supported(const WgradArgs& a) {
   if (a.ntaps != 5 || (a.in_stride != 1 && a.in_stride != 2) || a.Cin % 128 || a.Cout % 64 || a.M < 1) return false;
   // stride 2 stages (and splits) two input rows per output row: measured 187 TFLOP/s for the kernel, 157 with the split passes against the exact
-  // kernel's 142 on 512 -> 1024, but 130 against 141 on 256 -> 512 -- only the wide layers take it (GN_WGBF_S2_MIN_CIN: A/B switch)
-  static const int s2_min_cin = getenv("GN_WGBF_S2_MIN_CIN") ? atoi(getenv("GN_WGBF_S2_MIN_CIN")) : 512;
-  if (a.in_stride == 2 && a.Cin < s2_min_cin) return false;
+  // kernel's 142 on 512 -> 1024, but 130 against 141 on 256 -> 512 -- only the wide layers take it
+  if (a.in_stride == 2 && a.Cin < 512) return false;
   int minoff = a.off[0], maxoff = a.off[0];
   for (int j = 1; j < 5; ++j) {
     minoff = std::min(minoff, a.off[j]);
@@ -378,8 +377,7 @@ bool wgrad_bf16x3_supported(const WgradArgs& a) {
 // The split passes and the kernel; the caller (launch_wgrad, conv_mfma.hip) owns the K-split plan (a.chunks_per_split, splits) and the reduce pass.
 int wgrad_bf16x3_run(const WgradArgs& a_in, int splits, void* ws, size_t ws_bytes, hipStream_t s) {
   WgradArgs a = a_in;
-  static const bool no_xcd = getenv("GN_WGBF_NOXCD") != nullptr;         // A/B switch
-  a.xcd_order = !no_xcd && splits % 8 == 0;
+  const int xcd_order = splits % 8 == 0;
   if (ws_bytes < wgrad_bf16x3_workspace_bytes(a.B, a.M, a.Cin, a.Cout, a.in_stride)) {
     set_error("wgrad_bf16x3: workspace too small");
     return GN_EWORKSPACE;
@@ -403,61 +401,56 @@ int wgrad_bf16x3_run(const WgradArgs& a_in, int splits, void* ws, size_t ws_byte
   dim3 grid(a.Cin / 128, a.Cout / 64, splits);
   const unsigned short* xc = xt;
   const unsigned short* dc = dyt;
-  static const bool no_wide_n = getenv("GN_WGBF_NO_WIDE_N") != nullptr;                 // A/B switch: stride 2 on 128 ci x 64 co blocks as at unit stride
-  const bool wide_n = !no_wide_n && a.Cout % 128 == 0;
-  static const bool four_waves = getenv("GN_WGBF_4WAVES") != nullptr;                  // A/B switch: 4 waves of 64 x 32 instead of 8 of 32 x 32 (stride 1)
+  const bool wide_n = a.Cout % 128 == 0;            // stride 2: 64 ci x 128 co blocks stage 54 instead of 73 KiB per chunk (196.7 against 190.1 TFLOP/s)
+#ifdef GN_ABLATION
   static const int abl = getenv("GN_WGBF_ABL") ? atoi(getenv("GN_WGBF_ABL")) : 0;       // timing ablations, stride 1 (results are wrong with any of them)
+#else
+  constexpr int abl = 0;
+#endif
   prof_begin(s);
   if (IS == 1) {
     constexpr size_t lds = 2 * (size_t)(3 * 128 * 80 + 3 * 64 * 64);
-    static unsigned long long d0 = 0, d1 = 0, d2 = 0, d4 = 0;
+#ifdef GN_ABLATION
+    static unsigned long long d1 = 0, d2 = 0, d4 = 0;
     if (abl == 1) {
       allow_big_lds((const void*)wgrad_bf16x3_kernel<1, 0, 1>, &d1);
-      hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 0, 1>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane);
+      hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 0, 1>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane, xcd_order);
     } else if (abl == 2) {
       allow_big_lds((const void*)wgrad_bf16x3_kernel<1, 0, 2>, &d2);
-      hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 0, 2>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane);
+      hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 0, 2>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane, xcd_order);
     } else if (abl == 4) {
       allow_big_lds((const void*)wgrad_bf16x3_kernel<1, 0, 4>, &d4);
-      hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 0, 4>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane);
-    } else if (four_waves) {
-      allow_big_lds((const void*)wgrad_bf16x3_kernel<1, 0>, &d0);
-      hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 0>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane);
-    } else {
+      hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 0, 4>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane, xcd_order);
+    } else
+#endif
+    {
+      (void)abl;
+      // eight waves of 32 x 32 x 5 taps, two per SIMD (four waves of 64 x 32: 229-239 against 248 TFLOP/s; removed in round 5)
       static unsigned long long d8 = 0;
       allow_big_lds((const void*)wgrad_bf16x3_kernel<1, 0, 0, 1>, &d8);
-      hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 0, 0, 1>), grid, dim3(512), lds, s, a, xc, dc, x_plane, dy_plane);
+      hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 0, 0, 1>), grid, dim3(512), lds, s, a, xc, dc, x_plane, dy_plane, xcd_order);
     }
   } else {
     constexpr size_t lds = 2 * (size_t)(3 * 2 * 128 * 80 + 3 * 64 * 64);
-    static unsigned long long e0 = 0, e1 = 0;
     static unsigned long long f0 = 0, f1 = 0;
-    if (four_waves) {
-      if (pl & 1) {
-        allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 1>, &e1);
-        hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 1>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane);
-      } else {
-        allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 0>, &e0);
-        hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 0>), grid, dim3(256), lds, s, a, xc, dc, x_plane, dy_plane);
-      }
-    } else if (wide_n) {
+    if (wide_n) {
       // 64 ci x 128 co blocks
       constexpr size_t lds2 = 2 * (size_t)(3 * 2 * 64 * 80 + 3 * 128 * 64);
       dim3 grid2(a.Cin / 64, a.Cout / 128, splits);
       static unsigned long long g0 = 0, g1 = 0;
       if (pl & 1) {
         allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 1, 0, 1, 4>, &g1);
-        hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 1, 0, 1, 4>), grid2, dim3(512), lds2, s, a, xc, dc, x_plane, dy_plane);
+        hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 1, 0, 1, 4>), grid2, dim3(512), lds2, s, a, xc, dc, x_plane, dy_plane, xcd_order);
       } else {
         allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 0, 0, 1, 4>, &g0);
-        hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 0, 0, 1, 4>), grid2, dim3(512), lds2, s, a, xc, dc, x_plane, dy_plane);
+        hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 0, 0, 1, 4>), grid2, dim3(512), lds2, s, a, xc, dc, x_plane, dy_plane, xcd_order);
       }
     } else if (pl & 1) {
       allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 1, 0, 1>, &f1);
-      hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 1, 0, 1>), grid, dim3(512), lds, s, a, xc, dc, x_plane, dy_plane);
+      hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 1, 0, 1>), grid, dim3(512), lds, s, a, xc, dc, x_plane, dy_plane, xcd_order);
     } else {
       allow_big_lds((const void*)wgrad_bf16x3_kernel<2, 0, 0, 1>, &f0);
-      hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 0, 0, 1>), grid, dim3(512), lds, s, a, xc, dc, x_plane, dy_plane);
+      hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 0, 0, 1>), grid, dim3(512), lds, s, a, xc, dc, x_plane, dy_plane, xcd_order);
     }
   }
   prof_end(s, 2.0 * a.B * (double)a.M * 5 * a.Cin * a.Cout, 2);

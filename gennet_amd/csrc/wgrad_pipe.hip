@@ -126,30 +126,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(W
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave / WAVES_N, wn = wave % WAVES_N;
   const int i32 = lane & 31, h = lane >> 5;
-  // block -> (Cin tile, Cout tile, K-split).  In grid order (x fastest) block i runs on XCD i mod 8: with 8 Cin tiles every XCD owns one
-  // of them and reads ALL of dy -- dy crosses the fabric 8 times.  xcd_order gives XCD k the K-splits k, k + 8, ... with all their
-  // tiles (consecutive blocks of an XCD walk the tiles of one split), so each x slab and dy tile of a split is fetched by one XCD only
-  // and its L2 serves the Cin-tile x Cout-tile reuse.
+  // block -> (Cin tile, Cout tile, K-split), grid order.  (Whole K-splits per XCD and a patch order of the tile plane were measured in rounds 2-3:
+  // a third fewer fabric fetches, 1 % slower -- the Infinity Cache already serves the 8 XCDs that read the same dy tiles at the same time; removed.)
   int ct = blockIdx.x, nt_ = blockIdx.y, split = blockIdx.z;
-  if (a.xcd_order == 2) {
-    // patch order (round 3): inside every split the 8 XCDs take the 8 patches of a (px x 8/px) partition of the (Cin tile,
-    // Cout tile) plane, so an XCD's L2 serves each x slab tile to pn and each dy tile to pc blocks (4 x 4 tiles on G 512 -> 1024) instead of
-    // owning one Cin tile with ALL the Cout tiles (dy crossing the fabric 8 times)
-    const int gx = gridDim.x, gy = gridDim.y, tiles = gx * gy;
-    const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-    const int r = lin % tiles, k = r & 7, i = r >> 3;
-    const int px = a.patch_px, py = 8 / px, pc = gx / px, pn = gy / py;
-    split = lin / tiles;
-    ct = (k % px) * pc + (i % pc);
-    nt_ = (k / px) * pn + (i / pc);
-  } else if (a.xcd_order) {
-    const int tiles = gridDim.x * gridDim.y;
-    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int q = lin >> 3, tile = q % tiles;
-    split = (q / tiles) * 8 + (lin & 7);
-    ct = tile % (int)gridDim.x;
-    nt_ = tile / (int)gridDim.x;
-  }
   ct = __builtin_amdgcn_readfirstlane(ct); nt_ = __builtin_amdgcn_readfirstlane(nt_); split = __builtin_amdgcn_readfirstlane(split);
   const int c0 = ct * TC, n0 = nt_ * TN;
 
@@ -278,52 +257,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(W
       pj[(size_t)c * a.Cout + n] = acc[j][r];
     }
   }
-  // Split-K reduction in the kernel (round 4; OPT-IN, GN_WGRAD_FOLD: measured 2.3 % slower on the headline step, see launch_wgrad in conv_mfma.hip --
-  // the fences below cost more than the pass they replace): instead of a separate pass over all partial slabs (wgrad_reduce_kernel: 21 launches and 1.5 ms of
-  // the headline step), the block that arrives LAST at its (Cin tile, Cout tile) sums that tile's slabs -- written microseconds ago by the other
-  // splits -- in split order 0, 1, ..., the order of wgrad_reduce_kernel, so dw is bit-identical.  Release: every thread's stores, then a
-  // device-scope fence, then the block barrier, then ONE atomic per block; acquire: the fence after the counter read (the XCDs' L2s are not
-  // coherent with each other without it).  The last block puts the counter back to zero for the next launch.
-  if (a.tile_done) {
-    __threadfence();
-    __syncthreads();
-    int* flag = reinterpret_cast<int*>(smem);                // the stages are free: every wave is past the loop's last barrier
-    const int S = gridDim.z;
-    if (tid == 0) {
-      int* cnt = a.tile_done + ct * (a.Cout / TN) + nt_;
-      const int last = atomicAdd(cnt, 1) == S - 1;
-      if (last) atomicExch(cnt, 0);
-      *flag = last;
-    }
-    __syncthreads();
-    if (*flag) {
-      __threadfence();
-      const size_t tapstride = (size_t)a.Cin * a.Cout, splitstride = (size_t)NTAPS * tapstride;
-      constexpr int V = TC * (TN / 4);                       // float4 values of one tap of the tile
-      // sixteen slab loads in flight per thread, summed in split order afterwards
-      constexpr int KB = 16;
-#pragma unroll 1
-      for (int j = 0; j < NTAPS; ++j)
-#pragma unroll 1
-        for (int idx = tid; idx < V; idx += NT) {
-          const size_t e = j * tapstride + (size_t)(c0 + idx / (TN / 4)) * a.Cout + n0 + 4 * (idx % (TN / 4));
-          float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          for (int k0 = 0; k0 < S; k0 += KB) {
-            float4 v[KB];
-#pragma unroll
-            for (int k = 0; k < KB; ++k)
-              v[k] = k0 + k < S ? *reinterpret_cast<const float4*>(a.part + (size_t)(k0 + k) * splitstride + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < KB; ++k)
-              if (k0 + k < S) {
-                if (k0 + k == 0) acc4 = v[0];
-                else { acc4.x += v[k].x; acc4.y += v[k].y; acc4.z += v[k].z; acc4.w += v[k].w; }
-              }
-          }
-          *reinterpret_cast<float4*>(a.dw + e) = acc4;
-        }
-    }
-  }
+  // (The split-K reduction folded into this kernel -- last-arriving block per tile -- was measured in round 4: -2.3 % on the step; the device-scope
+  // release / acquire is an L2 write-back + invalidate of an XCD-private L2 under the blocks still in their main loop.  Removed; profiles/r04_ab_wgrad_fold.json.)
 #endif
 }
 
@@ -340,21 +275,6 @@ static void launch_wgrad_pipe(const WgradArgs& a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((wgrad_pipe_kernel<WAVES_C, WAVES_N, IS>), grid, dim3(64 * WAVES_C * WAVES_N), lds, s, a);
 }
 
-
-// per-tile arrival counters of the folded split-K reduction: zero at load, put back to zero by the last block of every launch (one stream per process)
-constexpr int WGRAD_TILE_COUNTERS = 8192;
-__device__ int g_wgrad_tile_done[WGRAD_TILE_COUNTERS];
-
-int* wgrad_pipe_tile_counters(int* capacity) {
-  static int* ptr = nullptr;
-  if (!ptr) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wgrad_tile_done)) != hipSuccess) return nullptr;
-    ptr = static_cast<int*>(p);
-  }
-  *capacity = WGRAD_TILE_COUNTERS;
-  return ptr;
-}
 
 void wgrad_pipe_launch(const WgradArgs& a, dim3 grid, bool narrow, hipStream_t s) {
   if (narrow) {

@@ -143,51 +143,6 @@ def test_conv1d_fwd_stats_stays_inside_an_exact_size_workspace(B, L, Cin, Cout):
     assert np.abs(sums.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
-_WGRAD_FOLD_SHAPES = [(16, 512, 64, 128, 1), (6, 300, 128, 64, 1), (8, 256, 128, 256, 2), (3, 1000, 64, 64, 1), (16, 512, 64, 128, 1)]
-
-
-def _wgrad_fold_cases():
-    """dw of every shape in order (the list revisits its first shape: per-tile counters must be back at zero after every launch)."""
-    from gennet_amd import ops
-    out = []
-    for B, L, Cin, Cout, s in _WGRAD_FOLD_SHAPES:
-        Lout, pl = ops.conv_geometry(L, 5, s, 'same')
-        x = ops.fill_normal((B, L, Cin), 0.0, 1.0, 5, 0, torch.device('cuda'))
-        dy = ops.fill_normal((B, Lout, Cout), 0.0, 1.0, 6, 0, torch.device('cuda'))
-        for _ in range(2):
-            dw, db = ops.conv1d_wgrad(x, dy, 5, s, pl)
-        out.append((dw.cpu().numpy(), db.cpu().numpy()))
-    return out
-
-
-def test_wgrad_split_k_reduction_inside_the_kernel_is_bit_identical_to_the_reduce_pass(tmp_path):
-    """Opt-in GN_WGRAD_FOLD=1 (measured slower on the headline step and off by default, conv_mfma.hip): wgrad_pipe_kernel's last-arriving block per
-    tile sums the split-K slabs in the order of wgrad_reduce_kernel.  The weight gradient must equal, bit for bit, what the separate reduce pass
-    gives (the switch is read once per process: a child process runs the folded leg), for batch-sized and sub-batch K-splits, both input strides,
-    repeated launches and changing shapes."""
-    import subprocess
-    import sys
-    out = str(tmp_path / 'fold.npz')
-    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch; import test_kernels_gpu as T; "
-            "r = T._wgrad_fold_cases(); np.savez(%r, *[a for pair in r for a in pair])") % (ROOT, os.path.join(ROOT, 'tests'), out)
-    env = dict(os.environ, GN_WGRAD_FOLD='1')
-    r = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:]
-    ref = np.load(out)
-    got = [a for pair in _wgrad_fold_cases() for a in pair]
-    assert len(got) == len(ref.files)
-    for k, a in enumerate(got):
-        assert np.array_equal(a, ref['arr_%d' % k]), (k, _WGRAD_FOLD_SHAPES[k // 2])
-    # and against the oracle, once (the same shapes are covered by test_conv1d_* above at their own sizes)
-    from gennet_amd import ops
-    rng = np.random.RandomState(2)
-    B, L, Cin, Cout = 4, 200, 64, 64
-    x = f32(rng.randn(B, L, Cin)); dy = f32(rng.randn(B, L, Cout)); w = np.zeros((5, Cin, Cout))
-    _, dw_ref, db_ref = K.conv1d_bwd(x, w, dy, 1, 'same')
-    dw, db = ops.conv1d_wgrad(g(x), g(dy), 5, 1, 2)
-    close(dw, dw_ref, 5e-5); close(db, db_ref, 5e-5)
-
-
 def test_conv1d_mfma_exact_integers():
     """A = small integers, B asymmetric integers: fp32 MFMA must be bit-exact (catches row/col swaps, tap mix-ups).  This is a statement about the
     DIRECT kernels (a k-ordered fmaf chain of integers is exact); the transform-domain kernel multiplies by G's sixths and fifteenths and is checked
@@ -551,30 +506,3 @@ def test_full_size_layers_spot_checked_against_the_definition(L, Cin, Cout, s, p
     assert np.abs(db - dy64.sum(axis=(0, 1))).max() <= 5e-5 * np.abs(db).max()
 
 
-def test_optin_eight_wave_stride2_tile_is_bit_identical_to_the_default():
-    """GN_CONV_WIDE8 (256 x 128 blocks of eight waves for the stride-2 forward: measured, not the default -- DESIGN section 6) is read once per
-    process, so the variant runs in a child process; both kernels walk channels, taps and k-steps in the same order: bit-identical output."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    from gennet_amd import ops
-    B, L, Cin, Cout, k, s = 16, 1018, 16, 1024, 5, 2                # 16 x 8 x 16 = 2048 wave tiles: the wide-wave (not the narrow) path
-    rng = np.random.RandomState(7)
-    x = rng.randn(B, L, Cin).astype(np.float32); w = (rng.randn(k, Cin, Cout) / np.sqrt(k * Cin)).astype(np.float32); b = rng.randn(Cout).astype(np.float32)
-    Lout, pl = ops.conv_geometry(L, k, s, 'valid')
-    y = ops.conv1d_fwd(g(x), g(w), g(b), s, pl, Lout).cpu().numpy()
-    with tempfile.TemporaryDirectory() as td:
-        np.savez(os.path.join(td, 'in.npz'), x=x, w=w, b=b)
-        code = ("import numpy as np, torch\nfrom gennet_amd import ops\nd = np.load(r'%s')\nt = lambda a: torch.tensor(a, device='cuda:0')\n"
-                "y = ops.conv1d_fwd(t(d['x']), t(d['w']), t(d['b']), %d, %d, %d).cpu().numpy()\nnp.save(r'%s', y)\n"
-                % (os.path.join(td, 'in.npz'), s, pl, Lout, os.path.join(td, 'out.npy')))
-        env = dict(os.environ, GN_CONV_WIDE8='1')
-        subprocess.run([sys.executable, '-c', code], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
-        y8 = np.load(os.path.join(td, 'out.npy'))
-    assert y.shape == y8.shape and np.array_equal(y, y8)
-    x64, w64 = x.astype(np.float64), w.astype(np.float64)
-    for _ in range(50):
-        bb, t, co = rng.randint(B), rng.randint(Lout), rng.randint(Cout)
-        acc = float(b[co]) + sum(x64[bb, s * t + kk - pl] @ w64[kk, :, co] for kk in range(k))
-        assert abs(y8[bb, t, co] - acc) <= 2e-5 * np.abs(y).max()

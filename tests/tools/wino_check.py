@@ -1,7 +1,7 @@
 """Development check + A/B timing of the transform-domain conv kernel (csrc/conv_wino.hip) against the fp64 oracle and the direct kernel.
-python scripts/wino_check.py [--bench]"""
+python tests/tools/wino_check.py [--bench]"""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np
 import torch
 from gennet_amd import ops
