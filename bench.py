@@ -176,6 +176,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='refdefaults: run the loop bodies eagerly instead of replaying captured hipGraphs')
     ap.add_argument('--predict-batch', type=int, default=0, help='chunk size of generator.predict for the fake half (0: the GAN batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--batch-scale', type=int, default=1, help='multiply the per-GPU batch sizes: `--gpus 1 --batch-scale N` runs the GLOBAL batch of an N-GPU '
+                                                                'job on one GPU -- its last_losses are what `--gpus N` prints (same draws, rank-tiled)')
     ap.add_argument('--opt-in', action='store_true', help='after the headline numbers are final, time the same K steps under the opt-in bf16-split conv math in a '
                                                           'CHILD process (its failure, hang or fault becomes opt_in.error; never part of value)')
     ap.add_argument('--no-opt-in', action='store_true', help='(accepted for old command lines; the extra leg is off unless --opt-in is given)')
@@ -199,14 +201,15 @@ def main():
         sys.stderr.write('bench.py: --gpus %d but the job has WORLD_SIZE=%s (world size %d)\n' % (args.gpus, os.environ.get('WORLD_SIZE'), world))
         sys.exit(2)
     wl = WORKLOADS[args.config]
-    N_PIX, CNN_BATCH, GAN_BATCH, WAVES = wl['n_pix'], wl['cnn_batch'], wl['gan_batch'], wl['waves']
+    N_PIX, CNN_BATCH, GAN_BATCH, WAVES = wl['n_pix'], wl['cnn_batch'] * args.batch_scale, wl['gan_batch'] * args.batch_scale, wl['waves'] * args.batch_scale
     predict_batch = args.predict_batch or GAN_BATCH
     graphed = bool(wl.get('graph')) and not args.no_graph and args.gpus == 1
     if args.config == 'refdefaults' and args.bank == 100000:
         args.bank = 50000                        # sample_num of gw_template_maker.py:60
     dev = engine.device()
     engine.set_init_seed(1)                     # identical initial weights on every rank
-    engine.set_device_seed(1000 + rank)         # per-rank dropout / latent / noise streams
+    engine.set_device_seed(1000)                # ONE device stream: every rank takes the counters of its rows of the global draw (latents, noise, dropout
+                                                # masks: engine.PhiloxStream.take_rows), so N ranks x B rows draw what one rank draws for N x B rows
     random.seed(1); np.random.seed(1)           # host index stream identical on all ranks; rank r keeps its slice
 
     # synthetic 2048-/4096-sample BBH segments: this project's FD chirp through an analytic aLIGO-like PSD (no LAL, no lalinference
@@ -215,7 +218,7 @@ def main():
     f = np.arange(N_PIX * 2 + 1) * 0.25
     psd = 1e-46 * ((np.maximum(f, 10.0) / 150.0) ** -4.0 + 2.0 + 2.0 * (f / 150.0) ** 2.0)
     psd[f < 10.0] = 0.0
-    synth = T.OnlineBank(N_PIX, 4, psd, seed=1000 + rank, noise=None)
+    synth = T.OnlineBank(N_PIX, 4, psd, seed=1000, noise=None)      # the stored bank: the SAME templates on every rank (ranks slice one index list)
     probe, _ = synth.draw(4096)
     synth.g = 1.0 / float(probe.std())
     del probe
@@ -368,7 +371,10 @@ def main():
                                       'every batch synthesised on the GPU inside the step: CNN rows = template + PSD-coloured noise whitened with the same PSD, one launch (prior -> chirp -> irFFT -> align -> crop -> gen_noise -> whiten_data(td) -> add); GAN real images = [noise-free template | coloured whitened noise], two launches' if wl['online']
                                       else '%d whitened BBH templates synthesised on the GPU into an HBM-resident bank before the timed region' % bank_n),
                        'name': args.config, 'n_pix': N_PIX, 'cnn_batch': CNN_BATCH, 'gan_batch': GAN_BATCH, 'predict_batch': predict_batch,
-                       'waveforms_per_step_per_gpu': WAVES, 'bank_rows': bank_n, 'parallelism': 'dp%d' % world, 'hipgraph_replay': graphed},
+                       'waveforms_per_step_per_gpu': WAVES, 'bank_rows': bank_n, 'parallelism': 'dp%d' % world, 'hipgraph_replay': graphed,
+                       'global_cnn_batch': CNN_BATCH * world, 'global_gan_batch': GAN_BATCH * world, 'batch_scale': args.batch_scale,
+                       'equivalence': 'losses are normalised by the GLOBAL batch and every random draw (host index list, device latents / noise / dropout masks) is '
+                                      'the rank slice of ONE global draw: `--gpus N` and `--gpus 1 --batch-scale N` print the same last_losses up to fp32 summation order'},
             'roofline': {'bound': 'mfma', 'kernel': 'Conv1D forward + data gradient on the fp32 matrix instructions: conv_wino_kernel (transform-domain F(2,5), unit-stride 5-tap '
                                                     'layers, v_mfma_f32_16x16x4_f32) + conv_mfma_pipe_kernel (direct implicit GEMM, v_mfma_f32_32x32x2_f32; + conv_mfma_dma_kernel / '
                                                     'conv_mfma_kernel for ragged or 1-tap shapes)',

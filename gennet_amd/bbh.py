@@ -205,6 +205,13 @@ def sample_indices(n, batch, rng=_pyrandom, rank=0, world=1):
     return idx[rank * batch:(rank + 1) * batch]
 
 
+def _draw_rows(fill, rows, row_len, rank, world, *args):
+    """fill((rows, row_len), *args, seed, offset, device) for this rank's rows [rank * rows, (rank + 1) * rows) of a global draw of world * rows
+    rows: the counters of ONE stream that every rank advances alike (engine.PhiloxStream.take_rows) -- N ranks draw what one process would."""
+    seed, offs = device_rng().take_rows(row_len, [(rank * rows, rows)], rows * world)
+    return fill((rows, row_len), *args, seed, offs[0], device())
+
+
 def pe_train_step(signal_pe, bank, batch, cnn_noise_frac=1.0 / 8.0, rng=_pyrandom, nprng=np.random, rank=0, world=1):
     """One iteration of the CNN loop, bbhMahoGANy.py:1155-1165.  Noise N(0, sigma), sigma ~ U(0,5) drawn once per batch
     on the host stream, is added to the first int(B*cnn_noise_frac) rows (the reference hard-codes the length 1024 at
@@ -212,12 +219,15 @@ def pe_train_step(signal_pe, bank, batch, cnn_noise_frac=1.0 / 8.0, rng=_pyrando
     it = bank.sample(batch, rng, rank, world)
     x = ops.gather_rows(bank.images, it)
     y = ops.gather_rows(bank.pars, it)
-    n_noisy = int(batch * cnn_noise_frac)
+    # the first int(B * frac) rows of the GLOBAL batch are the noisy ones (:1161); rank r holds global rows [r * batch, (r + 1) * batch)
+    n_noisy_global = int(batch * world * cnn_noise_frac)
+    n_noisy = max(0, min(batch, n_noisy_global - rank * batch))
     sigma = float(nprng.uniform(0, 5))
-    if n_noisy > 0:
-        seed, off = device_rng().take(n_noisy * bank.n_pix)
-        noise = ops.fill_normal((n_noisy, bank.n_pix), 0.0, sigma, seed, off, device())
-        ops.axpy(x[:n_noisy], noise, 1.0)
+    if n_noisy_global > 0:
+        seed, offs = device_rng().take_rows(bank.n_pix, [(rank * batch, n_noisy)] if n_noisy > 0 else [], n_noisy_global)
+        if n_noisy > 0:
+            noise = ops.fill_normal((n_noisy, bank.n_pix), 0.0, sigma, seed, offs[0], device())
+            ops.axpy(x[:n_noisy], noise, 1.0)
     return signal_pe.train_on_batch(x.reshape(batch, bank.n_pix, 1), [y[:, 0].contiguous(), y[:, 1].contiguous()])
 
 
@@ -264,18 +274,18 @@ def gan_train_step(nets, bank, event, batch, rng=_pyrandom, rank=0, world=1, pre
         real = real.repeat(int(n_noise_real), 1)                      # whole copies one after another, as np.concatenate builds them
         batch = batch * int(n_noise_real)
     n = real.shape[1]
-    seed, off = device_rng().take(batch * 100)
-    z = ops.fill_uniform((batch, 100), -1.0, 1.0, seed, off, device())
+    z = _draw_rows(ops.fill_uniform, batch, 100, rank, world, -1.0, 1.0)
     fake = nets.generator.predict_device(z, batch_size=predict_batch)                    # inference phase (:1248)
     if noise is None:
-        seed, off = device_rng().take(batch * n)
-        noise = ops.fill_normal((batch, n, 1), 0.0, 1.0, seed, off, device())
+        noise = _draw_rows(ops.fill_normal, batch, n, rank, world, 0.0, 1.0).reshape(batch, n, 1)
     elif tuple(noise.shape[:2]) != (batch, n):
         raise ValueError('gan_train_step: noise has shape %r, the real half has (%d, %d)' % (tuple(noise.shape), batch, n))
     sX, sy = assemble_discriminator_batch(real, noise, fake, event)
-    sd_loss = nets.signal_discriminator.train_on_batch(sX, sy)
-    seed, off = device_rng().take(batch * 100)
-    z = ops.fill_uniform((batch, 100), -1.0, 1.0, seed, off, device())
+    # rows of the global discriminator batch [real (world * batch) | fake REVERSED (world * batch)] this rank holds: its real rows, and -- its own fakes
+    # reversed are a contiguous run of the globally reversed fake half -- the mirrored rank's block of it
+    row_map = None if world == 1 else ([(rank * batch, batch), (world * batch + (world - 1 - rank) * batch, batch)], 2 * world * batch)
+    sd_loss = nets.signal_discriminator.train_on_batch(sX, sy, row_map=row_map)
+    z = _draw_rows(ops.fill_uniform, batch, 100, rank, world, -1.0, 1.0)
     sg_loss = nets.signal_discriminator_on_generator.train_on_batch(z, torch.ones(batch, device=device()))
     return [sg_loss[0], sg_loss[1], sd_loss[0], sd_loss[1]]
 

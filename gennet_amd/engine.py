@@ -170,6 +170,23 @@ class PhiloxStream(object):
         self.offset += (int(n_values) + 3) // 4
         return self.seed, off
 
+    def take_rows(self, row_len, blocks, global_rows):
+        """Counter ranges for (a rank's part of) a GLOBAL tensor of global_rows rows of row_len values each, the batch axis leading (SURVEY 8e:
+        "latent z and noise likewise" -- N ranks x B / N rows draw exactly what one process draws for B rows, same seed everywhere).
+        blocks = [(global_row_start, n_rows), ...]: the global rows this caller holds, in its local row order.  Returns (seed, [counter offset
+        of every block]); the stream advances by the counters of the WHOLE global tensor on every rank, whatever part a rank takes.
+        One block (0, global_rows) is take(global_rows * row_len)."""
+        row_len, global_rows = int(row_len), int(global_rows)
+        base = self.offset
+        self.offset += (global_rows * row_len + 3) // 4
+        offs = []
+        for g0, n in blocks:
+            if (int(g0) * row_len) % 4:
+                raise ValueError('PhiloxStream.take_rows: a block starting at global row %d of %d-value rows does not start on a Philox counter '
+                                 '(4 values each)' % (g0, row_len))
+            offs.append(base + int(g0) * row_len // 4)
+        return self.seed, offs
+
 
 _RNG = PhiloxStream(0)
 
@@ -287,8 +304,12 @@ def device_rng():
 
 
 class RunContext(object):
-    def __init__(self, training, dp=None, dropout_masks=None, train_params=None, site=None):
+    def __init__(self, training, dp=None, dropout_masks=None, train_params=None, site=None, row_map=None):
         self.training = training
+        # which rows of the GLOBAL batch this step's local rows are: [(global_row_start, n_rows), ...] in local order, and the global row count.
+        # Every per-row random draw inside the step (dropout masks) takes the counters of its global rows (PhiloxStream.take_rows), so N ranks
+        # draw what one process would.  None: the rows are the whole batch.
+        self.row_map = row_map
         self.site = site                   # name of the model whose train_on_batch runs (BatchNormalization keeps per-site state)
         self.capture = None                # testing hook: dict that receives {layer name: output tensor} of every executed node
         self.dp = dp
@@ -860,17 +881,19 @@ class Model(Layer):
         assert len(ys) == n_out, 'model has %d outputs' % n_out
         return [to_device(a).reshape(B, 1) for a in ys]
 
-    def train_on_batch(self, x, y, dropout_masks=None, capture=None):
+    def train_on_batch(self, x, y, dropout_masks=None, capture=None, row_map=None):
         """One optimizer step.  Returns [loss, (per-output losses,) (accuracies)] as python floats, keras order.
         `dropout_masks` ({dropout layer name: uint8 keep mask}) is a testing hook that replaces the Philox draws; `capture` (a dict) is
-        another: it receives {layer name: output tensor} of every executed layer (outputs include the fused activation / dropout)."""
+        another: it receives {layer name: output tensor} of every executed layer (outputs include the fused activation / dropout).
+        row_map (data parallelism): ([(global_row_start, n_rows), ...], global_rows) when the local rows are not the rank's contiguous slice
+        [rank * B, (rank + 1) * B) of the global batch (the default) -- the discriminator batch of bbh.gan_train_step."""
         xs = self._prep_inputs(x)
         B = xs[0].shape[0]
         ys = self._prep_targets(y, B)
-        stats = self.train_on_batch_device(xs, ys, dropout_masks, capture)
+        stats = self.train_on_batch_device(xs, ys, dropout_masks, capture, row_map)
         return self.train_result(stats, B)
 
-    def train_on_batch_device(self, xs, ys, dropout_masks=None, capture=None):
+    def train_on_batch_device(self, xs, ys, dropout_masks=None, capture=None, row_map=None):
         """train_on_batch on device tensors (inputs as the graph takes them, targets (B, 1)) without the final device -> host read: returns
         the (n_outputs, 2) device tensor [summed loss term, metric hits] that train_result turns into keras' list.  No host synchronisation
         anywhere in it, so the whole step can be captured into a hipGraph (engine.StepGraph)."""
@@ -881,7 +904,9 @@ class Model(Layer):
         dp = self.data_parallel
         world = dp.world_size if dp is not None else 1
         masks = {k: to_device(v, torch.uint8) for k, v in (dropout_masks or {}).items()}
-        ctx = RunContext(True, dp, masks, self._train_params, self.name)
+        if row_map is None and dp is not None and world > 1:
+            row_map = ([(dp.rank * B, B)], B * world)
+        ctx = RunContext(True, dp, masks, self._train_params, self.name, row_map)
         ctx.capture = capture
         outs = self._forward(xs, ctx)
         dps, stats = [], []

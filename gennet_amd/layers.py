@@ -349,9 +349,15 @@ class BatchNormalization(Layer):
         mask, rate = None, 0.0
         if node.fused_drop is not None and node.fused_drop[0] > 0.0:
             rate, drop_layer = node.fused_drop
-            if ctx.dropout_masks.get(drop_layer.name) is None and C % 4 == 0 and not _NO_DROPGEN:
-                # no injected mask: draw it inside the apply pass (same Philox stream as Dropout.make_mask would take)
-                seed, off = device_rng().take(x2.numel())
+            if ctx.dropout_masks.get(drop_layer.name) is None and C % 4 == 0 and not _NO_DROPGEN and (ctx.row_map is None or len(ctx.row_map[0]) == 1):
+                # no injected mask: draw it inside the apply pass (same Philox stream as Dropout.make_mask would take; under data parallelism the
+                # counters of this rank's rows of the global tensor)
+                if ctx.row_map is None:
+                    seed, off = device_rng().take(x2.numel())
+                else:
+                    (g0, nrows), grows = ctx.row_map[0][0], ctx.row_map[1]
+                    seed, offs = device_rng().take_rows(x2.numel() // nrows, [(g0, nrows)], grows)
+                    off = offs[0]
                 y, mask = ops.bn_apply_dropgen(x2, scale, shift, act[0], act[1], rate, seed, off)
                 ctx.tape[node.index] = (x2, mask, smean, sinv, count, act, rate, scale, shift)
                 return y.reshape(x.shape)
@@ -465,8 +471,17 @@ class Dropout(Layer):
         if inj is not None:
             return inj.reshape(shape).contiguous()
         n = int(np.prod(shape))
-        seed, off = device_rng().take(n)
-        return ops.dropout_mask(shape, self.rate, seed, off, device())
+        if ctx.row_map is None:
+            seed, off = device_rng().take(n)
+            return ops.dropout_mask(shape, self.rate, seed, off, device())
+        # data parallelism: the local rows are blocks of the global batch; every block draws the counters of its global rows
+        blocks, grows = ctx.row_map
+        if sum(nr for _, nr in blocks) != shape[0]:
+            raise ValueError('Dropout: the row map covers %d rows, the tensor has %d' % (sum(nr for _, nr in blocks), shape[0]))
+        row_len = n // shape[0]
+        seed, offs = device_rng().take_rows(row_len, blocks, grows)
+        parts = [ops.dropout_mask((nr,) + tuple(shape[1:]), self.rate, seed, off, device()) for (_, nr), off in zip(blocks, offs)]
+        return parts[0] if len(parts) == 1 else torch.cat(parts)
 
     def forward(self, ctx, node, x):
         if not ctx.training or self.rate == 0.0:

@@ -54,7 +54,7 @@ def main():
     dp = dist.init()
     rank, world = (dp.rank, dp.world_size) if dp else (0, 1)
     engine.set_init_seed(1)
-    engine.set_device_seed(1000 + rank)
+    engine.set_device_seed(1000)              # one device stream: every rank takes the counters of its rows of the global draw
     random.seed(1); np.random.seed(1)
 
     base = '%s%s' % (args.templates, args.event_name)

@@ -71,6 +71,27 @@ def run_cpu(out):
     random.seed(1)
     res['idx'] = [bbh.sample_indices(100000, 4096 // world, random, rank, world) for _ in range(3)]
     res['next'] = random.random()
+    # (4) device random draws tile ONE Philox stream (engine.PhiloxStream.take_rows; host-only bookkeeping, so it runs here): the counter ranges this
+    # rank takes for the draws of one CNN step + one GAN iteration at BASELINE configs[3]'s global batch 4096 (CNN noise rows, latents, noise column,
+    # the discriminator's and the generator's dropout masks) and where the stream stands afterwards
+    from gennet_amd import engine
+    st = engine.PhiloxStream(1000)
+    Bg, n_pix = 4096, 2048
+    b = Bg // world
+    rngs = []
+
+    def take(row_len, blocks, grows):
+        seed, offs = st.take_rows(row_len, blocks, grows)
+        rngs.append([(o, o + (nr * row_len + 3) // 4) for (g0, nr), o in zip(blocks, offs)])
+    n_noisy_g = Bg // 8
+    n_noisy = max(0, min(b, n_noisy_g - rank * b))
+    take(n_pix, [(rank * b, n_noisy)] if n_noisy else [], n_noisy_g)                         # CNN noise rows
+    take(100, [(rank * b, b)], Bg)                                                            # latents
+    take(n_pix, [(rank * b, b)], Bg)                                                          # noise column
+    take(n_pix // 2 * 2 * 256, [(rank * b, b), (Bg + (world - 1 - rank) * b, b)], 2 * Bg)     # D conv1 dropout on [real | fake reversed]
+    take(100, [(rank * b, b)], Bg)                                                            # second latent draw
+    take(256 * (n_pix // 2), [(rank * b, b)], Bg)                                             # G's first dropout
+    res['philox'] = {'ranges': rngs, 'end': st.offset}
     pickle.dump(res, open('%s.%d' % (out, rank), 'wb'))
     if dp:
         torch.distributed.barrier()
@@ -127,5 +148,32 @@ def run_gpu(out, backend='gloo'):
         torch.distributed.destroy_process_group()
 
 
+def run_gpu_public(out):
+    """The PUBLIC loop bodies (bbh.pe_train_step, bbh.gan_train_step: nothing injected -- host index stream, device latents, noise and dropout masks all
+    drawn inside) with N ranks x B / N rows against one rank x B rows: the draws of the ranks tile the single-process draws."""
+    from gennet_amd import bbh, dist, engine
+    dp = dist.init('gloo')
+    rank, world = (dp.rank, dp.world_size) if dp else (0, 1)
+    engine.set_init_seed(3)
+    engine.set_device_seed(77)                       # the same device stream on every rank
+    random.seed(5); np.random.seed(6)                # the same host streams on every rank
+    n_pix, B = 64, 8
+    rng = np.random.RandomState(11)
+    event = f32(rng.randn(n_pix, 1))
+    nets = bbh.build_and_compile(event, n_pix, data_parallel=dp)
+    bank = bbh.DeviceBank(f32(rng.randn(40, n_pix)), np.stack([rng.uniform(20, 35, 40), rng.uniform(0.5, 1, 40)], 1))
+    ev = engine.to_device(event.reshape(-1))
+    res = {'losses': []}
+    for it in range(2):
+        res['losses'].append(bbh.pe_train_step(nets.signal_pe, bank, B // world, cnn_noise_frac=0.5, rank=rank, world=world))
+        res['losses'].append(bbh.gan_train_step(nets, bank, ev, B // world, rank=rank, world=world, predict_batch=4))
+    res['rng_end'] = engine.device_rng().offset
+    res['weights'] = {'G': nets.generator.get_weights(), 'D': nets.signal_discriminator.get_weights(), 'PE': nets.signal_pe.get_weights()}
+    pickle.dump(res, open('%s.%d' % (out, rank), 'wb'))
+    if dp:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 if __name__ == '__main__':
-    {'cpu': run_cpu, 'gpu': run_gpu, 'rccl1': lambda out: run_gpu(out, 'nccl')}[sys.argv[1]](sys.argv[2])
+    {'cpu': run_cpu, 'gpu': run_gpu, 'gpu_public': run_gpu_public, 'rccl1': lambda out: run_gpu(out, 'nccl')}[sys.argv[1]](sys.argv[2])

@@ -62,6 +62,14 @@ def test_dp_math_over_gloo_cpu(tmp_path, single_process_cpu, world):
     assert np.allclose(sum(r['bn']['dgamma_local'] for r in two), one['bn']['dsum'][5:], rtol=1e-12)
     # host sampling: every rank advanced the stream identically; the rank slices, in rank order, ARE the single-process draw of 4096 rows
     assert all(r['next'] == one['next'] for r in two)
+    # device draws: every rank stands at the same stream position, the single process's; the ranks' counter ranges of every draw tile the global
+    # range without gap or overlap (the discriminator's mask in two blocks per rank: its real rows and the mirrored rank's block of the reversed fakes)
+    assert all(r['philox']['end'] == one['philox']['end'] for r in two)
+    for k, full in enumerate(one['philox']['ranges']):
+        parts = sorted(seg for r in two for seg in r['philox']['ranges'][k])
+        lo, hi = min(s[0] for s in full), max(s[1] for s in full)
+        assert parts[0][0] == lo and parts[-1][1] == hi, (k, parts[:2], full)
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:])), (k, parts)
     import random
     random.seed(1)
     for k in range(3):
@@ -92,6 +100,27 @@ def test_two_ranks_equal_one_rank_on_gpu(tmp_path):
     for name in ('G', 'D', 'PE'):
         for w0, w1 in zip(two[0]['weights'][name], two[1]['weights'][name]):
             assert np.array_equal(w0, w1)                   # replicas stay bit-identical
+
+
+@pytest.mark.gpu
+def test_public_loop_bodies_two_ranks_equal_one_rank(tmp_path):
+    """N ranks == 1 rank by construction, not statistically.  bbh.pe_train_step and bbh.gan_train_step with NOTHING injected: the two
+    ranks' index slices, CNN noise rows, latents, noise columns and dropout masks are the rank parts of the single process's draws (one host stream, one
+    Philox stream advanced by the global sizes), so every loss agrees to fp32 summation order and the weights as in the injected-input test above."""
+    one = launch('gpu_public', str(tmp_path / 'one'), 1)[0]
+    two = launch('gpu_public', str(tmp_path / 'two'), 2)
+    assert all(r['rng_end'] == one['rng_end'] for r in two)            # the device stream stands where the single process's stands
+    for r in two:
+        for a, b in zip(r['losses'], one['losses']):
+            assert len(a) == len(b)
+            for u, v in zip(a, b):
+                assert abs(u - v) <= 1e-5 * abs(v) + 1e-7, (r['losses'], one['losses'])
+        for name in ('G', 'D', 'PE'):
+            for w, wr in zip(r['weights'][name], one['weights'][name]):
+                diff = np.abs(w - wr)
+                bound = 1e-4 * np.abs(wr).max() + 0.02 * 2 * 9e-5
+                n_out = int((diff > bound).sum())
+                assert n_out <= max(1, int(1e-4 * diff.size)) and diff.max() <= 4 * 9e-5, (name, w.shape, n_out, float(diff.max()))
 
 
 @pytest.mark.gpu

@@ -59,12 +59,21 @@ def test_the_draws_of_one_cnn_step_and_one_gan_iteration_tile_the_stream():
         seed, off = plain(n_values)
         taken.append((off, int(n_values)))
         return seed, off
+    plain_rows = stream.take_rows
+
+    def recording_take_rows(row_len, blocks, global_rows):          # the loop bodies draw row-tiled (one block = the whole batch in a single process)
+        seed, offs = plain_rows(row_len, blocks, global_rows)
+        assert len(blocks) == 1 and blocks[0] == (0, global_rows) and offs[0] == stream.offset - (global_rows * row_len + 3) // 4
+        taken.append((offs[0], int(global_rows * row_len)))
+        return seed, offs
     stream.take = recording_take
+    stream.take_rows = recording_take_rows
     try:
         bbh.pe_train_step(nets.signal_pe, bank, B)
         bbh.gan_train_step(nets, bank, ev, B)
     finally:
         del stream.take
+        del stream.take_rows
     # consumers of one iteration: CNN noise rows; z, noise column, D's two dropout layers, z, G's six dropout layers + D's two inside the combined model
     assert len(taken) == 1 + 2 + 2 + 1 + 6 + 2, taken
     pos = 0
