@@ -96,7 +96,9 @@ def masks_by_name(stack, masks, layers):
 @pytest.mark.parametrize("n_pix,B,steps", [(128, 6, 3), (256, 5, 3),
                                           (1024, 4, 2),        # the reference script's own default n_pix (bbhMahoGANy.py:84)
                                           (2048, 4, 2),        # BASELINE configs 1-4 size: the 64 000- and 519 168-input Dense heads, 2048-row convs
-                                          (4096, 2, 1)])       # BASELINE config 5 size (129 536- and 1 043 456-input heads)
+                                          (4096, 2, 1),        # BASELINE config 5 size (129 536- and 1 043 456-input heads)
+                                          (2048, 64, 1)])      # round 5: a 64-row chunk at BASELINE size directly against the oracle -- the chunk
+                                                               # tests/test_bench_sizes_gpu.py compares the 256- / 512- / 1024-row launches of bench.py with
 def test_pe_train_on_batch_matches_oracle(n_pix, B, steps):
     from gennet_amd import bbh
     from gennet_amd.engine import Adam
@@ -160,8 +162,10 @@ def _build_gan(n_pix, rng):
 @pytest.mark.parametrize("n_pix,B,iters", [(64, 4, 2),
                                           (1024, 3, 1),        # the reference script's own default n_pix; odd batch
                                           (4096, 2, 1),        # BASELINE config 5 size: Dense(100 -> 524 288), 4096-row convs, 1 048 576-input head
-                                          (2048, 4, 1)])       # BASELINE size: Dense(100 -> 262 144) + feature-BN over B, the 524 288-input head,
+                                          (2048, 4, 1),        # BASELINE size: Dense(100 -> 262 144) + feature-BN over B, the 524 288-input head,
                                                                # channel-BN over 2048*B rows, fused dgrad epilogues, fold_bn predict inside the graph
+                                          (2048, 64, 1)])      # round 5: D step on 2 x 64 rows, G step on 64 rows at BASELINE size against
+                                                               # the oracle: closes the chain oracle <-> 64-row chunk <-> bench.py's batch sizes
 def test_gan_iteration_matches_oracle(n_pix, B, iters):
     """Full GAN iterations (bbhMahoGANy.py:1241-1299) with injected masks: D step on [real | fake], then G step through the
     frozen D; at the small size a second iteration exercises the moving statistics and both Adam states."""
