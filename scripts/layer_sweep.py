@@ -38,9 +38,13 @@ LAYERS = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--math', default=None, help="conv arithmetic: wino (the engine's default) | fp32 (direct kernels only) | bf16x3")
     a = ap.parse_args()
-    from gennet_amd import ops
-    dev = torch.device('cuda:0')
+    from gennet_amd import engine, ops
+    dev = engine.device()                 # sets the process's conv arithmetic (GENNET_CONV_MATH, 'wino' when unset), as every model does
+    if a.math:
+        ops.set_conv_math(a.math)
+    print('conv math: %s' % (a.math or ops.default_conv_math()))
     rows = []
     for name, B, L, cin, cout, k, s, padding, nf, nd, nw in LAYERS:
         x = torch.randn(B, L, cin, device=dev)

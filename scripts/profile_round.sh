@@ -7,6 +7,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 TAG=${1:-r01}
 python scripts/layer_sweep.py > gpurun_out/${TAG}_layer_sweep.txt 2>&1
+python scripts/layer_sweep.py --math fp32 > gpurun_out/${TAG}_layer_sweep_direct_kernels.txt 2>&1
 python bench.py --steps 4 --warmup 1 2> gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench.json.log
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_prof.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_pmc_fetch.log 2>&1
