@@ -454,7 +454,7 @@ def test_bench_line_with_the_opt_in_leg_keeps_the_headline_exact():
 def test_every_profile_the_readme_lists_is_committed():
     import re
     txt = open(os.path.join(ROOT, 'profiles', 'README.md')).read()
-    names = set(re.findall(r'`(r0[1-4]_[A-Za-z0-9_.]+\.(?:json|csv|txt|log))`', txt))
+    names = set(re.findall(r'`(r0[1-5]_[A-Za-z0-9_.]+\.(?:json|csv|txt|log))`', txt))
     assert len(names) > 40
     missing = sorted(n for n in names if not os.path.exists(os.path.join(ROOT, 'profiles', n)))
     assert not missing, missing
