@@ -110,6 +110,8 @@ static int conv_dispatch(const ConvArgs& a, hipStream_t s) {
   if (a.Cout <= 4) return conv_smallcout_dispatch(a, s);
   if (g_conv_math == 2 && a.Cin >= 32 && conv_wino_supported(a) && conv_wino_workspace_bytes(a.Cin, a.Cout) <= g_conv_ws_bytes)
     return conv_wino_run(a, g_conv_ws, g_conv_ws_bytes, s);
+  if (g_conv_math == 2 && conv_wino_s2_kind(a) == 1 && conv_wino_s2_workspace_bytes(a.Cin, a.Cout) <= g_conv_ws_bytes)
+    return conv_wino_s2_run(a, g_conv_ws, g_conv_ws_bytes, s);                 // stride-2 forward: F(2,3) + F(2,2)
   // size threshold of the opt-in split: the split pass costs ~10 bytes per input element per launch, the conv gains ~0.02 ps per element and output
   // channel, so small-Cout layers gain little and small-Cin layers (few K chunks) lose to the prologue
   constexpr int min_cin = 256, min_cout = 256;
@@ -369,6 +371,8 @@ static int dgrad_impl(const float* dy, const float* wt, float* dx, int B, int L,
     a.t.out_off_odd = 1 - (pad_left & 1);
     a.act = GN_ACT_LINEAR;
     a.gy = gy; a.gmask = gmask; a.gact = gact; a.gparam = gparam; a.gscale = 1.0f / (1.0f - grate);
+    if (g_conv_math == 2 && conv_wino_s2_kind(a) == 2 && conv_wino_s2_workspace_bytes(a.Cin, a.Cout) <= g_conv_ws_bytes)
+      return conv_wino_s2_run(a, g_conv_ws, g_conv_ws_bytes, (hipStream_t)stream);      // both phases in the transform domain: F(2,3) and F(2,2) over the same dy rows
     // opt-in split math: one launch for both phases where the 256-row blocks fill (the x fragments of tap pairs that read the same rows are read once)
     constexpr int min_cin = 256, min_cout = 256;
     static const bool no_merge = getenv("GN_BF16X3_NO_MERGE") != nullptr;            // A/B switch: the two phase launches (tests/test_bf16x3_gpu.py)

@@ -15,7 +15,7 @@ int check_launch(const char* what);
 // rng_base() = the device word every Philox kernel adds to its counter offset (NULL outside graph capture; gn_set_rng_base).
 const uint64_t* rng_base();
 void prof_begin(hipStream_t s);
-void prof_end(hipStream_t s, double flop, int kind, double bytes = 0.0);  // kind 0: conv_mfma (fwd, dgrad), 1: wgrad_mfma, 2: bf16x3 conv, 3: fused synthesiser, 4: fused noise chain, 5: transform-domain conv (flop = algorithmic), 6: transform-domain wgrad
+void prof_end(hipStream_t s, double flop, int kind, double bytes = 0.0);  // kind 0: conv_mfma (fwd, dgrad), 1: wgrad_mfma, 2: bf16x3 conv, 3: fused synthesiser, 4: fused noise chain, 5: transform-domain conv F(2,5) (flop = executed = 0.6 algorithmic), 6: transform-domain wgrad, 7: transform-domain stride-2 conv (0.7)
 
 
 // ---------------------------------------------------------------------------------------------
@@ -133,6 +133,10 @@ int conv_bf16x3_run_merged(const ConvArgs& a, void* ws, hipStream_t s);
 size_t conv_wino_workspace_bytes(int Cin, int Cout);
 bool conv_wino_supported(const ConvArgs& a);
 int conv_wino_run(const ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s);
+// conv_wino_s2.hip (the stride-2 5-tap layers: F(2,3) + F(2,2) on the even / odd rows; forward and the merged two-phase data gradient)
+size_t conv_wino_s2_workspace_bytes(int Cin, int Cout);
+int conv_wino_s2_kind(const ConvArgs& a);                 // 1 forward, 2 merged data gradient, 0 not supported
+int conv_wino_s2_run(const ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s);
 // wgrad_wino.hip (the transposed form for the weight gradient of the same layers)
 void wgrad_split_plan(int B, int M, int Cin, int Cout, int TC, int TN, int* splits, int* chunks_per_split);      // conv_mfma.hip: K-chunks of 32 rows
 bool wgrad_wino_supported(const WgradArgs& a);
