@@ -52,7 +52,7 @@ def pmc_traffic_per_launch(run_mix):
             continue
         ks = json.load(open(path))['kernels']
         direct = [v for k, v in ks.items() if 'conv_mfma' in k]          # conv_mfma_pipe_kernel, conv_mfma_dma_kernel, conv_mfma_kernel
-        wino = [v for k, v in ks.items() if 'conv_wino_kernel' in k]
+        wino = [v for k, v in ks.items() if 'conv_wino_kernel' in k or 'conv_wino_s2_kernel' in k]
         nd, nw = sum(v['launches'] for v in direct), sum(v['launches'] for v in wino)
         rd, rw = run_mix
         if nd + nw == 0 or rd + rw == 0 or abs(nw / float(nd + nw) - rw / float(rd + rw)) > 0.02:
@@ -283,7 +283,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    conv = ops.prof_collect(0); wgrad = ops.prof_collect(1); syn_in_step = ops.prof_collect(3); x3 = ops.prof_collect(2); wino = ops.prof_collect(5); wgwino = ops.prof_collect(6)
+    conv = ops.prof_collect(0); wgrad = ops.prof_collect(1); syn_in_step = ops.prof_collect(3); x3 = ops.prof_collect(2); wino = ops.prof_collect(5); wgwino = ops.prof_collect(6); wino2 = ops.prof_collect(7)
     last_losses = {'cnn [total, mc_loss, q_loss, mc_acc, q_acc]': [float(v) for v in last['cnn']],
                    'gan [sg_loss, sg_acc, sd_loss, sd_acc]': [float(v) for v in last['gan']]}
     bad = [k for k, v in last_losses.items() if not np.all(np.isfinite(v))]
@@ -349,12 +349,13 @@ def main():
         # transform-domain kernel of the unit-stride 5-tap layers (conv_wino.hip: 6 multiplies per two outputs instead of 10 -- it EXECUTES 0.6 of the
         # algorithmic count, which is what the library reports for it).  achieved / frac price EXECUTED flop against the matrix peak (so frac <= 1);
         # the algorithmic rate is reported beside it.
-        WINO_RATIO = 0.6
-        fam_ms = conv['ms'] + wino['ms']
-        fam_exec = conv['flop'] + wino['flop']
-        fam_alg = conv['flop'] + wino['flop'] / WINO_RATIO
+        WINO_RATIO, WINO2_RATIO = 0.6, 0.7     # F(2,5): 6 of 10 multiplies; stride-2 layers, F(2,3) + F(2,2): 7 of 10
+        fam_ms = conv['ms'] + wino['ms'] + wino2['ms']
+        fam_exec = conv['flop'] + wino['flop'] + wino2['flop']
+        fam_alg = conv['flop'] + wino['flop'] / WINO_RATIO + wino2['flop'] / WINO2_RATIO
+        n_td = wino['launches'] + wino2['launches']
         ach = fam_exec / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
-        traffic, traffic_src, traffic_why = pmc_traffic_per_launch((conv['launches'], wino['launches']))
+        traffic, traffic_src, traffic_why = pmc_traffic_per_launch((conv['launches'], n_td))
         syn_tbs = syn['bytes'] / (syn['ms'] * 1e-3) / 1e12 if syn['ms'] > 0 else 0.0
         out = {
             'metric': 'waveforms/sec (CNN+GAN step, %d-sample BBH)' % N_PIX, 'value': value, 'unit': 'waveforms/s',
@@ -383,10 +384,10 @@ def main():
                          'algorithmic_tflops': fam_alg / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0,
                          'traffic_note': traffic_why or ('fabric-side bytes per conv launch of both families (2*FETCH_SIZE + WRITE_SIZE KiB, gfx950 FETCH correction) from the '
                                                          'separate PMC passes of the default-config command summarised in %s (launch mix checked against this run)' % traffic_src),
-                         'launches': conv['launches'] + wino['launches'], 'avg_launch_ms': fam_ms / max(conv['launches'] + wino['launches'], 1),
-                         'executed_flop_per_launch': fam_exec / max(conv['launches'] + wino['launches'], 1),
-                         'algorithmic_flop_per_launch': fam_alg / max(conv['launches'] + wino['launches'], 1),
-                         'algorithmic_bytes_per_launch': (conv['bytes'] + wino['bytes']) / max(conv['launches'] + wino['launches'], 1),
+                         'launches': conv['launches'] + n_td, 'avg_launch_ms': fam_ms / max(conv['launches'] + n_td, 1),
+                         'executed_flop_per_launch': fam_exec / max(conv['launches'] + n_td, 1),
+                         'algorithmic_flop_per_launch': fam_alg / max(conv['launches'] + n_td, 1),
+                         'algorithmic_bytes_per_launch': (conv['bytes'] + wino['bytes'] + wino2['bytes']) / max(conv['launches'] + n_td, 1),
                          'direct_kernels': {'launches': conv['launches'], 'avg_launch_ms': conv['ms'] / max(conv['launches'], 1),
                                             'achieved': conv['flop'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0,
                                             'frac': (conv['flop'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0) / PEAK_F32_MFMA_TFLOPS},
@@ -395,6 +396,11 @@ def main():
                                                      'achieved_executed': wino['flop'] / (wino['ms'] * 1e-3) / 1e12 if wino['ms'] > 0 else 0.0,
                                                      'frac': (wino['flop'] / (wino['ms'] * 1e-3) / 1e12 if wino['ms'] > 0 else 0.0) / PEAK_F32_MFMA_TFLOPS,
                                                      'algorithmic_tflops': wino['flop'] / WINO_RATIO / (wino['ms'] * 1e-3) / 1e12 if wino['ms'] > 0 else 0.0,
+                                                     'stride2_kernel': {'kernel': 'conv_wino_s2_kernel: F(2,3) + F(2,2) on the even / odd rows of the stride-2 5-tap layers (forward and merged data gradient)',
+                                                                        'launches': wino2['launches'], 'avg_launch_ms': wino2['ms'] / max(wino2['launches'], 1),
+                                                                        'multiplies_executed_per_algorithmic': WINO2_RATIO,
+                                                                        'achieved_executed': wino2['flop'] / (wino2['ms'] * 1e-3) / 1e12 if wino2['ms'] > 0 else 0.0,
+                                                                        'algorithmic_tflops': wino2['flop'] / WINO2_RATIO / (wino2['ms'] * 1e-3) / 1e12 if wino2['ms'] > 0 else 0.0},
                                                      'note': 'F(2,5) on points {0, 1, -1, 1/2, -2, inf}: fp32 operands, fp32 products, 6 per output pair instead of 10; error against '
                                                              'fp64 1.2-1.4x the direct fp32 chain\'s (profiles/r05_winograd_gate1.txt); GENNET_CONV_MATH=fp32 runs the direct kernels everywhere'},
                          'wgrad_mfma_kernel': {'kernel': 'weight gradient: wgrad_wino_kernel (transform domain, the same unit-stride 5-tap layers) + wgrad_pipe_kernel / wgrad_mfma_kernel (direct)',
@@ -409,10 +415,10 @@ def main():
                                                                            'achieved_executed': wgwino['flop'] / (wgwino['ms'] * 1e-3) / 1e12 if wgwino['ms'] > 0 else 0.0,
                                                                            'algorithmic_tflops': wgwino['flop'] / WINO_RATIO / (wgwino['ms'] * 1e-3) / 1e12 if wgwino['ms'] > 0 else 0.0},
                                                'algorithmic_bytes_per_launch': (wgrad['bytes'] + wgwino['bytes']) / max(wgrad['launches'] + wgwino['launches'], 1)},
-                         'mfma_kernel_time_share': (conv['ms'] + wino['ms'] + wgrad['ms'] + wgwino['ms']) * 1e-3 / dt,
+                         'mfma_kernel_time_share': (conv['ms'] + wino['ms'] + wino2['ms'] + wgrad['ms'] + wgwino['ms']) * 1e-3 / dt,
                          'profiler_note': 'the per-launch figures come from HIP events the library records on the launch stream around every MFMA launch INSIDE the '
                                           'timed region (two hipEventRecord per launch, ~%d launches per step): their cost is included in value, i.e. counts '
-                                          'against this line' % ((conv['launches'] + wino['launches'] + wgrad['launches'] + wgwino['launches']) // max(args.steps, 1)),
+                                          'against this line' % ((conv['launches'] + n_td + wgrad['launches'] + wgwino['launches']) // max(args.steps, 1)),
                          'step_algorithmic_tflops': world * WAVES * args.steps * (wl['gflop_cnn'] + wl['gflop_gan']) * 1e-3 / dt},
             'roofline_synth': {'bound': 'valu_f64', 'kernel': 'synth_fused_kernel<.., NOISE=%s> (%s)' % (('true', 'gn_synth_templates_noise: prior + template + coloured whitened noise')
                                                                                                          if wl['online'] else ('false', 'gn_synth_templates_prior')),

@@ -181,21 +181,100 @@ def test_a_batch_and_its_chunks_agree_bit_for_bit_and_runs_repeat():
 
 
 def test_dispatch_leaves_everything_else_on_the_direct_kernels():
-    """Strided, 2-4-tap, narrow or ragged-channel launches never reach the transform-domain kernel; GENNET_CONV_MATH=fp32 / ops.set_conv_math('fp32') takes it out."""
+    """2-4-tap, narrow or ragged-channel launches never reach the transform-domain kernels; GENNET_CONV_MATH=fp32 / ops.set_conv_math('fp32') takes it out."""
     from gennet_amd import ops
     dev = torch.device('cuda:0')
     ops.prof_enable(True)
     try:
         with ops.conv_math('wino'):
-            for (Cin, Cout, k, s) in [(64, 128, 5, 2), (64, 128, 3, 1), (16, 128, 5, 1), (64, 96, 5, 1), (36, 64, 5, 1)]:
+            for (Cin, Cout, k, s) in [(16, 128, 5, 2), (64, 128, 3, 1), (16, 128, 5, 1), (64, 96, 5, 1), (36, 64, 5, 1)]:
                 ops.prof_reset()
                 L = 80
                 Lout, pl = ops.conv_geometry(L, k, s, 'same')
                 ops.conv1d_fwd(torch.randn(2, L, Cin, device=dev), torch.randn(k, Cin, Cout, device=dev), None, s, pl, Lout)
-                assert launches(5) == 0 and launches(0) == 1, (Cin, Cout, k, s)
+                assert launches(5) == 0 and launches(7) == 0 and launches(0) == 1, (Cin, Cout, k, s)
         with ops.conv_math('fp32'):
             ops.prof_reset()
             ops.conv1d_fwd(torch.randn(2, 80, 64, device=dev), torch.randn(5, 64, 128, device=dev), None, 1, 2, 80)
             assert launches(5) == 0 and launches(0) == 1
     finally:
         ops.prof_enable(False)
+
+
+# ---------------------------------------------------------------------------------------------- stride-2 layers: F(2,3) + F(2,2) (csrc/conv_wino_s2.hip)
+S2_CASES = [
+    # B, L, Cin, Cout, padding          (pad_left parity decides which output phase the 3-tap half of the data gradient writes and where the 2-tap rows start)
+    (2, 64, 64, 64, 'same'),            # pad_left 1
+    (3, 133, 64, 128, 'valid'),         # pad_left 0, odd lengths: ragged last output pair
+    (2, 151, 64, 64, 'same'),           # pad_left 2
+    (2, 150, 128, 256, 'same'),
+    (1, 300, 256, 128, 'valid'),
+    (2, 6, 64, 64, 'valid'),            # one output row
+    (2, 1024, 512, 1024, 'same'),       # the discriminator's folded second Conv2D (bbhMahoGANy.py:447), two elements
+    (1, 1018, 512, 1024, 'valid'),      # the q branch's Conv1D(1024, 5, strides=2) (:386)
+]
+
+
+@pytest.mark.parametrize("B,L,Cin,Cout,padding", S2_CASES)
+def test_stride2_forward_and_data_gradient(B, L, Cin, Cout, padding):
+    """A stride-2 5-tap convolution = a 3-tap + a 2-tap unit-stride convolution on the even / odd rows; its data gradient = two phases of 3 and 2 taps over
+    the same dy rows, one launch.  Seven multiplies per output pair instead of ten; the transforms are additions, so the error may not exceed the direct
+    kernel's by more than rounding noise (gate: 1.5 x rms; measured 0.6-0.9 x)."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(7 * L + B)
+    x = f32(rng.randn(B, L, Cin)); lim = np.sqrt(6.0 / (5 * (Cin + Cout)))
+    w = f32(rng.uniform(-lim, lim, (5, Cin, Cout))); b = f32(rng.randn(Cout) * 0.1)
+    Lout, pl = ops.conv_geometry(L, 5, 2, padding)
+    pre = K.conv1d_fwd(x, w, b, 2, padding)
+    ref = np.where(pre > 0, pre, float(np.float32(0.2)) * pre)
+    dy = f32(rng.randn(B, Lout, Cout))
+    dx_ref, _, _ = K.conv1d_bwd(x, w, dy, 2, padding)
+    wt = ops.conv1d_transpose_w(g(w))
+    y_prev = f32(np.maximum(rng.randn(B, L, Cin), 0.0))
+    out = {}
+    ops.prof_enable(True)
+    try:
+        for math in ('wino', 'fp32'):
+            with ops.conv_math(math):
+                ops.prof_reset()
+                y = ops.conv1d_fwd(g(x), g(w), g(b), 2, pl, Lout, 'leaky', 0.2)
+                dx = ops.conv1d_dgrad(g(dy), wt, L, 2, pl)
+                dxf = ops.conv1d_dgrad(g(dy), wt, L, 2, pl, prev=(g(y_prev), 'relu', 0.0, None, 0.0))
+                out[math] = (y, dx, dxf, launches(7))
+    finally:
+        ops.prof_enable(False)
+    assert out['wino'][3] == 3 and out['fp32'][3] == 0                 # forward, data gradient, fused data gradient took the transform-domain kernel
+    (mw, rw), (md, rd) = errs(out['wino'][0], ref), errs(out['fp32'][0], ref)
+    assert mw <= RTOL and (Lout < 16 or rw <= 1.5 * rd + 1e-8), (mw, rw, md, rd)
+    (mw, rw), (md, rd) = errs(out['wino'][1], dx_ref), errs(out['fp32'][1], dx_ref)
+    assert mw <= RTOL and (L < 16 or rw <= 1.5 * rd + 1e-8), (mw, rw, md, rd)
+    assert errs(out['wino'][2], dx_ref * (y_prev > 0))[0] <= RTOL
+    # a batch and its halves: the same kernel, bit for bit
+    if B >= 2:
+        with ops.conv_math('wino'):
+            h = B // 2
+            y2 = torch.cat([ops.conv1d_fwd(g(x[:h]), g(w), g(b), 2, pl, Lout, 'leaky', 0.2), ops.conv1d_fwd(g(x[h:]), g(w), g(b), 2, pl, Lout, 'leaky', 0.2)])
+        assert torch.equal(y2, out['wino'][0])
+
+
+def test_stride2_batchnorm_statistics_and_dropout_epilogue():
+    from gennet_amd import ops
+    rng = np.random.RandomState(19)
+    B, L, Cin, Cout = 3, 150, 64, 128
+    x = f32(rng.randn(B, L, Cin)); w = f32(rng.randn(5, Cin, Cout) * 0.05); b = f32(rng.randn(Cout))
+    Lout, pl = ops.conv_geometry(L, 5, 2, 'same')
+    pre = K.conv1d_fwd(x, w, b, 2, 'same')
+    keep = rng.rand(B, Lout, Cout) >= 0.4
+    ref = np.where(pre > 0, pre, float(np.float32(0.2)) * pre) * keep / float(np.float32(0.6))
+    ops.prof_enable(True); ops.prof_reset()
+    try:
+        with ops.conv_math('wino'):
+            y = ops.conv1d_fwd_dropout(g(x), g(w), g(b), g(keep, torch.uint8), 2, pl, Lout, 'leaky', 0.2, 0.4)
+            ys, sums = ops.conv1d_fwd_stats(g(x), g(w), g(b), 2, pl, Lout)
+            assert launches(7) == 2
+    finally:
+        ops.prof_enable(False)
+    assert errs(y, ref)[0] <= 2 * RTOL and errs(ys, pre)[0] <= RTOL
+    yh = ys.cpu().numpy().astype(np.float64).reshape(-1, Cout)
+    s = sums.cpu().numpy()
+    assert np.allclose(s[:Cout], yh.sum(0), rtol=1e-12, atol=1e-9) and np.allclose(s[Cout:], (yh * yh).sum(0), rtol=1e-12)
