@@ -283,7 +283,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    conv = ops.prof_collect(0); wgrad = ops.prof_collect(1); syn_in_step = ops.prof_collect(3); x3 = ops.prof_collect(2); wino = ops.prof_collect(5); wgwino = ops.prof_collect(6); wino2 = ops.prof_collect(7)
+    conv = ops.prof_collect(0); wgrad = ops.prof_collect(1); syn_in_step = ops.prof_collect(3); x3 = ops.prof_collect(2); wino = ops.prof_collect(5); wgwino = ops.prof_collect(6); wino2 = ops.prof_collect(7); wgwino2 = ops.prof_collect(8)
     last_losses = {'cnn [total, mc_loss, q_loss, mc_acc, q_acc]': [float(v) for v in last['cnn']],
                    'gan [sg_loss, sg_acc, sd_loss, sd_acc]': [float(v) for v in last['gan']]}
     bad = [k for k, v in last_losses.items() if not np.all(np.isfinite(v))]
@@ -354,6 +354,8 @@ def main():
         fam_exec = conv['flop'] + wino['flop'] + wino2['flop']
         fam_alg = conv['flop'] + wino['flop'] / WINO_RATIO + wino2['flop'] / WINO2_RATIO
         n_td = wino['launches'] + wino2['launches']
+        wg_td = {'launches': wgwino['launches'] + wgwino2['launches'], 'ms': wgwino['ms'] + wgwino2['ms'], 'flop': wgwino['flop'] + wgwino2['flop'],
+                 'alg': wgwino['flop'] / WINO_RATIO + wgwino2['flop'] / WINO2_RATIO, 'bytes': wgwino['bytes'] + wgwino2['bytes']}
         ach = fam_exec / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
         traffic, traffic_src, traffic_why = pmc_traffic_per_launch((conv['launches'], n_td))
         syn_tbs = syn['bytes'] / (syn['ms'] * 1e-3) / 1e12 if syn['ms'] > 0 else 0.0
@@ -403,22 +405,23 @@ def main():
                                                                         'algorithmic_tflops': wino2['flop'] / WINO2_RATIO / (wino2['ms'] * 1e-3) / 1e12 if wino2['ms'] > 0 else 0.0},
                                                      'note': 'F(2,5) on points {0, 1, -1, 1/2, -2, inf}: fp32 operands, fp32 products, 6 per output pair instead of 10; error against '
                                                              'fp64 1.2-1.4x the direct fp32 chain\'s (profiles/r05_winograd_gate1.txt); GENNET_CONV_MATH=fp32 runs the direct kernels everywhere'},
-                         'wgrad_mfma_kernel': {'kernel': 'weight gradient: wgrad_wino_kernel (transform domain, the same unit-stride 5-tap layers) + wgrad_pipe_kernel / wgrad_mfma_kernel (direct)',
-                                               'achieved': (wgrad['flop'] + wgwino['flop']) / ((wgrad['ms'] + wgwino['ms']) * 1e-3) / 1e12 if wgrad['ms'] + wgwino['ms'] > 0 else 0.0,
-                                               'frac': ((wgrad['flop'] + wgwino['flop']) / ((wgrad['ms'] + wgwino['ms']) * 1e-3) / 1e12 if wgrad['ms'] + wgwino['ms'] > 0 else 0.0) / PEAK_F32_MFMA_TFLOPS,
+                         'wgrad_mfma_kernel': {'kernel': 'weight gradient: wgrad_wino_kernel / wgrad_wino_s2_kernel (transform domain: the unit-stride and the stride-2 5-tap layers) + wgrad_pipe_kernel / wgrad_mfma_kernel (direct)',
+                                               'achieved': (wgrad['flop'] + wg_td['flop']) / ((wgrad['ms'] + wg_td['ms']) * 1e-3) / 1e12 if wgrad['ms'] + wg_td['ms'] > 0 else 0.0,
+                                               'frac': ((wgrad['flop'] + wg_td['flop']) / ((wgrad['ms'] + wg_td['ms']) * 1e-3) / 1e12 if wgrad['ms'] + wg_td['ms'] > 0 else 0.0) / PEAK_F32_MFMA_TFLOPS,
                                                'achieved_note': 'EXECUTED flop of both families / their summed launch time',
-                                               'algorithmic_tflops': (wgrad['flop'] + wgwino['flop'] / WINO_RATIO) / ((wgrad['ms'] + wgwino['ms']) * 1e-3) / 1e12 if wgrad['ms'] + wgwino['ms'] > 0 else 0.0,
-                                               'launches': wgrad['launches'] + wgwino['launches'], 'avg_launch_ms': (wgrad['ms'] + wgwino['ms']) / max(wgrad['launches'] + wgwino['launches'], 1),
+                                               'algorithmic_tflops': (wgrad['flop'] + wg_td['alg']) / ((wgrad['ms'] + wg_td['ms']) * 1e-3) / 1e12 if wgrad['ms'] + wg_td['ms'] > 0 else 0.0,
+                                               'launches': wgrad['launches'] + wg_td['launches'], 'avg_launch_ms': (wgrad['ms'] + wg_td['ms']) / max(wgrad['launches'] + wg_td['launches'], 1),
                                                'direct_kernels': {'launches': wgrad['launches'], 'avg_launch_ms': wgrad['ms'] / max(wgrad['launches'], 1),
                                                                   'achieved': wgrad['flop'] / (wgrad['ms'] * 1e-3) / 1e12 if wgrad['ms'] > 0 else 0.0},
-                                               'transform_domain_kernel': {'launches': wgwino['launches'], 'avg_launch_ms': wgwino['ms'] / max(wgwino['launches'], 1),
-                                                                           'achieved_executed': wgwino['flop'] / (wgwino['ms'] * 1e-3) / 1e12 if wgwino['ms'] > 0 else 0.0,
-                                                                           'algorithmic_tflops': wgwino['flop'] / WINO_RATIO / (wgwino['ms'] * 1e-3) / 1e12 if wgwino['ms'] > 0 else 0.0},
-                                               'algorithmic_bytes_per_launch': (wgrad['bytes'] + wgwino['bytes']) / max(wgrad['launches'] + wgwino['launches'], 1)},
-                         'mfma_kernel_time_share': (conv['ms'] + wino['ms'] + wino2['ms'] + wgrad['ms'] + wgwino['ms']) * 1e-3 / dt,
+                                               'transform_domain_kernels': {'launches': wg_td['launches'], 'avg_launch_ms': wg_td['ms'] / max(wg_td['launches'], 1),
+                                                                            'achieved_executed': wg_td['flop'] / (wg_td['ms'] * 1e-3) / 1e12 if wg_td['ms'] > 0 else 0.0,
+                                                                            'algorithmic_tflops': wg_td['alg'] / (wg_td['ms'] * 1e-3) / 1e12 if wg_td['ms'] > 0 else 0.0,
+                                                                            'stride2_launches': wgwino2['launches']},
+                                               'algorithmic_bytes_per_launch': (wgrad['bytes'] + wg_td['bytes']) / max(wgrad['launches'] + wg_td['launches'], 1)},
+                         'mfma_kernel_time_share': (conv['ms'] + wino['ms'] + wino2['ms'] + wgrad['ms'] + wg_td['ms']) * 1e-3 / dt,
                          'profiler_note': 'the per-launch figures come from HIP events the library records on the launch stream around every MFMA launch INSIDE the '
                                           'timed region (two hipEventRecord per launch, ~%d launches per step): their cost is included in value, i.e. counts '
-                                          'against this line' % ((conv['launches'] + n_td + wgrad['launches'] + wgwino['launches']) // max(args.steps, 1)),
+                                          'against this line' % ((conv['launches'] + n_td + wgrad['launches'] + wg_td['launches']) // max(args.steps, 1)),
                          'step_algorithmic_tflops': world * WAVES * args.steps * (wl['gflop_cnn'] + wl['gflop_gan']) * 1e-3 / dt},
             'roofline_synth': {'bound': 'valu_f64', 'kernel': 'synth_fused_kernel<.., NOISE=%s> (%s)' % (('true', 'gn_synth_templates_noise: prior + template + coloured whitened noise')
                                                                                                          if wl['online'] else ('false', 'gn_synth_templates_prior')),

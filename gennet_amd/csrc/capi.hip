@@ -424,6 +424,7 @@ size_t gn_conv1d_wgrad_workspace(int B, int L, int Cin, int Cout, int k, int str
   (void)L;
   size_t w = (Cin <= 4 || Cout <= 4) ? wgrad_small_workspace_bytes(B, Lout, Cin, Cout, k) : wgrad_workspace_bytes(B, Lout, Cin, Cout, k);
   if (k == 5 && stride == 1 && Cin % 64 == 0 && Cout % 64 == 0) w = std::max(w, wgrad_wino_workspace_bytes(B, Lout, Cin, Cout));      // six point slabs per split
+  if (k == 5 && stride == 2 && Cin % 64 == 0 && Cout % 64 == 0) w = std::max(w, wgrad_wino_s2_workspace_bytes(B, Lout, Cin, Cout));   // seven
   size_t b = bias_grad_ws((size_t)B * Lout, Cout);
   return (w > b ? w : b) + 256;
 }
@@ -448,6 +449,11 @@ int gn_conv1d_wgrad(const float* x, const float* dy, float* dw, float* db, void*
     a.db = db;
     if (g_conv_math == 2 && wgrad_wino_supported(a) && ws_bytes >= wgrad_wino_workspace_bytes(B, Lout, Cin, Cout)) {
       rc = wgrad_wino_run(a, dw, ws_bytes, s);                 // transform-domain weight gradient; the bias gradient takes the separate pass below
+      if (rc) return rc;
+      return db ? bias_grad(dy, db, (size_t)B * Lout, Cout, ws, ws_bytes, s) : GN_OK;
+    }
+    if (g_conv_math == 2 && wgrad_wino_s2_supported(a) && ws_bytes >= wgrad_wino_s2_workspace_bytes(B, Lout, Cin, Cout)) {
+      rc = wgrad_wino_s2_run(a, dw, ws_bytes, s);              // ... of a stride-2 layer
       if (rc) return rc;
       return db ? bias_grad(dy, db, (size_t)B * Lout, Cout, ws, ws_bytes, s) : GN_OK;
     }

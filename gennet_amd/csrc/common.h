@@ -15,7 +15,7 @@ int check_launch(const char* what);
 // rng_base() = the device word every Philox kernel adds to its counter offset (NULL outside graph capture; gn_set_rng_base).
 const uint64_t* rng_base();
 void prof_begin(hipStream_t s);
-void prof_end(hipStream_t s, double flop, int kind, double bytes = 0.0);  // kind 0: conv_mfma (fwd, dgrad), 1: wgrad_mfma, 2: bf16x3 conv, 3: fused synthesiser, 4: fused noise chain, 5: transform-domain conv F(2,5) (flop = executed = 0.6 algorithmic), 6: transform-domain wgrad, 7: transform-domain stride-2 conv (0.7)
+void prof_end(hipStream_t s, double flop, int kind, double bytes = 0.0);  // kind 0: conv_mfma (fwd, dgrad), 1: wgrad_mfma, 2: bf16x3 conv, 3: fused synthesiser, 4: fused noise chain, 5: transform-domain conv F(2,5) (flop = executed = 0.6 algorithmic), 6: transform-domain wgrad, 7: transform-domain stride-2 conv (0.7), 8: transform-domain stride-2 wgrad (0.7)
 
 
 // ---------------------------------------------------------------------------------------------
@@ -142,6 +142,10 @@ void wgrad_split_plan(int B, int M, int Cin, int Cout, int TC, int TN, int* spli
 bool wgrad_wino_supported(const WgradArgs& a);
 size_t wgrad_wino_workspace_bytes(int B, int M, int Cin, int Cout);
 int wgrad_wino_run(WgradArgs& a, float* dw, size_t ws_bytes, hipStream_t s);
+// wgrad_wino_s2.hip (... of the stride-2 layers: transposed F(2,3) + F(2,2))
+bool wgrad_wino_s2_supported(const WgradArgs& a);
+size_t wgrad_wino_s2_workspace_bytes(int B, int M, int Cin, int Cout);
+int wgrad_wino_s2_run(WgradArgs& a, float* dw, size_t ws_bytes, hipStream_t s);
 // wgrad_bf16x3.hip (the same split for the weight gradient, opt-in)
 size_t wgrad_bf16x3_workspace_bytes(int B, int M, int Cin, int Cout, int in_stride);
 bool wgrad_bf16x3_supported(const WgradArgs& a);

@@ -278,3 +278,43 @@ def test_stride2_batchnorm_statistics_and_dropout_epilogue():
     yh = ys.cpu().numpy().astype(np.float64).reshape(-1, Cout)
     s = sums.cpu().numpy()
     assert np.allclose(s[:Cout], yh.sum(0), rtol=1e-12, atol=1e-9) and np.allclose(s[Cout:], (yh * yh).sum(0), rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------- weight gradients (csrc/wgrad_wino.hip, csrc/wgrad_wino_s2.hip)
+WGRAD_CASES = [
+    # B, L, Cin, Cout, stride, padding
+    (2, 64, 64, 64, 1, 'same'), (3, 133, 64, 128, 1, 'valid'), (2, 301, 256, 128, 1, 'same'), (40, 517, 64, 64, 1, 'valid'),        # the last: several K splits
+    (2, 64, 64, 64, 2, 'same'), (3, 133, 64, 128, 2, 'valid'), (2, 151, 64, 64, 2, 'same'), (1, 300, 256, 128, 2, 'valid'), (2, 6, 64, 64, 2, 'valid'),
+    (40, 1018, 64, 128, 2, 'valid'),                                                                                                 # several K splits
+    (2, 1024, 512, 1024, 2, 'same'),                                                                                                 # bbhMahoGANy.py:447 folded, two elements
+]
+
+
+@pytest.mark.parametrize("B,L,Cin,Cout,stride,padding", WGRAD_CASES)
+def test_weight_gradient_against_oracle_and_direct_kernel(B, L, Cin, Cout, stride, padding):
+    """dW = G^T [ sum over rows (B^T x) * (A dy) ]: the transposed algorithm, per-point partial sums in fp32, the inverse transform and the sum over the K
+    splits in fp64 (one rounding per tap).  Unit stride: 6 multiplies per output pair instead of 10; stride 2: 7 instead of 10, additions only.  Against
+    the fp64 oracle to the direct kernel's tolerance, rms no worse than 1.5 x (stride 1: 4 x, Gate 1's bound) the direct kernel's; the bias gradient is a
+    separate fp64 pass; a repeat is bit-identical (fixed split plan, no atomics)."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(11 * L + B + stride)
+    x = f32(rng.randn(B, L, Cin))
+    Lout, pl = ops.conv_geometry(L, 5, stride, padding)
+    dy = f32(rng.randn(B, Lout, Cout))
+    _, dw_ref, db_ref = K.conv1d_bwd(x, np.zeros((5, Cin, Cout)), dy, stride, padding)
+    out = {}
+    ops.prof_enable(True)
+    try:
+        for math in ('wino', 'fp32'):
+            with ops.conv_math(math):
+                ops.prof_reset()
+                dw, db = ops.conv1d_wgrad(g(x), g(dy), 5, stride, pl)
+                dw2, _ = ops.conv1d_wgrad(g(x), g(dy), 5, stride, pl)
+                out[math] = (dw, db, launches(6 if stride == 1 else 8), launches(1))
+                assert torch.equal(dw, dw2)
+    finally:
+        ops.prof_enable(False)
+    assert out['wino'][2] == 2 and out['wino'][3] == 0 and out['fp32'][2] == 0 and out['fp32'][3] == 2
+    (mw, rw), (md, rd) = errs(out['wino'][0], dw_ref), errs(out['fp32'][0], dw_ref)
+    assert mw <= RTOL and rw <= (4.0 if stride == 1 else 1.5) * rd + 1e-8, (mw, rw, md, rd)
+    assert errs(out['wino'][1], db_ref)[0] <= 1e-6

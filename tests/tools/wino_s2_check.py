@@ -1,5 +1,5 @@
 """Development check + A/B timing of the stride-2 transform-domain kernels (csrc/conv_wino_s2.hip) against the fp64 oracle and the direct kernels.
-python tests/tools/wino_s2_check.py [--bench]"""
+python tests/tools/wino_s2_check.py [--bench] [--wgrad]"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np
@@ -58,6 +58,59 @@ def bench(B, L, Cin, Cout, padding, reps=5):
         print('%-5s B %d L %d %d->%d: direct %.3f ms (%.1f) | transform domain %.3f ms (%.1f algorithmic TFLOP/s)  x%.3f'
               % (what, B, L, Cin, Cout, out['fp32'], fl / out['fp32'] / 1e9, out['wino'], fl / out['wino'] / 1e9, out['fp32'] / out['wino']), flush=True)
 
+
+def check_wgrad(B, L, Cin, Cout, padding, seed=0):
+    rng = np.random.RandomState(seed + L)
+    x = rng.randn(B, L, Cin).astype(np.float32)
+    Lout, pl = ops.conv_geometry(L, 5, 2, padding)
+    dy = rng.randn(B, Lout, Cout).astype(np.float32)
+    w0 = np.zeros((5, Cin, Cout))
+    _, dw_ref, db_ref = K.conv1d_bwd(x.astype(np.float64), w0, dy.astype(np.float64), 2, padding)
+    xd, dyd = torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev)
+    res = {}
+    for math in ('wino', 'fp32'):
+        with ops.conv_math(math):
+            ops.prof_enable(True); ops.prof_reset()
+            dw, db = ops.conv1d_wgrad(xd, dyd, 5, 2, pl)
+            n8 = ops.prof_collect(8)['launches']
+            ops.prof_enable(False)
+        res[math] = (dw.cpu().numpy(), db.cpu().numpy(), n8)
+    s = np.sqrt(np.mean(dw_ref ** 2))
+    e = {m: (np.abs(res[m][0] - dw_ref).max() / s, np.sqrt(np.mean((res[m][0] - dw_ref) ** 2)) / s) for m in res}
+    eb = np.abs(res['wino'][1] - db_ref).max() / np.abs(db_ref).max()
+    print('wgrad B %d L %d %d->%d %s pl %d: launches %d | max %.2e rms %.2e (direct %.2e %.2e) | db %.1e'
+          % (B, L, Cin, Cout, padding, pl, res['wino'][2], e['wino'][0], e['wino'][1], e['fp32'][0], e['fp32'][1], eb), flush=True)
+    assert res['wino'][2] == 1 and e['wino'][0] < 5e-5 and eb < 1e-5, 'stride-2 transform-domain weight gradient wrong'
+
+
+def bench_wgrad(B, L, Cin, Cout, padding, reps=5):
+    x = torch.randn(B, L, Cin, device=dev)
+    Lout, pl = ops.conv_geometry(L, 5, 2, padding)
+    dy = torch.randn(B, Lout, Cout, device=dev)
+    out = {}
+    for math in ('fp32', 'wino'):
+        with ops.conv_math(math):
+            fn = lambda: ops.conv1d_wgrad(x, dy, 5, 2, pl)
+            fn(); fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            out[math] = e0.elapsed_time(e1) / reps
+    fl = 2.0 * B * Lout * 5 * Cin * Cout
+    print('wgrad B %d L %d %d->%d: direct %.3f ms (%.1f) | transform domain %.3f ms (%.1f algorithmic TFLOP/s)  x%.3f'
+          % (B, L, Cin, Cout, out['fp32'], fl / out['fp32'] / 1e9, out['wino'], fl / out['wino'] / 1e9, out['fp32'] / out['wino']), flush=True)
+
+
+if __name__ == '__main__' and '--wgrad' in sys.argv:
+    for args in [(2, 64, 64, 64, 'same'), (3, 133, 64, 128, 'valid'), (2, 150, 128, 256, 'same'), (2, 151, 64, 64, 'same'), (1, 300, 256, 128, 'valid'), (7, 1024, 128, 64, 'same'),
+                 (5, 37, 64, 64, 'same'), (2, 6, 64, 64, 'valid'), (40, 1018, 64, 128, 'valid')]:
+        check_wgrad(*args)
+    if '--bench' in sys.argv:
+        bench_wgrad(1024, 1024, 512, 1024, 'same'); bench_wgrad(512, 1024, 512, 1024, 'same'); bench_wgrad(256, 1018, 512, 1024, 'valid'); bench_wgrad(256, 2040, 256, 512, 'valid')
+        bench_wgrad(256, 4084, 128, 256, 'valid'); bench_wgrad(256, 8192, 64, 128, 'valid')
+    sys.exit(0)
 
 if __name__ == '__main__':
     for args in [(2, 64, 64, 64, 'same'), (3, 133, 64, 128, 'valid'), (2, 150, 128, 256, 'same'), (2, 151, 64, 64, 'same'), (1, 300, 256, 128, 'valid'), (2, 1024, 512, 1024, 'same'),
