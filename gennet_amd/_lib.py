@@ -26,6 +26,11 @@ _SIGS = {
     'gn_conv1d_wgrad': [vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'gn_conv2d_w2_fold': [vp, vp, vp, vp, i32, i32, i32, vp],
     'gn_conv2d_w2_unfold_grad': [vp, vp, vp, vp, i32, i32, i32, vp],
+    'gn_conv1d_tapfold_x': [vp, vp, i32, i32, i32, i32, i32, vp],
+    'gn_conv1d_tapunfold_dx': [vp, vp, i32, i32, i32, i32, i32, vp],
+    'gn_conv1d_tapfold_w': [vp, vp, i32, i32, i32, vp],
+    'gn_conv1d_tapunfold_dw': [vp, vp, i32, i32, i32, vp],
+    'gn_conv1d_tap_groups': [i32, vp, vp],
     'gn_conv1d_up2_fold': [vp, vp, vp, vp, i32, i32, i32, vp],
     'gn_conv1d_up2_unfold_grad': [vp, vp, vp, vp, i32, i32, i32, vp],
     'gn_dense_fwd': [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],

@@ -42,10 +42,10 @@ class Config(object):
             setattr(self, k, v)
 
 
-def generator_model(n_pix=1024):
-    """bbhMahoGANy.py:212-295."""
+def generator_model(n_pix=1024, filtsize=5):
+    """bbhMahoGANy.py:212-295.  filtsize: the reference's edit-the-file knob (:228, `filtsize = 5 # 10 is best`); 1..10."""
     model = Sequential(name='generator')
-    act, momentum, drate, padding, weights, filtsize = 'tanh', 0.99, 0.2, 'same', 'glorot_uniform', 5
+    act, momentum, drate, padding, weights = 'tanh', 0.99, 0.2, 'same', 'glorot_uniform'
     model.add(Dense(256 * 1 * int(n_pix / 2), kernel_initializer=weights, input_shape=(100,)))
     model.add(BatchNormalization(momentum=momentum))
     model.add(Activation(act))
@@ -60,7 +60,7 @@ def generator_model(n_pix=1024):
         model.add(Dropout(drate))
     model.add(Conv1D(1, filtsize, padding=padding))
     model.add(Activation('linear'))
-    model._config = ('generator_model', n_pix)
+    model._config = ('generator_model', n_pix, filtsize)
     return model
 
 
@@ -138,9 +138,8 @@ def set_trainable(model, trainable):
 
 
 def model_from_config(cfg):
-    name, n_pix = cfg
     return {'generator_model': generator_model, 'signal_pe_model': signal_pe_model,
-            'signal_discriminator_model': signal_discriminator_model}[name](n_pix)
+            'signal_discriminator_model': signal_discriminator_model}[cfg[0]](*cfg[1:])
 
 
 class Nets(object):
@@ -157,12 +156,12 @@ def chisquare_loss(n_sig=1.0):
     return chisquare_Loss
 
 
-def build_and_compile(noise_signal, n_pix, lr=9e-5, do_pe=True, data_parallel=None, chi_loss=False, n_sig=1.0):
+def build_and_compile(noise_signal, n_pix, lr=9e-5, do_pe=True, data_parallel=None, chi_loss=False, n_sig=1.0, filtsize=5):
     """bbhMahoGANy.py:1089-1119, in the reference's order (the order fixes which weights each compiled model trains):
     the combined model is compiled while the discriminator is frozen, the discriminator after it is unfrozen.
-    chi_loss (:97, :1106-1109): the combined model trains on chisquare_Loss instead of binary cross-entropy."""
+    chi_loss (:97, :1106-1109): the combined model trains on chisquare_Loss instead of binary cross-entropy; filtsize (:228): the generator's filter size."""
     nets = Nets()
-    nets.generator = generator_model(n_pix)
+    nets.generator = generator_model(n_pix, filtsize)
     nets.signal_discriminator = signal_discriminator_model(n_pix)
     nets.data_subtraction = data_subtraction_model(noise_signal, n_pix)
     nets.signal_pe = signal_pe_model(n_pix) if do_pe else None

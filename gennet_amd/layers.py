@@ -123,11 +123,20 @@ class Conv1D(Layer):
         if self.stride < 1 or (Cin > 4 and self.stride > 2):
             raise NotImplementedError('Conv1D(strides=%d) on %d input channels: the matrix-core kernels implement strides 1 and 2 '
                                       '(any stride >= 1 runs for <= 4 input channels)' % (self.stride, Cin))
+        if not 1 <= self.k <= 40:
+            raise NotImplementedError('Conv1D(kernel_size=%d): 1..40 taps (bbhMahoGANy.py:228 names 5 and 10)' % self.k)
         self.kernel = self.add_weight('kernel', glorot_uniform((self.k, Cin, self.filters)))
         self.bias = self.add_weight('bias', np.zeros(self.filters, np.float32))
 
     def compute_output_shape(self, input_shape):
         return (ops.conv_geometry(input_shape[0], self.k, self.stride, self.padding)[0], self.filters)
+
+    def _tap_fold(self, x, w):
+        """More than 5 taps (`filtsize = 5 # 10 is best`, bbhMahoGANy.py:228) run as G = ceil(k/5) groups of h = ceil(k/G) taps over the input with its
+        shifted copies as further channel groups (csrc/tap_fold.hip): the same <= 5-tap matrix-core kernels, the tap groups accumulating in their K loop.
+        -> (x2, w2, (L, pad_left))"""
+        _, pl = ops.conv_geometry(x.shape[1], self.k, self.stride, self.padding)
+        return ops.conv1d_tapfold_x(x, self.k, pl), ops.conv1d_tapfold_w(w), (x.shape[1], pl)
 
     @property
     def can_fold_bn(self):
@@ -147,6 +156,8 @@ class Conv1D(Layer):
         (2L, filters) output in memory."""
         if getattr(node, 'fold_up', None) is None:
             Lout, pl = ops.conv_geometry(x.shape[1], self.k, self.stride, self.padding)
+            if self.k > 5:                  # w is the tap-folded kernel, x will be (forward: _tap_fold)
+                return w, b, ops.tap_groups(self.k)[1], self.stride, 0, Lout, self.filters
             return w, b, self.k, self.stride, pl, Lout, self.filters
         wf, bf = ops.conv1d_up2_fold(w, b, self.stride)
         return wf, bf, 3, 1, 1, x.shape[1], wf.shape[2]
@@ -162,11 +173,21 @@ class Conv1D(Layer):
             bn = bn_node.layer
             scale, shift = ops.bn_infer_coeffs(bn.gamma.data, bn.beta.data, bn.moving_mean.data, bn.moving_variance.data, bn.epsilon)
             w2, b2 = ops.conv_fold_bn(self.kernel.data, self.bias.data, scale, shift)
-            w2, b2, _, stride, pl, Lout, _ = self._geometry(node, x, w2, b2)
+            xin = x
+            if self.k > 5:
+                x, w2, _ = self._tap_fold(x, w2)
+            w2, b2, _, stride, pl, Lout, _ = self._geometry(node, xin, w2, b2)
             act = bn_node.fused_act or ('linear', 0.0)
             ctx.skip.add(bn_node.index)
             return ops.conv1d_fwd(x, w2, b2, stride, pl, Lout, act[0], act[1]).view(B, -1, self.filters)
-        w, b, k, stride, pl, Lout, Ce = self._geometry(node, x, self.kernel.data, self.bias.data)
+        tf = None
+        if self.k > 5:
+            xin = x
+            x, w2, tf = self._tap_fold(x, self.kernel.data)
+            w, b, k, stride, pl, Lout, Ce = self._geometry(node, xin, w2, self.bias.data)
+            tf = tf + (w2,)
+        else:
+            w, b, k, stride, pl, Lout, Ce = self._geometry(node, x, self.kernel.data, self.bias.data)
         fused_drop = node.fused_drop is not None and self.filters > 4
         if node.fused_drop is not None and not fused_drop:
             raise NotImplementedError('Dropout directly after a Conv1D with <= 4 filters')
@@ -176,18 +197,28 @@ class Conv1D(Layer):
             # form, whose columns are (phase, channel): that BN layer runs its own statistics pass.)
             y, sums = ops.conv1d_fwd_stats(x, w, b, stride, pl, Lout)
             ctx.bn_sums[bn_node.index] = sums
-            ctx.tape[node.index] = (x, y, a, pl, None, 0.0, w if fold else None)
+            ctx.tape[node.index] = (x, y, a, pl, None, 0.0, w if fold else None, tf)
             return y
         y, mask, rate = _conv_fwd(node, ctx, x, w, b, stride, pl, Lout, a, (B, Lout, Ce))
-        ctx.tape[node.index] = (x, y, a, pl, mask, rate, w if fold else None)       # y, mask in the shape of the conv that ran
+        ctx.tape[node.index] = (x, y, a, pl, mask, rate, w if fold else None, tf)   # x, y, mask in the shape of the conv that ran
         y = y.view(B, -1, self.filters)
         if ctx.training and (a[0] != 'linear' or mask is not None):
             ctx.epi[node.index] = (y, a[0], a[1], None if mask is None else mask.view(y.shape), rate)
         return y
 
     def backward(self, ctx, node, dy, need_dx, need_dw, prev=None):
-        x, y, a, pl, mask, rate, wf = ctx.tape.pop(node.index)
+        x, y, a, pl, mask, rate, wf, tf = ctx.tape.pop(node.index)
         dy = _conv_bwd_epilogue(dy.contiguous().view(y.shape), y, a, mask, rate, ctx, node)
+        if tf is not None:
+            # more than 5 taps: the gradients of the h-tap conv over (x, shifted x, ...) that ran, unfolded (csrc/tap_fold.hip)
+            L0, pl0, w2 = tf
+            if need_dw:
+                dw2, _ = ops.conv1d_wgrad(x, dy, w2.shape[0], self.stride, 0, None, self.bias.grad)
+                ops.conv1d_tapunfold_dw(dw2, self.k, self.kernel.grad)
+            if need_dx:
+                dx2 = ops.conv1d_dgrad(dy, ops.conv1d_transpose_w(w2), x.shape[1], self.stride, 0, None)
+                return ops.conv1d_tapunfold_dx(dx2, L0, self.k, pl0)
+            return None
         if need_dw:
             if wf is None:
                 ops.conv1d_wgrad(x, dy, self.k, self.stride, pl, self.kernel.grad, self.bias.grad)

@@ -199,6 +199,51 @@ def conv2d_w2_unfold_grad(dwf, dbf, Cin, Cout, dw=None, db=None):
     return dw, db
 
 
+def tap_groups(k):
+    """(G, h): a k-tap Conv1D (k > 5) runs as G = ceil(k/5) tap groups of h = ceil(k/G) taps (gn_conv1d_tap_groups, csrc/tap_fold.hip)."""
+    G = (k + 4) // 5
+    return G, (k + G - 1) // G
+
+
+def conv1d_tapfold_x(x, k, pl):
+    """More than 5 taps as h taps over G*Cin channels (csrc/tap_fold.hip): the input with its shifted copies beside it, left padding materialised."""
+    _chk(x)
+    B, L, Cin = x.shape
+    x2 = torch.empty((B, L + pl, tap_groups(k)[0] * Cin), dtype=torch.float32, device=x.device)
+    _lib.call('gn_conv1d_tapfold_x', _p(x), _p(x2), B, L, Cin, k, pl, _stream())
+    return x2
+
+
+def conv1d_tapunfold_dx(dx2, L, k, pl):
+    _chk(dx2)
+    B, L2, C2 = dx2.shape
+    G = tap_groups(k)[0]
+    assert L2 == L + pl and C2 % G == 0
+    dx = torch.empty((B, L, C2 // G), dtype=torch.float32, device=dx2.device)
+    _lib.call('gn_conv1d_tapunfold_dx', _p(dx2), _p(dx), B, L, C2 // G, k, pl, _stream())
+    return dx
+
+
+def conv1d_tapfold_w(w):
+    _chk(w)
+    k, Cin, Cout = w.shape
+    G, h = tap_groups(k)
+    w2 = torch.empty((h, G * Cin, Cout), dtype=torch.float32, device=w.device)
+    _lib.call('gn_conv1d_tapfold_w', _p(w), _p(w2), k, Cin, Cout, _stream())
+    return w2
+
+
+def conv1d_tapunfold_dw(dw2, k, dw=None):
+    _chk(dw2, dw)
+    h, C2, Cout = dw2.shape
+    G, hh = tap_groups(k)
+    assert h == hh and C2 % G == 0
+    if dw is None:
+        dw = torch.empty((k, C2 // G, Cout), dtype=torch.float32, device=dw2.device)
+    _lib.call('gn_conv1d_tapunfold_dw', _p(dw2), _p(dw), k, C2 // G, Cout, _stream())
+    return dw
+
+
 def conv1d_up2_fold(w, b, stride):
     """UpSampling1D(2) -> Conv1D(5, 'same', stride) as a 3-tap stride-1 conv on the un-upsampled input (gn_conv1d_up2_fold)."""
     _chk(w, b)

@@ -108,6 +108,20 @@ int gn_conv1d_wgrad(const float* x, const float* dy, float* dw, float* db, void*
  * unfold_grad: dw[kh,kw,c,c2] = sum over the (w,w2) blocks with w-w2+2 == kw (0 for kw in {0,4}); db = dbf[:Cout]+dbf[Cout:] */
 int gn_conv2d_w2_fold(const float* w, const float* bias, float* wf, float* biasf, int kh, int Cin, int Cout, void* stream);
 int gn_conv2d_w2_unfold_grad(const float* dwf, const float* dbf, float* dw, float* db, int kh, int Cin, int Cout, void* stream);
+/* Conv1D with 6 <= k <= 40 taps (`filtsize = 5 # 10 is best`, bbhMahoGANy.py:228, the Conv1D(.., filtsize, ..) of :250-292; the 16-tap layers of the
+ * reference's saved Keras models) as an h-tap convolution over G*Cin channels with pad_left 0 (csrc/tap_fold.hip), G = ceil(k/5) groups of h = ceil(k/G)
+ * taps (gn_conv1d_tap_groups): every further tap group becomes a further group of input channels over the input shifted by g*h rows, so the <= 5-tap
+ * kernels above run it and accumulate the groups in their own K loop.
+ *   gn_conv1d_tapfold_x:    x (B, L, Cin) -> x2 (B, L + pad_left, G*Cin), x2[b, j, g*Cin:(g+1)*Cin] = x[b, j - pad_left + g*h] (0 outside the input)
+ *   gn_conv1d_tapfold_w:    w (k, Cin, Cout) -> w2 (h, G*Cin, Cout), w2[t, g*Cin:(g+1)*Cin] = w[t + g*h] (zero taps where t + g*h >= k)
+ *   gn_conv1d_tapunfold_dw: the inverse, for the weight gradient: dw2 (h, G*Cin, Cout) -> dw (k, Cin, Cout)
+ *   gn_conv1d_tapunfold_dx: dx2 (B, L + pad_left, G*Cin) -> dx (B, L, Cin), dx[b, l] = sum_g dx2[b, l + pad_left - g*h, g*Cin:(g+1)*Cin]
+ * Then y = gn_conv1d_fwd*(x2, w2, bias, k' = h, stride, pad_left' = 0, L' = L + pad_left, Cin' = G*Cin) with the layer's own Lout. */
+int gn_conv1d_tap_groups(int k, int* groups, int* taps);
+int gn_conv1d_tapfold_x(const float* x, float* x2, int B, int L, int Cin, int k, int pad_left, void* stream);
+int gn_conv1d_tapunfold_dx(const float* dx2, float* dx, int B, int L, int Cin, int k, int pad_left, void* stream);
+int gn_conv1d_tapfold_w(const float* w, float* w2, int k, int Cin, int Cout, void* stream);
+int gn_conv1d_tapunfold_dw(const float* dw2, float* dw, int k, int Cin, int Cout, void* stream);
 
 /* ---- UpSampling1D(2) -> Conv1D(C, 5, strides=s, padding='same') fold (bbhMahoGANy.py:249-250 s=2, :258-259 s=1) ----
  * The pair equals a 3-tap stride-1 'same' conv (pad_left 1) on the UN-upsampled input x (B, L, Cin), so the upsampled tensor is

@@ -23,14 +23,14 @@ LEAKY_ALPHA = float(np.float32(0.2))     # LeakyReLU(alpha=0.2) as Keras holds i
 # ----------------------------------------------------------------------------------------------
 # layer specs
 # ----------------------------------------------------------------------------------------------
-def generator_spec(n_pix):
+def generator_spec(n_pix, filtsize=5):
     L = [('dense', 100, 256 * (n_pix // 2)), ('bn', 256 * (n_pix // 2)), ('act', 'tanh', 0.0), ('drop', 0.2),
          ('reshape', (n_pix // 2, 256)),
-         ('up', 2), ('conv1d', 256, 64, 5, 2, 'same'), ('bn', 64), ('act', 'tanh', 0.0), ('drop', 0.2),
-         ('up', 2), ('conv1d', 64, 128, 5, 1, 'same'), ('bn', 128), ('act', 'tanh', 0.0), ('drop', 0.2)]
+         ('up', 2), ('conv1d', 256, 64, filtsize, 2, 'same'), ('bn', 64), ('act', 'tanh', 0.0), ('drop', 0.2),
+         ('up', 2), ('conv1d', 64, 128, filtsize, 1, 'same'), ('bn', 128), ('act', 'tanh', 0.0), ('drop', 0.2)]
     for cin, cout in ((128, 256), (256, 512), (512, 1024)):
-        L += [('conv1d', cin, cout, 5, 1, 'same'), ('bn', cout), ('act', 'tanh', 0.0), ('drop', 0.2)]
-    L += [('conv1d', 1024, 1, 5, 1, 'same'), ('act', 'linear', 0.0)]
+        L += [('conv1d', cin, cout, filtsize, 1, 'same'), ('bn', cout), ('act', 'tanh', 0.0), ('drop', 0.2)]
+    L += [('conv1d', 1024, 1, filtsize, 1, 'same'), ('act', 'linear', 0.0)]
     return L
 
 
@@ -240,10 +240,10 @@ class PENet(object):
 # GAN: generator G, discriminator D, combined G -> MyLayer(event) -> D(frozen)
 # ----------------------------------------------------------------------------------------------
 class GAN(object):
-    def __init__(self, n_pix, event, rng=None, dtype=np.float64, moving_average='tf_zero_debias'):
+    def __init__(self, n_pix, event, rng=None, dtype=np.float64, moving_average='tf_zero_debias', filtsize=5):
         rng = rng or np.random.RandomState(2)
         self.n_pix = n_pix
-        self.G = Stack(generator_spec(n_pix), rng, dtype, moving_average)
+        self.G = Stack(generator_spec(n_pix, filtsize), rng, dtype, moving_average)
         self.D = Stack(discriminator_spec(n_pix), rng, dtype)
         self.event = np.asarray(event, dtype).reshape(n_pix, 1)
         self.opt_g = AdamState(self.G.params)      # signal_discriminator_on_generator (:1107), D frozen

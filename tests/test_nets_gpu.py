@@ -144,35 +144,37 @@ def test_pe_train_on_batch_matches_oracle(n_pix, B, steps):
     assert rel(p[0], p_ref[0]) < 5e-5 and rel(p[1], p_ref[1]) < 5e-5
 
 
-def _build_gan(n_pix, rng):
+def _build_gan(n_pix, rng, filtsize=5):
     from gennet_amd import bbh
     event = f32(rng.randn(n_pix, 1))
-    ref = N.GAN(n_pix, event, rng)
+    ref = N.GAN(n_pix, event, rng, filtsize=filtsize)
     round_stack(ref.G); round_stack(ref.D)
     for st in (ref.G, ref.D):
         for p in st.params:
             if p.ndim == 1:
                 p[...] = f32(p + 0.05 * rng.randn(*p.shape))
-    nets = bbh.build_and_compile(event, n_pix, do_pe=False)
+    nets = bbh.build_and_compile(event, n_pix, do_pe=False, filtsize=filtsize)
     load_stack_into_layers(ref.G, nets.generator.layers)
     load_stack_into_layers(ref.D, nets.signal_discriminator.layers)
     return ref, nets, event
 
 
-@pytest.mark.parametrize("n_pix,B,iters", [(64, 4, 2),
-                                          (1024, 3, 1),        # the reference script's own default n_pix; odd batch
-                                          (4096, 2, 1),        # BASELINE config 5 size: Dense(100 -> 524 288), 4096-row convs, 1 048 576-input head
-                                          (2048, 4, 1),        # BASELINE size: Dense(100 -> 262 144) + feature-BN over B, the 524 288-input head,
+@pytest.mark.parametrize("n_pix,B,iters,filtsize", [(64, 4, 2, 5),
+                                          (64, 4, 2, 10),      # `filtsize = 5 # 10 is best` (bbhMahoGANy.py:228): every generator conv as 5 taps over (x, x shifted by 5)
+                                          (256, 3, 1, 7),      # an odd filter size: 4 taps + a zero-padded one
+                                          (1024, 3, 1, 5),     # the reference script's own default n_pix; odd batch
+                                          (4096, 2, 1, 5),     # BASELINE config 5 size: Dense(100 -> 524 288), 4096-row convs, 1 048 576-input head
+                                          (2048, 4, 1, 5),     # BASELINE size: Dense(100 -> 262 144) + feature-BN over B, the 524 288-input head,
                                                                # channel-BN over 2048*B rows, fused dgrad epilogues, fold_bn predict inside the graph
-                                          (2048, 64, 1)])      # round 5: D step on 2 x 64 rows, G step on 64 rows at BASELINE size against
+                                          (2048, 64, 1, 5)])   # round 5: D step on 2 x 64 rows, G step on 64 rows at BASELINE size against
                                                                # the oracle: closes the chain oracle <-> 64-row chunk <-> bench.py's batch sizes
-def test_gan_iteration_matches_oracle(n_pix, B, iters):
+def test_gan_iteration_matches_oracle(n_pix, B, iters, filtsize):
     """Full GAN iterations (bbhMahoGANy.py:1241-1299) with injected masks: D step on [real | fake], then G step through the
     frozen D; at the small size a second iteration exercises the moving statistics and both Adam states."""
     from gennet_amd import bbh
     from gennet_amd.engine import to_device
     rng = np.random.RandomState(3)
-    ref, nets, event = _build_gan(n_pix, rng)
+    ref, nets, event = _build_gan(n_pix, rng, filtsize)
     ev_dev = to_device(event.reshape(-1))
     G, D, DG = nets.generator, nets.signal_discriminator, nets.signal_discriminator_on_generator
     # the combined model trains exactly the generator's weights; the discriminator model its own
