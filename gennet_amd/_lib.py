@@ -47,6 +47,8 @@ _SIGS = {
     'gn_dropout_apply': [vp, vp, vp, sz, f32, vp],
     'gn_upsample2_fwd': [vp, vp, i32, i32, i32, vp],
     'gn_upsample2_bwd': [vp, vp, i32, i32, i32, vp],
+    'gn_maxpool_h2_fwd': [vp, vp, i32, i32, i32, vp],
+    'gn_maxpool_h2_bwd': [vp, vp, vp, i32, i32, i32, vp],
     'gn_subtract_stack_fwd': [vp, vp, vp, i32, i32, vp],
     'gn_subtract_stack_bwd': [vp, vp, i32, i32, vp],
     'gn_affine_stack_fwd': [vp, vp, vp, f32, f32, vp, i32, i32, vp],

@@ -21,7 +21,7 @@ import torch
 
 from . import ops
 from .engine import Adam, Input, Model, Sequential, StepGraph, capturing, device, device_rng, to_device
-from .layers import (Activation, BatchNormalization, Conv1D, Conv2D, Dense, Dropout, Flatten, LeakyReLU, MyLayer, ReLU,
+from .layers import (Activation, BatchNormalization, Conv1D, Conv2D, Dense, Dropout, Flatten, LeakyReLU, MaxPooling2D, MyLayer, ReLU,
                      Reshape, UpSampling1D)
 
 
@@ -90,20 +90,29 @@ def signal_pe_model(n_pix=1024):
     return model
 
 
-def signal_discriminator_model(n_pix=1024):
-    """bbhMahoGANy.py:408-498, active configuration."""
-    drate, alpha, padding, weights, filtsize, n_neuron_scale = 0.4, 0.2, 'same', 'glorot_uniform', (5, 5), 4
+def signal_discriminator_model(n_pix=1024, num_lays=2, batchnorm=False, maxpool=False):
+    """bbhMahoGANy.py:408-498.  Defaults = the active configuration (:424-426); num_lays 1..6, batchnorm and maxpool are the reference's edit-the-file
+    knobs, layer order as written there (layer 2 normalises AFTER its activation, :449-450; layers 3-6 before, :457-458)."""
+    drate, alpha, padding, weights, filtsize, n_neuron_scale, momentum = 0.4, 0.2, 'same', 'glorot_uniform', (5, 5), 4, 0.99
+    if not 1 <= num_lays <= 6:
+        raise ValueError('num_lays %r (the reference writes out layers 1..6, bbhMahoGANy.py:436-490)' % (num_lays,))
     model = Sequential(name='signal_discriminator')
-    model.add(Conv2D(64 * n_neuron_scale, filtsize, kernel_initializer=weights, input_shape=(n_pix, 2, 1), strides=(2, 1), padding=padding))
-    model.add(LeakyReLU(alpha=alpha))
-    model.add(Dropout(drate))
-    model.add(Conv2D(128 * n_neuron_scale, filtsize, kernel_initializer=weights, strides=(2, 1), padding=padding))
-    model.add(LeakyReLU(alpha=alpha))
-    model.add(Dropout(drate))
+    for i, (filters, strides) in enumerate(((64 * n_neuron_scale, (2, 1)), (128 * n_neuron_scale, (2, 1)), (256, (1, 1)), (512, (1, 1)), (1024, (1, 1)),
+                                            (1024, (1, 1)))[:num_lays]):
+        kw = {'input_shape': (n_pix, 2, 1)} if i == 0 else {}
+        model.add(Conv2D(filters, filtsize, kernel_initializer=weights, strides=strides, padding=padding, **kw))
+        if batchnorm and i >= 2:
+            model.add(BatchNormalization(momentum=momentum))
+        model.add(LeakyReLU(alpha=alpha))
+        if batchnorm and i == 1:
+            model.add(BatchNormalization(momentum=momentum))
+        model.add(Dropout(drate))
+        if maxpool:
+            model.add(MaxPooling2D(pool_size=(2, 1)))
     model.add(Flatten())
     model.add(Dense(1))
     model.add(Activation('sigmoid'))
-    model._config = ('signal_discriminator_model', n_pix)
+    model._config = ('signal_discriminator_model', n_pix, num_lays, batchnorm, maxpool)
     return model
 
 
@@ -156,13 +165,14 @@ def chisquare_loss(n_sig=1.0):
     return chisquare_Loss
 
 
-def build_and_compile(noise_signal, n_pix, lr=9e-5, do_pe=True, data_parallel=None, chi_loss=False, n_sig=1.0, filtsize=5):
+def build_and_compile(noise_signal, n_pix, lr=9e-5, do_pe=True, data_parallel=None, chi_loss=False, n_sig=1.0, filtsize=5, d_config=None):
     """bbhMahoGANy.py:1089-1119, in the reference's order (the order fixes which weights each compiled model trains):
     the combined model is compiled while the discriminator is frozen, the discriminator after it is unfrozen.
-    chi_loss (:97, :1106-1109): the combined model trains on chisquare_Loss instead of binary cross-entropy; filtsize (:228): the generator's filter size."""
+    chi_loss (:97, :1106-1109): the combined model trains on chisquare_Loss instead of binary cross-entropy; filtsize (:228): the generator's filter size; d_config (:424-426): the discriminator's
+    num_lays / batchnorm / maxpool."""
     nets = Nets()
     nets.generator = generator_model(n_pix, filtsize)
-    nets.signal_discriminator = signal_discriminator_model(n_pix)
+    nets.signal_discriminator = signal_discriminator_model(n_pix, **(d_config or {}))
     nets.data_subtraction = data_subtraction_model(noise_signal, n_pix)
     nets.signal_pe = signal_pe_model(n_pix) if do_pe else None
     dp = data_parallel

@@ -41,8 +41,8 @@ def _pick(mod, *names):
 
 _core = _pick(_layers, 'Activation', 'Dense', 'Dropout', 'Flatten', 'Reshape')
 _norm = _pick(_layers, 'BatchNormalization')
-_conv = dict(_pick(_layers, 'Conv1D', 'Conv2D', 'UpSampling1D'),
-             **_unused('37-38', 'UpSampling2D', 'Conv2DTranspose', 'MaxPooling2D', 'AveragePooling1D', 'MaxPooling1D'))
+_conv = dict(_pick(_layers, 'Conv1D', 'Conv2D', 'UpSampling1D', 'MaxPooling2D'),
+             **_unused('37-38', 'UpSampling2D', 'Conv2DTranspose', 'AveragePooling1D', 'MaxPooling1D'))
 _act = dict(_pick(_layers, 'LeakyReLU', 'PReLU', 'ReLU'), **_unused('39', 'ThresholdedReLU'))
 _top = dict(_pick(_engine, 'Input'), **_pick(_layers, 'MyLayer'))
 _top.update(_unused('33-34', 'GlobalAveragePooling1D', 'AlphaDropout', 'GaussianDropout', 'GaussianNoise'))

@@ -205,6 +205,8 @@ def layer_config(layer):
         cfg.update(data_format='channels_last')
     elif isinstance(layer, L.UpSampling1D):
         cfg.update(size=2)
+    elif isinstance(layer, L.MaxPooling2D):
+        cfg.update(pool_size=[2, 1], padding='valid', strides=[2, 1], data_format='channels_last')
     # custom layers (MyLayer, bbhMahoGANy.py:164-188, defines no get_config): base config only, like Keras writes for them
     return cfg
 
@@ -291,6 +293,8 @@ def _layer_from_config(class_name, cfg, custom_objects):
         return L.Flatten(**kw)
     if class_name == 'UpSampling1D':
         return L.UpSampling1D(size=cfg.get('size', 2), **kw)
+    if class_name == 'MaxPooling2D':
+        return L.MaxPooling2D(pool_size=tuple(cfg.get('pool_size', (2, 2))), strides=cfg.get('strides'), padding=cfg.get('padding', 'valid'), **kw)
     raise ValueError('Unknown layer: %s (pass it through custom_objects={%r: ...})' % (class_name, class_name))
 
 

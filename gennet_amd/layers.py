@@ -591,6 +591,31 @@ class UpSampling1D(Layer):
         return ops.upsample2_bwd(dy.contiguous())
 
 
+class MaxPooling2D(Layer):
+    """bbhMahoGANy.py:444, :453, :462, ... (`maxpool = True`): MaxPooling2D(pool_size=(2,1)) -- pairs of rows along H; strides = pool_size, 'valid'."""
+
+    def __init__(self, pool_size=(2, 2), strides=None, padding='valid', **kw):
+        Layer.__init__(self, **kw)
+        pool_size = (pool_size, pool_size) if isinstance(pool_size, int) else tuple(pool_size)
+        strides = pool_size if strides is None else ((strides, strides) if isinstance(strides, int) else tuple(strides))
+        if pool_size != (2, 1) or strides != (2, 1) or padding != 'valid':
+            raise NotImplementedError('MaxPooling2D is implemented for the reference\'s case only: pool_size (2,1), strides (2,1), padding "valid"')
+
+    def compute_output_shape(self, input_shape):
+        if input_shape[0] < 2:
+            raise ValueError('MaxPooling2D(pool_size=(2,1)) on %d rows' % input_shape[0])
+        return (input_shape[0] // 2,) + tuple(input_shape[1:])
+
+    def forward(self, ctx, node, x):
+        x = x.contiguous()
+        if ctx.training:
+            ctx.tape[node.index] = x
+        return ops.maxpool_h2_fwd(x)
+
+    def backward(self, ctx, node, dy, need_dx, need_dw):
+        return ops.maxpool_h2_bwd(dy.contiguous(), ctx.tape.pop(node.index))
+
+
 class MyLayer(Layer):
     """bbhMahoGANy.py:164-188: stack([x, const - x], axis=2): (B, n_pix, 1) -> (B, n_pix, 2, 1), const = measured data h(t)."""
 

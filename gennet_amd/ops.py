@@ -199,6 +199,25 @@ def conv2d_w2_unfold_grad(dwf, dbf, Cin, Cout, dw=None, db=None):
     return dw, db
 
 
+def maxpool_h2_fwd(x):
+    """MaxPooling2D(pool_size=(2,1)) on (B, H, ...): gn_maxpool_h2_fwd."""
+    _chk(x)
+    B, H = x.shape[0], x.shape[1]
+    R = x.numel() // max(B * H, 1)
+    y = torch.empty((B, H // 2) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    _lib.call('gn_maxpool_h2_fwd', _p(x), _p(y), B, H, R, _stream())
+    return y
+
+
+def maxpool_h2_bwd(dy, x):
+    _chk(dy, x)
+    B, H = x.shape[0], x.shape[1]
+    R = x.numel() // max(B * H, 1)
+    dx = torch.empty_like(x)
+    _lib.call('gn_maxpool_h2_bwd', _p(dy), _p(x), _p(dx), B, H, R, _stream())
+    return dx
+
+
 def tap_groups(k):
     """(G, h): a k-tap Conv1D (k > 5) runs as G = ceil(k/5) tap groups of h = ceil(k/G) taps (gn_conv1d_tap_groups, csrc/tap_fold.hip)."""
     G = (k + 4) // 5

@@ -177,6 +177,11 @@ int gn_dropout_apply(const float* x, const uint8_t* mask, float* y, size_t n, fl
 /* UpSampling1D(size=2) (bbhMahoGANy.py:249,:258) and its adjoint */
 int gn_upsample2_fwd(const float* x, float* y, int B, int L, int C, void* stream);
 int gn_upsample2_bwd(const float* dy, float* dx, int B, int L, int C, void* stream);
+/* MaxPooling2D(pool_size=(2,1)) (the discriminator's `maxpool = True` configuration, bbhMahoGANy.py:426, :444-490): x (B, H, R) -> y (B, H/2, R), the
+ * maximum over row pairs along H, R = W * C floats per row; an odd last row is dropped ('valid').  Backward: dy to the row that held the maximum (a tie:
+ * the first row of the pair, as TensorFlow's max-pool gradient), zero elsewhere. */
+int gn_maxpool_h2_fwd(const float* x, float* y, int B, int H, int R, void* stream);
+int gn_maxpool_h2_bwd(const float* dy, const float* x, float* dx, int B, int H, int R, void* stream);
 /* MyLayer (bbhMahoGANy.py:180-184): img[b,t,0] = x[b,t]; img[b,t,1] = event[t] - x[b,t];  adjoint dx = d0 - d1 */
 int gn_subtract_stack_fwd(const float* x, const float* event, float* img, int B, int n, void* stream);
 int gn_subtract_stack_bwd(const float* dimg, float* dx, int B, int n, void* stream);

@@ -173,6 +173,23 @@ def upsample1d_bwd(dy, size=2):
     return dy.reshape(B, L // size, size, C).sum(axis=2)
 
 
+def maxpool_h2_fwd(x):
+    """MaxPooling2D(pool_size=(2,1)) (bbhMahoGANy.py:444-490, `maxpool = True`): max over row pairs along axis 1, 'valid' (an odd last row is dropped).
+    -> (y, take_second): the routing mask the backward pass uses; a tie goes to the first row (TensorFlow's kernels keep the first maximum)."""
+    Ho = x.shape[1] // 2
+    a, c = x[:, 0:2 * Ho:2], x[:, 1:2 * Ho:2]
+    second = c > a
+    return np.where(second, c, a), second
+
+
+def maxpool_h2_bwd(dy, second, H):
+    dx = np.zeros((dy.shape[0], H) + dy.shape[2:], dy.dtype)
+    Ho = dy.shape[1]
+    dx[:, 0:2 * Ho:2] = np.where(second, 0.0, dy)
+    dx[:, 1:2 * Ho:2] = np.where(second, dy, 0.0)
+    return dx
+
+
 def mylayer_fwd(x, const):
     """bbhMahoGANy.py:180-184: stack([x, const - x], axis=2): (B,n,1) -> (B,n,2,1)."""
     return np.stack([x, const - x], axis=2)

@@ -34,10 +34,22 @@ def generator_spec(n_pix, filtsize=5):
     return L
 
 
-def discriminator_spec(n_pix):
-    return [('conv2d', 1, 256, (5, 5), (2, 1), 'same'), ('act', 'leaky', LEAKY_ALPHA), ('drop', 0.4),
-            ('conv2d', 256, 512, (5, 5), (2, 1), 'same'), ('act', 'leaky', LEAKY_ALPHA), ('drop', 0.4),
-            ('flatten',), ('dense', (n_pix // 4) * 2 * 512, 1), ('act', 'sigmoid', 0.0)]
+def discriminator_spec(n_pix, num_lays=2, batchnorm=False, maxpool=False):
+    """bbhMahoGANy.py:408-498; defaults = the active configuration (:424-426).  Layer 2 normalises after its activation (:449-450), layers 3-6 before."""
+    L, H, cin = [], n_pix, 1
+    for i, (cout, sh) in enumerate(((256, 2), (512, 2), (256, 1), (512, 1), (1024, 1), (1024, 1))[:num_lays]):
+        L.append(('conv2d', cin, cout, (5, 5), (sh, 1), 'same'))
+        H = K.conv_out_len(H, 5, sh, 'same')
+        if batchnorm and i >= 2:
+            L.append(('bn', cout))
+        L.append(('act', 'leaky', LEAKY_ALPHA))
+        if batchnorm and i == 1:
+            L.append(('bn', cout))
+        L.append(('drop', 0.4))
+        if maxpool:
+            L.append(('maxpool',)); H //= 2
+        cin = cout
+    return L + [('flatten',), ('dense', H * 2 * cin, 1), ('act', 'sigmoid', 0.0)]
 
 
 def pe_branch_specs(n_pix):
@@ -161,6 +173,22 @@ class Stack(object):
                 self.tape.append(x.shape); x = x.reshape(x.shape[0], -1)
             elif kind == 'up':
                 self.tape.append(None); x = K.upsample1d_fwd(x, s[1])
+            elif kind == 'maxpool':
+                H = x.shape[1]; y, second = K.maxpool_h2_fwd(x)
+                if decisions is not None and li in decisions:
+                    # the routing of a pair whose two values agree to within fp32 rounding is a branch decision like the ReLU kink: decisions[li] is the
+                    # implementation's INPUT of this layer; inside the band its routing is taken, outside a disagreement is counted (tests: must be 0)
+                    Ho = H // 2
+                    xi = np.asarray(decisions[li]).reshape(x.shape)
+                    a, c = x[:, 0:2 * Ho:2], x[:, 1:2 * Ho:2]
+                    theirs = xi[:, 1:2 * Ho:2] > xi[:, 0:2 * Ho:2]
+                    band = np.abs(c - a) <= self.DECISION_BAND * np.abs(x).max()
+                    mism = theirs != second
+                    flip = mism & band
+                    self.decision_stats[li] = (int(band.sum()), int(flip.sum()), int((mism & ~band).sum()), int(second.size))
+                    if flip.any():
+                        second = np.where(flip, theirs, second); y = np.where(second, c, a)
+                self.tape.append((second, H)); x = y
             else:
                 raise ValueError(kind)
         return x
@@ -193,6 +221,8 @@ class Stack(object):
                 dy = dy.reshape(t)
             elif kind == 'up':
                 dy = K.upsample1d_bwd(dy, s[1])
+            elif kind == 'maxpool':
+                dy = K.maxpool_h2_bwd(dy, t[0], t[1])
         return dy, grads
 
 
@@ -240,13 +270,17 @@ class PENet(object):
 # GAN: generator G, discriminator D, combined G -> MyLayer(event) -> D(frozen)
 # ----------------------------------------------------------------------------------------------
 class GAN(object):
-    def __init__(self, n_pix, event, rng=None, dtype=np.float64, moving_average='tf_zero_debias', filtsize=5):
+    def __init__(self, n_pix, event, rng=None, dtype=np.float64, moving_average='tf_zero_debias', filtsize=5, d_config=None):
         rng = rng or np.random.RandomState(2)
         self.n_pix = n_pix
         self.G = Stack(generator_spec(n_pix, filtsize), rng, dtype, moving_average)
-        self.D = Stack(discriminator_spec(n_pix), rng, dtype)
+        self.D = Stack(discriminator_spec(n_pix, **(d_config or {})), rng, dtype, moving_average)
         self.event = np.asarray(event, dtype).reshape(n_pix, 1)
         self.opt_g = AdamState(self.G.params)      # signal_discriminator_on_generator (:1107), D frozen
+        # `batchnorm = True` in the discriminator: its BatchNormalization layers are called once per graph they are part of (their own model and the combined
+        # one), and every call creates its own zero-debias shadow accumulators (tf moving_averages.assign_moving_average(zero_debias=True) makes `biased` and
+        # `local_step` per call site) that both write the one moving_mean / moving_variance: a second set for the G step
+        self.D_zd_combined = {li: [np.zeros_like(v[0]), np.zeros_like(v[1]), 0] for li, v in self.D.zd.items()}
         self.opt_d = AdamState(self.D.params)      # signal_discriminator (:1115)
 
     def generate(self, z):
@@ -270,7 +304,11 @@ class GAN(object):
         sy = np.asarray(sy, z.dtype).reshape(-1, 1)
         x = self.G.forward(z, True, g_masks)
         img = K.mylayer_fwd(x, self.event)
-        p = self.D.forward(img, True, d_masks, decisions=d_decisions)
+        own, self.D.zd = self.D.zd, self.D_zd_combined
+        try:
+            p = self.D.forward(img, True, d_masks, decisions=d_decisions)
+        finally:
+            self.D.zd = own
         loss, dp = K.bce_loss(p, sy, p_impl)
         self.bce_sat = K.bce_loss.last
         dimg, _ = self.D.backward(dp)

@@ -506,3 +506,19 @@ def test_full_size_layers_spot_checked_against_the_definition(L, Cin, Cout, s, p
     assert np.abs(db - dy64.sum(axis=(0, 1))).max() <= 5e-5 * np.abs(db).max()
 
 
+
+
+@pytest.mark.parametrize("B,H,W,C", [(3, 32, 2, 256), (2, 7, 2, 5), (1, 2, 1, 1), (4, 1024, 2, 64)])
+def test_maxpool_h2_bit_exact(B, H, W, C):
+    """MaxPooling2D(pool_size=(2,1)) (bbhMahoGANy.py:444-490, `maxpool = True`): comparisons and copies only, so bit-identical to the oracle -- with the
+    Dropout zeros in front of it (exact ties: gradient to the first row of the pair) and an odd last row (dropped, zero gradient)."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(H + C)
+    x = (rng.randn(B, H, W, C) * (rng.rand(B, H, W, C) >= 0.4)).astype(np.float32)
+    x[0, :2] = x[0, 0]                                           # a non-zero tie
+    y_ref, second = K.maxpool_h2_fwd(x)
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    y = ops.maxpool_h2_fwd(g(x))
+    assert y.shape == y_ref.shape and np.array_equal(y.cpu().numpy(), y_ref)
+    dx = ops.maxpool_h2_bwd(g(dy), g(x))
+    assert np.array_equal(dx.cpu().numpy(), K.maxpool_h2_bwd(dy, second, H))

@@ -48,6 +48,14 @@ def decisions_for(stack, layers, capture):
     for l, li in zip(with_params, specs):
         if li + 1 < len(stack.spec) and stack.spec[li + 1][0] == 'act' and stack.spec[li + 1][1] in ('relu', 'relu_max', 'leaky'):
             out[li + 1] = capture[l.name].detach().cpu().numpy()
+    # MaxPooling2D (`maxpool = True`): the implementation's INPUT of the layer = the output of the nearest executed layer in front of it (a Dropout fused
+    # into its producer does not run as a node of its own); the oracle takes its routing for pairs that agree to within the band
+    pools = [l for l in layers if l.__class__.__name__ == 'MaxPooling2D']
+    for l, li in zip(pools, [li for li, s in enumerate(stack.spec) if s[0] == 'maxpool']):
+        j = layers.index(l) - 1
+        while layers[j].name not in capture:
+            j -= 1
+        out[li] = capture[layers[j].name].detach().cpu().numpy()
     return out
 
 
@@ -144,37 +152,43 @@ def test_pe_train_on_batch_matches_oracle(n_pix, B, steps):
     assert rel(p[0], p_ref[0]) < 5e-5 and rel(p[1], p_ref[1]) < 5e-5
 
 
-def _build_gan(n_pix, rng, filtsize=5):
+def _build_gan(n_pix, rng, filtsize=5, d_config=None):
     from gennet_amd import bbh
     event = f32(rng.randn(n_pix, 1))
-    ref = N.GAN(n_pix, event, rng, filtsize=filtsize)
+    ref = N.GAN(n_pix, event, rng, filtsize=filtsize, d_config=d_config)
     round_stack(ref.G); round_stack(ref.D)
     for st in (ref.G, ref.D):
         for p in st.params:
             if p.ndim == 1:
                 p[...] = f32(p + 0.05 * rng.randn(*p.shape))
-    nets = bbh.build_and_compile(event, n_pix, do_pe=False, filtsize=filtsize)
+    nets = bbh.build_and_compile(event, n_pix, do_pe=False, filtsize=filtsize, d_config=d_config)
     load_stack_into_layers(ref.G, nets.generator.layers)
     load_stack_into_layers(ref.D, nets.signal_discriminator.layers)
     return ref, nets, event
 
 
-@pytest.mark.parametrize("n_pix,B,iters,filtsize", [(64, 4, 2, 5),
-                                          (64, 4, 2, 10),      # `filtsize = 5 # 10 is best` (bbhMahoGANy.py:228): every generator conv as 5 taps over (x, x shifted by 5)
-                                          (256, 3, 1, 7),      # an odd filter size: 4 taps + a zero-padded one
-                                          (1024, 3, 1, 5),     # the reference script's own default n_pix; odd batch
-                                          (4096, 2, 1, 5),     # BASELINE config 5 size: Dense(100 -> 524 288), 4096-row convs, 1 048 576-input head
-                                          (2048, 4, 1, 5),     # BASELINE size: Dense(100 -> 262 144) + feature-BN over B, the 524 288-input head,
+D4 = dict(num_lays=4, batchnorm=True, maxpool=True)       # the discriminator's edit-the-file knobs (bbhMahoGANy.py:424-426): Conv2D strides (1,1), BatchNormalization
+D6 = dict(num_lays=6, batchnorm=True, maxpool=False)      # after (layer 2) and before (layers 3-6) the LeakyReLU, MaxPooling2D((2,1)) behind every Dropout
+D3 = dict(num_lays=3, batchnorm=False, maxpool=True)
+
+
+@pytest.mark.parametrize("n_pix,B,iters,filtsize,d_config", [(64, 4, 2, 5, None),
+                                          (64, 4, 2, 5, D4), (64, 3, 1, 5, D6), (128, 3, 1, 5, D3),
+                                          (64, 4, 2, 10, None),  # `filtsize = 5 # 10 is best` (bbhMahoGANy.py:228): every generator conv as 5 taps over (x, x shifted by 5)
+                                          (256, 3, 1, 7, None),  # an odd filter size: 4 taps + a zero-padded one
+                                          (1024, 3, 1, 5, None), # the reference script's own default n_pix; odd batch
+                                          (4096, 2, 1, 5, None), # BASELINE config 5 size: Dense(100 -> 524 288), 4096-row convs, 1 048 576-input head
+                                          (2048, 4, 1, 5, None), # BASELINE size: Dense(100 -> 262 144) + feature-BN over B, the 524 288-input head,
                                                                # channel-BN over 2048*B rows, fused dgrad epilogues, fold_bn predict inside the graph
-                                          (2048, 64, 1, 5)])   # round 5: D step on 2 x 64 rows, G step on 64 rows at BASELINE size against
+                                          (2048, 64, 1, 5, None)])   # round 5: D step on 2 x 64 rows, G step on 64 rows at BASELINE size against
                                                                # the oracle: closes the chain oracle <-> 64-row chunk <-> bench.py's batch sizes
-def test_gan_iteration_matches_oracle(n_pix, B, iters, filtsize):
+def test_gan_iteration_matches_oracle(n_pix, B, iters, filtsize, d_config):
     """Full GAN iterations (bbhMahoGANy.py:1241-1299) with injected masks: D step on [real | fake], then G step through the
     frozen D; at the small size a second iteration exercises the moving statistics and both Adam states."""
     from gennet_amd import bbh
     from gennet_amd.engine import to_device
     rng = np.random.RandomState(3)
-    ref, nets, event = _build_gan(n_pix, rng, filtsize)
+    ref, nets, event = _build_gan(n_pix, rng, filtsize, d_config)
     ev_dev = to_device(event.reshape(-1))
     G, D, DG = nets.generator, nets.signal_discriminator, nets.signal_discriminator_on_generator
     # the combined model trains exactly the generator's weights; the discriminator model its own
@@ -198,8 +212,10 @@ def test_gan_iteration_matches_oracle(n_pix, B, iters, filtsize):
         assert_decisions_consistent(ref.D)
         assert abs(out[0] - out_ref[0]) <= 2e-5 * abs(out_ref[0]) and out[1] == pytest.approx(out_ref[1])
         dgr = [p.grad.cpu().numpy() for l in D.layers for p in l.params]
+        dmax = max(np.abs(gr).max() for gr in ref.last_d_grads)
         for gq, gr in zip(dgr, ref.last_d_grads):
-            assert rel(gq, gr) < 2e-4
+            # (`batchnorm = True`: a bias feeding a BatchNormalization has an exactly-zero gradient in exact arithmetic: absolute floor as in the G step below)
+            assert np.abs(gq - gr).max() <= 2e-4 * np.abs(gr).max() + (1e-6 * dmax if d_config and d_config['batchnorm'] else 0.0), rel(gq, gr)
         assert np.all(dgr[0][:, 0] == 0) and np.all(dgr[0][:, 4] == 0)      # dead width taps of the 5x5 kernel
 
         z2 = f32(rng.uniform(-1, 1, (B, 100)))
@@ -225,15 +241,26 @@ def test_gan_iteration_matches_oracle(n_pix, B, iters, filtsize):
     for st, model in ((ref.G, G), (ref.D, D)):
         ws = [p.data.cpu().numpy() for l in model.layers for p in l.params]
         for w, wr in zip(ws, st.params):
-            assert np.abs(w - wr).max() <= 2e-4 * np.abs(wr).max() + 0.02 * 2 * 9e-5      # see the Adam note in the PE test
+            bound = 2e-4 * np.abs(wr).max() + 0.02 * 2 * 9e-5                               # see the Adam note in the PE test
+            if d_config is None:
+                assert np.abs(w - wr).max() <= bound
+            else:
+                # behind a deep normalised discriminator the generator's gradients are small enough that for some elements the ABSOLUTE fp32 error exceeds
+                # Adam's epsilon (1e-7): the first step of such an element is lr * g / (|g| + eps) with g of either sign -- up to 2 lr apart; a few per tensor
+                bad = np.abs(w - wr) > bound
+                assert bad.mean() <= 1e-3 and np.abs(w - wr).max() <= 2 * iters * 9e-5, (float(bad.mean()), float(np.abs(w - wr).max()))
     # generator.predict after the update(s): moving statistics through fold_bn inside the full graph
     z3 = f32(rng.uniform(-1, 1, (B, 100)))
     assert rel(G.predict(z3), ref.generate(z3)) < 1e-4
-    bns = [l for l in G.layers if hasattr(l, 'moving_mean')]
-    bn_idx = [li for li, s in enumerate(ref.G.spec) if s[0] == 'bn']
-    for l, li in zip(bns, bn_idx):
-        assert rel(l.moving_mean.data.cpu().numpy(), ref.G.state[li][0]) < 1e-4 or np.abs(ref.G.state[li][0]).max() < 1e-6
-        assert rel(l.moving_variance.data.cpu().numpy(), ref.G.state[li][1]) < 1e-4
+    for st, model in ((ref.G, G), (ref.D, D)):
+        # (the discriminator's BatchNormalization layers, `batchnorm = True`, see the batch in both steps: its own and -- frozen, but in the training phase --
+        # the generator's, and update their moving statistics in both, as the train functions Keras builds at the first train_on_batch do)
+        bns = [l for l in model.layers if hasattr(l, 'moving_mean')]
+        bn_idx = [li for li, s in enumerate(st.spec) if s[0] == 'bn']
+        assert len(bns) == len(bn_idx)
+        for l, li in zip(bns, bn_idx):
+            assert rel(l.moving_mean.data.cpu().numpy(), st.state[li][0]) < 1e-4 or np.abs(st.state[li][0]).max() < 1e-6
+            assert rel(l.moving_variance.data.cpu().numpy(), st.state[li][1]) < 1e-4
 
 
 def test_unfused_layers_match_fused_epilogues():
