@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgs a, const u
 #pragma unroll
   for (int i = 0; i < Q_WAVE; ++i) dma_one(i, min(1, n_chunks - 1), smem_b + STAGE);
   __builtin_amdgcn_s_waitcnt(VMCNT_Q);                      // chunk 0 has landed (chunk 1 may still fly)
-  __builtin_amdgcn_s_barrier();
+  asm volatile("s_barrier" ::: "memory");       // (not the builtin: it is IntrNoMem, LDS loads may move across it -- ADVICE r4)
 
   // fragment buffers: tap 0 -> [2], tap j >= 1 -> [(j - 1) & 1]
   bf16x8 fa[3][3][2], fb[3][3];
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgs a, const u
         }
         // every read of this stage has landed; chunk ch+1 must have landed: at most this chunk's own Q_WAVE DMAs stay in flight
         __builtin_amdgcn_s_waitcnt(VMCNT_Q);
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_barrier" ::: "memory");       // (not the builtin: it is IntrNoMem, LDS loads may move across it -- ADVICE r4)
         if (ch + 1 < n_chunks) read_tap(smem_b + s_nxt * STAGE, 0, fa[2], fb[2]);
       }
       mma_tap(fa[cur], fb[cur]);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
 #pragma unroll
   for (int i = 0; i < Q_WAVE; ++i) dma_one(i, min(1, n_chunks - 1), smem_b + STAGE);
   __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
-  __builtin_amdgcn_s_barrier();
+  asm volatile("s_barrier" ::: "memory");       // (not the builtin: it is IntrNoMem, LDS loads may move across it -- ADVICE r4)
 
   bf16x8 fa[2][3][2], fb[2][3][2];                          // fragment double buffer: the tap with running parity P reads from [P], prefetches into [P ^ 1]
   read_tap(smem_b, 0, fa[0], fb[0]);
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
       } else {
         // every read of stage sa has landed (lgkmcnt(0) above, on every wave once past the barrier); chunk ch+1 must have landed
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_barrier" ::: "memory");       // (not the builtin: it is IntrNoMem, LDS loads may move across it -- ADVICE r4)
 #pragma unroll
         for (int i = 0; i < Q_FIRST; ++i) dma_one(i, c_dma2, sa);      // (past the end: one harmless re-stage of the last chunk keeps the count uniform)
         ndma = Q_FIRST;
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide3_kernel(ConvArgs a, c
 #pragma unroll
   for (int i = 0; i < Q_WAVE; ++i) dma_one(i, min(1, n_chunks - 1), smem_b + STAGE);
   __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
-  __builtin_amdgcn_s_barrier();
+  asm volatile("s_barrier" ::: "memory");       // (not the builtin: it is IntrNoMem, LDS loads may move across it -- ADVICE r4)
 
   bf16x8 fa[2][3][2], fb[2][3][2];                          // fragment double buffer: the tap with running parity P reads from [P], prefetches into [P ^ 1]
   read_tap(smem_b, 0, fa[0], fb[0]);
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide3_kernel(ConvArgs a, c
       } else {
         // every read of stage sa has landed; chunk ch+1 must have landed: at most this chunk's own Q_WAVE DMAs (chunk ch+2) stay in flight
         __builtin_amdgcn_s_waitcnt(VMCNT_Q);
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_barrier" ::: "memory");       // (not the builtin: it is IntrNoMem, LDS loads may move across it -- ADVICE r4)
         if (ch + 1 < n_chunks) read_tap(sb, 0, fa[P ^ 1], fb[P ^ 1]);
       }
       mma_tap(fa[P], fb[P]);
