@@ -105,7 +105,7 @@ def _gan_iterations(n_pix, B, iters):
         # ---- generator step through the frozen discriminator (:1294-1296)
         z2 = f32(rng.uniform(-1, 1, (B, 100)))
         g_masks = stack_masks(ref.G, z2, rng)
-        d_masks2 = stack_masks(ref.D, K.mylayer_fwd(ref.G.forward(z2, False), ref.event), rng)
+        d_masks2 = stack_masks(ref.D, (z2.shape[0], n_pix, 2, 1), rng)
         names = dict(masks_by_name(ref.G, g_masks, G.layers)); names.update(masks_by_name(ref.D, d_masks2, D.layers))
         d_before = [p.data.clone() for l in D.layers for p in l.params]
         cap = {}
