@@ -338,7 +338,11 @@ def test_save_and_load_model_roundtrip_on_host(tmp_path):
     from gennet_amd.engine import Adam
     from gennet_amd.keras.models import load_model
     for build, loss in ((lambda: bbh.signal_pe_model(128), 'mean_squared_error'), (lambda: bbh.signal_discriminator_model(64), 'binary_crossentropy'),
-                        (lambda: bbh.generator_model(64), 'binary_crossentropy')):
+                        (lambda: bbh.generator_model(64), 'binary_crossentropy'),
+                        # the reference's edit-the-file knobs (bbhMahoGANy.py:228, :424-426): a 10-tap generator, a 4-layer discriminator with
+                        # BatchNormalization and MaxPooling2D((2,1)) -- kernel_size / pool_size go through the Keras JSON
+                        (lambda: bbh.generator_model(64, 10), 'binary_crossentropy'),
+                        (lambda: bbh.signal_discriminator_model(64, num_lays=4, batchnorm=True, maxpool=True), 'binary_crossentropy')):
         m = build()
         m.compile(loss=loss, optimizer=Adam(lr=9e-5, beta_1=0.5), metrics=['accuracy'])
         path = str(tmp_path / (m.name + '.h5'))
