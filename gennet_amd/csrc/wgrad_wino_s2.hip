@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_s2_kernel(WgradArgs a, int 
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[p][ct][r] = 0.f;
 
-  constexpr int X_ITEMS = 3, Y_ITEMS = 1;
+  constexpr int X_ITEMS = 3;                 // + one piece of dy
   int xoff[X_ITEMS], yoff;
 #pragma unroll
   for (int it = 0; it < X_ITEMS; ++it) {

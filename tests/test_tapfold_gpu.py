@@ -42,6 +42,8 @@ CASES = [
     (1, 2048, 256, 512, 10, 1, 'same'),   # generator layer 4 at BASELINE length, one element
     (2, 100, 16, 32, 16, 1, 'same'),      # 4 groups of 4 taps (kernel_size 16: the Conv1D layers of the reference's saved d_model.hdf5 family)
     (2, 100, 16, 32, 13, 2, 'valid'),     # 3 groups of 5 taps, two zero taps
+    (2, 64, 1, 16, 16, 1, 'same'),        # one input channel, 16 taps (the first Conv1D of the reference's saved models): 4 taps over 4 channels, the small-channel kernels
+    (3, 50, 2, 8, 8, 2, 'valid'),
 ]
 
 
