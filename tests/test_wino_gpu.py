@@ -322,3 +322,35 @@ def test_weight_gradient_against_oracle_and_direct_kernel(B, L, Cin, Cout, strid
     (mw, rw), (md, rd) = errs(out['wino'][0], dw_ref), errs(out['fp32'][0], dw_ref)
     assert mw <= RTOL and rw <= (4.0 if stride == 1 else 1.5) * rd + 1e-8, (mw, rw, md, rd)
     assert errs(out['wino'][1], db_ref)[0] <= 1e-6
+
+
+def test_random_shapes_agree_with_the_direct_kernels():
+    """60 random launches (both strides and paddings, odd chunk counts, ragged row and column tiles, 1-row inputs) of forward, data gradient and weight
+    gradient: transform-domain against direct kernels at the kernels' tolerance -- the direct kernels being the ones every other test file pins on the oracle."""
+    from gennet_amd import ops
+    rng = np.random.RandomState(2025)
+    dev = torch.device('cuda:0')
+    worst = 0.0
+    for it in range(60):
+        stride = int(rng.choice([1, 2]))
+        padding = str(rng.choice(['same', 'valid']))
+        Cin = int(rng.choice([32, 40, 64, 72, 128, 192, 320]))
+        Cout = int(rng.choice([64, 128, 192, 256]))
+        B = int(rng.randint(1, 6))
+        L = int(rng.randint(5 if padding == 'valid' else 1, 700))
+        act = str(rng.choice(['linear', 'relu', 'tanh', 'leaky']))
+        Lout, pl = ops.conv_geometry(L, 5, stride, padding)
+        x = torch.tensor(rng.randn(B, L, Cin), dtype=torch.float32, device=dev)
+        w = torch.tensor(rng.randn(5, Cin, Cout) * np.sqrt(2.0 / (5 * Cin)), dtype=torch.float32, device=dev)
+        b = torch.tensor(rng.randn(Cout) * 0.1, dtype=torch.float32, device=dev)
+        dy = torch.tensor(rng.randn(B, Lout, Cout), dtype=torch.float32, device=dev)
+        wt = ops.conv1d_transpose_w(w)
+        res = {}
+        for math in ('wino', 'fp32'):
+            with ops.conv_math(math):
+                res[math] = (ops.conv1d_fwd(x, w, b, stride, pl, Lout, act, 0.2), ops.conv1d_dgrad(dy, wt, L, stride, pl), ops.conv1d_wgrad(x, dy, 5, stride, pl)[0])
+        for k, (a_, d_) in enumerate(zip(res['wino'], res['fp32'])):
+            e = float((a_ - d_).abs().max() / d_.abs().max().clamp_min(1e-30))
+            worst = max(worst, e)
+            assert e <= RTOL, (it, k, B, L, Cin, Cout, stride, padding, act, e)
+    print('worst relative difference %.2e' % worst)
