@@ -353,16 +353,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * (MERGE == 2 ? 2 : 1), (64 
   // the spread issue 0.1 %.
   constexpr int NPIECES = S_ITEMS + W_ITEMS;
   int c0_next = 0;
+  const int wv64 = __builtin_amdgcn_readfirstlane(tid & ~63);       // the wave's first thread as a scalar: the LDS-DMA destination (M0) needs no per-piece v_readfirstlane
   auto dma_piece = [&](auto kc, auto stg) {
     constexpr int k = decltype(kc)::value;
     float* stage = smem + decltype(stg)::value * BUF;
     if constexpr (k < S_ITEMS) {
       if ((k + 1) * NT <= S_COUNT || tid + k * NT < S_COUNT)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stage + (k * NT + (tid & ~63)) * 4), 16, soff[k], c0_next * 4, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stage + (k * NT + wv64) * 4), 16, soff[k], c0_next * 4, 0, 0);
     } else {
       constexpr int it = k - S_ITEMS;
-      if ((it + 1) * NT <= W_TOTAL || (tid & ~63) + it * NT < W_TOTAL)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(stage + SLAB + (it * NT + (tid & ~63)) * 4), 16, woff[it], c0_next * a.Cout * 4, 0, 0);
+      if ((it + 1) * NT <= W_TOTAL || wv64 + it * NT < W_TOTAL)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(stage + SLAB + (it * NT + wv64) * 4), 16, woff[it], c0_next * a.Cout * 4, 0, 0);
     }
   };
 

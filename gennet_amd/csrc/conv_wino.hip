@@ -206,17 +206,18 @@ __global__ __launch_bounds__(64 * WAVES_M, (WAVES_M > 4 ? 1 : 2)) void conv_wino
   const int w_chunk_bytes = n_tiles * UT * 4;      // the U tiles of one channel chunk
   int c_next = 0, st_next = 0;
   bool in_loop = false;
+  const int wv64 = __builtin_amdgcn_readfirstlane(tid & ~63);       // the wave's first thread, in a scalar register: the LDS-DMA destination (M0) is then scalar arithmetic
   auto dma_piece = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     if ((ABL & 1) && in_loop) return;
     float* stg = smem + st_next * BUF;
     if constexpr (k < S_ITEMS) {
       if ((k + 1) * NT <= S_COUNT || tid + k * NT < S_COUNT)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stg + (k * NT + (tid & ~63)) * 4), 16, soff[k], c_next * KC * 4, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stg + (k * NT + wv64) * 4), 16, soff[k], c_next * KC * 4, 0, 0);
     } else {
       constexpr int it = k - S_ITEMS;
-      if ((it + 1) * NT <= W_TOTAL || (tid & ~63) + it * NT < W_TOTAL)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(stg + SLAB + (it * NT + (tid & ~63)) * 4), 16, (n_tile * UT + (tid + it * NT) * 4) * 4,
+      if ((it + 1) * NT <= W_TOTAL || wv64 + it * NT < W_TOTAL)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(stg + SLAB + (it * NT + wv64) * 4), 16, (n_tile * UT + (tid + it * NT) * 4) * 4,
                                                  c_next * w_chunk_bytes, 0, 0);
     }
   };

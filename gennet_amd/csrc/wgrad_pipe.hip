@@ -185,15 +185,16 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(W
     xrow = IS * m0 * a.Cin * 4;
     drow = m0 * a.Cout * 4;
   };
+  const int wv64 = __builtin_amdgcn_readfirstlane(tid & ~63);       // the wave's first thread as a scalar: the LDS-DMA destination (M0) needs no per-piece v_readfirstlane
   auto dma_piece = [&](auto kc, auto stg) {
     constexpr int k = decltype(kc)::value;
     float* stage = smem + decltype(stg)::value * BUF;
     if constexpr (k < S_ITEMS) {
       if ((k + 1) * NT <= S_COUNT || tid + k * NT < S_COUNT)            // x rows before 0 give a negative (= huge unsigned) offset: out of range -> 0
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lptr_t)(stage + (k * NT + (tid & ~63)) * 4), 16, soff[k] + xrow, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lptr_t)(stage + (k * NT + wv64) * 4), 16, soff[k] + xrow, 0, 0, 0);
     } else {
       constexpr int it = k - S_ITEMS;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ds, (lptr_t)(stage + SLAB + (it * NT + (tid & ~63)) * 4), 16, doff[it] + drow, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ds, (lptr_t)(stage + SLAB + (it * NT + wv64) * 4), 16, doff[it] + drow, 0, 0, 0);
     }
   };
 

@@ -157,22 +157,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradArgs a, int off
   const int xbytes = __builtin_amdgcn_readfirstlane(a.Lin * a.Cin * 4), ybytes = __builtin_amdgcn_readfirstlane(a.M * a.Cout * 4);
   int q_next = 0, st_next = 0;
   bool in_loop = false;
+  const int wv64 = __builtin_amdgcn_readfirstlane(tid & ~63);       // the wave's first thread, in a scalar register: the LDS-DMA destination (M0) is then scalar arithmetic
   auto dma_piece = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     if ((ABL & 1) && in_loop) return;
     const int b = __builtin_amdgcn_readfirstlane(q_next / cpb), cb = __builtin_amdgcn_readfirstlane(q_next % cpb);
     float* stg = smem + st_next * BUF;
     if constexpr (k < X_ITEMS) {
-      if (k < 2 || tid < 128) {
+      if (k < 2 || wv64 < 128) {
+        // (x keeps the chunk offset in the per-lane offset: its halo rows in front of a chunk have NEGATIVE offsets from the chunk's first row, which a
+        // shifted descriptor base would turn into out-of-range = zero)
         const uintptr_t p = (uintptr_t)(a.x + (size_t)b * a.Lin * a.Cin);
         const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, xbytes, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(stg + (k * NT + (tid & ~63)) * 4), 16, xoff[k] + cb * 32 * a.Cin * 4, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(stg + (k * NT + wv64) * 4), 16, xoff[k] + cb * 32 * a.Cin * 4, 0, 0, 0);
       }
     } else {
       constexpr int it = k - X_ITEMS;
-      const uintptr_t p = (uintptr_t)(a.dy + (size_t)b * a.M * a.Cout);
-      const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, ybytes, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(stg + XS + (it * NT + (tid & ~63)) * 4), 16, yoff[it] + cb * 32 * a.Cout * 4, 0, 0, 0);
+      // dy: the chunk's row offset goes into the descriptor's BASE (and out of its size), so the per-lane offset is loop-invariant (no vector add per
+      // piece); the range check still zero-fills the rows past the end of the batch element
+      const int cbo = cb * 32 * a.Cout * 4;
+      const uintptr_t p = (uintptr_t)(a.dy + (size_t)b * a.M * a.Cout) + (uintptr_t)(unsigned)cbo;
+      const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, ybytes - cbo, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(stg + XS + (it * NT + wv64) * 4), 16, yoff[it], 0, 0, 0);
     }
   };
   auto dma_all = [&]() {

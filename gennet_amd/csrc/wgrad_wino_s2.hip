@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_s2_kernel(WgradArgs a, int 
   }
   const int xbytes = __builtin_amdgcn_readfirstlane(a.Lin * a.Cin * 4), ybytes = __builtin_amdgcn_readfirstlane(a.M * a.Cout * 4);
   int q_next = 0, st_next = 0;
+  const int wv64 = __builtin_amdgcn_readfirstlane(tid & ~63);       // the wave's first thread, in a scalar register: the LDS-DMA destination (M0) is then scalar arithmetic
   auto dma_piece = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     const int b = __builtin_amdgcn_readfirstlane(q_next / cpb), cb = __builtin_amdgcn_readfirstlane(q_next % cpb);
@@ -155,11 +156,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_s2_kernel(WgradArgs a, int 
     if constexpr (k < X_ITEMS) {
       const uintptr_t p = (uintptr_t)(a.x + (size_t)b * a.Lin * a.Cin);
       const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, xbytes, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(stg + (k * NT + (tid & ~63)) * 4), 16, xoff[k] + cb * 32 * a.Cin * 4, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(stg + (k * NT + wv64) * 4), 16, xoff[k] + cb * 32 * a.Cin * 4, 0, 0, 0);
     } else {
-      const uintptr_t p = (uintptr_t)(a.dy + (size_t)b * a.M * a.Cout);
-      const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, ybytes, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(stg + XS + (tid & ~63) * 4), 16, yoff + cb * 16 * a.Cout * 4, 0, 0, 0);
+      // dy: the chunk's row offset in the descriptor's base and size, as in wgrad_wino.hip (x cannot: its halo rows sit at negative offsets)
+      const int cbo = cb * 16 * a.Cout * 4;
+      const uintptr_t p = (uintptr_t)(a.dy + (size_t)b * a.M * a.Cout) + (uintptr_t)(unsigned)cbo;
+      const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, ybytes - cbo, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(stg + XS + wv64 * 4), 16, yoff, 0, 0, 0);
     }
   };
   auto dma_all = [&]() {
