@@ -101,6 +101,9 @@ def bench_wgrad(B, L, Cin, Cout, reps=5):
 
 
 if __name__ == '__main__' and '--wgrad' in sys.argv:
+    if '--abl' in sys.argv:        # timing only (ablation build: results are wrong)
+        bench_wgrad(512, 2048, 512, 1024)
+        sys.exit(0)
     for args in [(2, 64, 64, 64, 'same'), (3, 130, 128, 256, 'same'), (2, 257, 64, 128, 'valid'), (5, 37, 64, 64, 'same'), (1, 1, 64, 64, 'same'), (4, 2048, 128, 256, 'same'),
                  (2, 2044, 128, 256, 'valid'), (16, 600, 256, 512, 'same')]:
         check_wgrad(*args)
