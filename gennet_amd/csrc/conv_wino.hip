@@ -11,7 +11,7 @@
 // the fp32 vector rate and a v_fma_f32 beside it costs its full four cycles of the SIMD -- so the input transform, done in registers by the wave
 // that consumes it, must be amortised over as many output columns as the accumulator budget allows: v_mfma_f32_16x16x4_f32 (four accumulator
 // registers per 16 x 16 tile) lets a wave own 16 tiles (32 output rows) x 64 columns x 6 points in 96 accumulator registers, so one transformed
-// fragment feeds four column tiles, and the transform itself runs as packed fp32 (v_pk_fma_f32 on channel pairs): 18 VALU instructions per 48 MFMAs.
+// fragment feeds four column tiles, and the transform itself runs as packed fp32 (v_pk_fma_f32 on channel pairs): 14 VALU instructions per 48 MFMAs.
 //
 // Block = WAVES_M waves stacked in M, 64 columns; per 8-channel chunk: input slab (the rows of a stride-2, 6-tap convolution: tile t reads rows
 // 2t .. 2t+5; staged as an even-row and an odd-row plane, so a wave's 16 tiles x 4 channel pairs are 512 contiguous bytes per row offset: no
@@ -44,12 +44,13 @@ __global__ void wino_u_kernel(const float* __restrict__ w, float* __restrict__ U
 #pragma unroll
   for (int q = 0; q < 5; ++q) g[q] = (double)w[(size_t)t.wq[q] * cc + i];
   float u[6];
-  u[0] = (float)(0.5 * g[0]);
-  u[1] = (float)((g[0] + g[1] + g[2] + g[3] + g[4]) * (1.0 / 6.0));
-  u[2] = (float)((g[0] - g[1] + g[2] - g[3] + g[4]) * (1.0 / 6.0));
+  // (rows 0, 1, 2, 5 carry the factor 2 that wino_piece's rows leave out)
+  u[0] = (float)g[0];
+  u[1] = (float)((g[0] + g[1] + g[2] + g[3] + g[4]) * (1.0 / 3.0));
+  u[2] = (float)((g[0] - g[1] + g[2] - g[3] + g[4]) * (1.0 / 3.0));
   u[3] = (float)((16.0 * g[0] + 8.0 * g[1] + 4.0 * g[2] + 2.0 * g[3] + g[4]) * (1.0 / 15.0));
   u[4] = (float)((g[0] - 2.0 * g[1] + 4.0 * g[2] - 8.0 * g[3] + 16.0 * g[4]) * (1.0 / 30.0));
-  u[5] = (float)(0.5 * g[4]);
+  u[5] = (float)g[4];
   const int chunk = ci >> 3, c = ci & 7, kq = c >> 1, s = c & 1;
   const int tile = co >> 6, nn = co & 63, ct = nn >> 4, n16 = nn & 15, cth = ct >> 1, ctl = ct & 1;
   const size_t base = ((size_t)chunk * (Cout >> 6) + tile) * 3072 + ((cth * 4 + kq) * 16 + n16) * 4 + ctl * 2 + s;
@@ -62,7 +63,7 @@ __global__ void wino_u_kernel(const float* __restrict__ w, float* __restrict__ U
 //   slot 8p     issues the two reads of the NEXT point's U values (after the last point: point 0 of the next chunk, whose stage has been complete since
 //               the previous barrier), slot 0 also this lane's six raw row fragments of the NEXT chunk; a counted lgkmcnt retires exactly what the slot
 //               consumes (LDS returns in order);
-//   slots >= 8  carry the 18 transform instructions of the next chunk, one every other slot; the staging pieces of chunk + 2 sit behind slots 1, 3, ...
+//   slots >= 8  carry the 14 transform instructions of the next chunk, one every third slot; the staging pieces of chunk + 2 sit behind slots 1, 3, ...
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wino_slot(f32x4& c, float a, float b) {
   asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "memory");
@@ -113,7 +114,7 @@ template <int RPER, int ABL = 0>
 struct WinoChunk {
   template <int NPIECES, int I = 0, class D>
   static __device__ __forceinline__ void run(f32x4 (&acc)[6][4], const f32x2 (&v)[6], f32x2 (&vn)[6], f32x2 (&d)[6], WinoT& t, f32x4 (&B)[2][2], unsigned addr_b,
-                                             unsigned addr_b_next, unsigned addr_a, unsigned long long k5, unsigned long long km3, D& dma) {
+                                             unsigned addr_b_next, unsigned addr_a, unsigned long long k15, unsigned long long km15, D& dma) {
     if constexpr (I < 48) {
       constexpr int P = I / 8, S = (I / 4) % 2, CT = I % 4;
       f32x4(&bc)[2] = B[P & 1];
@@ -128,10 +129,10 @@ struct WinoChunk {
       else wino_slot(acc[P][CT], av, bv);
       if constexpr ((I & 1) && (I >> 1) < NPIECES) dma(std::integral_constant<int, (I >> 1)>{});
       if constexpr (!(ABL & 2) && I >= 8) {
-        constexpr int lo = (I - 8) * 18 / 40, hi = (I - 7) * 18 / 40;
-        if constexpr (lo < hi) wino_piece<lo>(d, vn, t, k5, km3);
+        constexpr int lo = (I - 8) * kWinoPieces / 40, hi = (I - 7) * kWinoPieces / 40;
+        if constexpr (lo < hi) wino_piece<lo>(d, vn, t, k15, km15);
       }
-      run<NPIECES, I + 1>(acc, v, vn, d, t, B, addr_b, addr_b_next, addr_a, k5, km3, dma);
+      run<NPIECES, I + 1>(acc, v, vn, d, t, B, addr_b, addr_b_next, addr_a, k15, km15, dma);
     }
   }
 };
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64 * WAVES_M, (WAVES_M > 4 ? 1 : 2)) void conv_wino
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const unsigned base_a = lds0 + (wave * 16 + n16) * 32 + kq * 8;           // row (tile) of plane 0, channel pair kq
   const unsigned base_b = lds0 + SLAB * 4 + (kq * 16 + n16) * 16;           // + (2 p + cth) * 1024
-  const unsigned long long k5 = 0x40a0000040a00000ull, km3 = 0xc0400000c0400000ull;
+  const unsigned long long k15 = 0x3fc000003fc00000ull, km15 = 0xbfc00000bfc00000ull;       // 1.5, -1.5 on both halves
 
   const int n_chunks = a.Cin / KC;
   c_next = 0; st_next = 0; dma_all();
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(64 * WAVES_M, (WAVES_M > 4 ? 1 : 2)) void conv_wino
     const char* sb = reinterpret_cast<const char*>(smem);
 #pragma unroll
     for (int j = 0; j < 6; ++j) d[j] = *reinterpret_cast<const f32x2*>(sb + (base_a - lds0) + (j & 1) * RPER * 32 + (j >> 1) * 32);
-    wino_bt_all(d, V0, tt, k5, km3);
+    wino_bt_all(d, V0, tt, k15, km15);
     Bq[0][0] = *reinterpret_cast<const f32x4*>(sb + (base_b - lds0));
     Bq[0][1] = *reinterpret_cast<const f32x4*>(sb + (base_b - lds0) + 1024);
   }
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(64 * WAVES_M, (WAVES_M > 4 ? 1 : 2)) void conv_wino
       st_next = st2;
       const unsigned addr_a = base_a + st1 * STAGE_BYTES;                   // chunk + 1 landed before the previous barrier
       const unsigned addr_b = base_b + st * STAGE_BYTES, addr_b_next = base_b + st1 * STAGE_BYTES;
-      if (half == 0) WinoChunk<RPER, ABL>::template run<NPIECES>(acc, V0, V1, d, tt, Bq, addr_b, addr_b_next, addr_a, k5, km3, dma_piece);
-      else WinoChunk<RPER, ABL>::template run<NPIECES>(acc, V1, V0, d, tt, Bq, addr_b, addr_b_next, addr_a, k5, km3, dma_piece);
+      if (half == 0) WinoChunk<RPER, ABL>::template run<NPIECES>(acc, V0, V1, d, tt, Bq, addr_b, addr_b_next, addr_a, k15, km15, dma_piece);
+      else WinoChunk<RPER, ABL>::template run<NPIECES>(acc, V1, V0, d, tt, Bq, addr_b, addr_b_next, addr_a, k15, km15, dma_piece);
       if constexpr (!(ABL & 4)) __syncthreads();
       st = st1;
     }

@@ -5,7 +5,7 @@
 //
 // six multiplies per output-row pair and (ci, co) instead of ten (generator Conv1D(256 / 512 / 1024, 5), bbhMahoGANy.py:266-283; PE q branch :382-384).
 // Same ingredients as conv_wino.hip: v_mfma_f32_16x16x4_f32 with a wave tile of 16 ci x 64 co x 6 points (96 accumulator registers), so the expensive
-// transform (x: 18 packed instructions) is amortised over 64 columns; both operand transforms run in registers as packed fp32 on PAIRS of tiles -- a
+// transform (x: 14 packed instructions) is amortised over 64 columns; both operand transforms run in registers as packed fp32 on PAIRS of tiles -- a
 // lane's A / B operand of two consecutive k-steps (tiles kq and kq + 4 of an 8-tile pair-step) come out of ONE ds_read2st64_b32 as a register pair,
 // because the LDS image keeps 16 channels per row (64 bytes: the four tile groups of a wave-wide read fall on distinct bank quarters) and tiles four
 // apart sit 256 bytes apart.  The dy transform (4 packed instructions per column tile) is done just in time, one column tile ahead of its 12 MFMAs.
@@ -76,8 +76,8 @@ template <int H, int ABL = 0>
 struct WgPair {
   template <int NP0, int NP1, int I = 0, class DMA>
   static __device__ __forceinline__ void run(f32x4 (&acc)[6][4], const f32x2 (&v)[6], f32x2 (&vn)[6], f32x2 (&d)[6], WinoT& t, f32x2 (&D)[2][6], unsigned addr_b,
-                                             unsigned addr_b_next, const unsigned (&addr_a)[3], const unsigned (&addr_a_next)[3], unsigned long long k5,
-                                             unsigned long long km3, DMA& dma) {
+                                             unsigned addr_b_next, const unsigned (&addr_a)[3], const unsigned (&addr_a_next)[3], unsigned long long k15,
+                                             unsigned long long km15, DMA& dma) {
     if constexpr (I < 48) {
       constexpr int CT = I / 12, G = I % 12, S = G / 6, P = G % 6;
       f32x2(&dc)[6] = D[CT & 1];
@@ -103,10 +103,10 @@ struct WgPair {
         if constexpr (G >= 5 && G <= 8) wino_a_piece<G - 5>(dn[0], dn[5], dn[1], dn[2], dn[3], dn[4]);
         if constexpr (CT >= 1 && (G <= 3 || G >= 9)) {
           constexpr int K = (CT - 1) * 6 + (G <= 3 ? G - 1 : G - 6);            // G = 1, 2, 3, 9, 10, 11 -> 0 .. 5
-          if constexpr (G >= 1) wino_piece<K>(d, vn, t, k5, km3);
+          if constexpr (G >= 1 && K < kWinoPieces) wino_piece<K>(d, vn, t, k15, km15);
         }
       }
-      run<NP0, NP1, I + 1>(acc, v, vn, d, t, D, addr_b, addr_b_next, addr_a, addr_a_next, k5, km3, dma);
+      run<NP0, NP1, I + 1>(acc, v, vn, d, t, D, addr_b, addr_b_next, addr_a, addr_a_next, k15, km15, dma);
     }
   }
 };
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradArgs a, int off
 #pragma unroll
   for (int j2 = 0; j2 < 3; ++j2) base_a[j2] = lds0 + wave * 2560 + ((kq + j2) * 16 + n16) * 4;
   const unsigned base_b = lds0 + XS * 4 + (kq * 16 + n16) * 4;
-  const unsigned long long k5 = 0x40a0000040a00000ull, km3 = 0xc0400000c0400000ull;
+  const unsigned long long k15 = 0x3fc000003fc00000ull, km15 = 0xbfc00000bfc00000ull;       // 1.5, -1.5 on both halves
 
   if (q_begin < q_end) {
     q_next = q_begin; st_next = 0; dma_all();
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradArgs a, int off
         const float* pp = reinterpret_cast<const float*>(sb + (base_a[j >> 1] - lds0) + (j & 1) * 1280);
         d[j][0] = pp[0]; d[j][1] = pp[64];
       }
-      wino_bt_all(d, V0, tt, k5, km3);
+      wino_bt_all(d, V0, tt, k15, km15);
       const float* pb = reinterpret_cast<const float*>(sb + (base_b - lds0));
       D[0][0][0] = pb[0]; D[0][0][1] = pb[64]; D[0][5][0] = pb[256]; D[0][5][1] = pb[320];
       wino_a_piece<0>(D[0][0], D[0][5], D[0][1], D[0][2], D[0][3], D[0][4]); wino_a_piece<1>(D[0][0], D[0][5], D[0][1], D[0][2], D[0][3], D[0][4]);
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradArgs a, int off
 #pragma unroll
       for (int j2 = 0; j2 < 3; ++j2) { addr_a[j2] = base_a[j2] + st * STAGE_BYTES; addr_a_next[j2] = base_a[j2] + st1 * STAGE_BYTES; }
       const unsigned addr_b = base_b + st * STAGE_BYTES, addr_b_next = base_b + st1 * STAGE_BYTES;
-      WgPair<0, ABL>::template run<3, 2>(acc, V0, V1, d, tt, D, addr_b, addr_b_next, addr_a, addr_a_next, k5, km3, dma_piece);
-      WgPair<1, ABL>::template run<3, 2>(acc, V1, V0, d, tt, D, addr_b, addr_b_next, addr_a, addr_a_next, k5, km3, dma_piece);
+      WgPair<0, ABL>::template run<3, 2>(acc, V0, V1, d, tt, D, addr_b, addr_b_next, addr_a, addr_a_next, k15, km15, dma_piece);
+      WgPair<1, ABL>::template run<3, 2>(acc, V1, V0, d, tt, D, addr_b, addr_b_next, addr_a, addr_a_next, k15, km15, dma_piece);
       if constexpr (!(ABL & 4)) __syncthreads();
       st = st1;
     }
@@ -253,12 +253,13 @@ __global__ void wgrad_wino_reduce_kernel(const float* __restrict__ part, float* 
   for (int s = 0; s < splits; ++s)
 #pragma unroll
     for (int p = 0; p < 6; ++p) Q[p] += (double)part[((size_t)s * 6 + p) * cc + i];
-  const double e = (Q[1] + Q[2]) * (1.0 / 6.0), o = (Q[1] - Q[2]) * (1.0 / 6.0);
-  dw[i] = (float)(0.5 * Q[0] + e + Q[3] * (16.0 / 15.0) + Q[4] * (1.0 / 30.0));
+  // (the partial sums of points 0, 1, 2, 5 are half of the integer form's: wino_piece scales those rows by 1/2)
+  const double e = (Q[1] + Q[2]) * (1.0 / 3.0), o = (Q[1] - Q[2]) * (1.0 / 3.0);
+  dw[i] = (float)(Q[0] + e + Q[3] * (16.0 / 15.0) + Q[4] * (1.0 / 30.0));
   dw[cc + i] = (float)(o + Q[3] * (8.0 / 15.0) - Q[4] * (2.0 / 30.0));
   dw[2 * cc + i] = (float)(e + Q[3] * (4.0 / 15.0) + Q[4] * (4.0 / 30.0));
   dw[3 * cc + i] = (float)(o + Q[3] * (2.0 / 15.0) - Q[4] * (8.0 / 30.0));
-  dw[4 * cc + i] = (float)(e + Q[3] * (1.0 / 15.0) + Q[4] * (16.0 / 30.0) + 0.5 * Q[5]);
+  dw[4 * cc + i] = (float)(e + Q[3] * (1.0 / 15.0) + Q[4] * (16.0 / 30.0) + Q[5]);
 }
 
 bool wgrad_wino_supported(const WgradArgs& a) {
