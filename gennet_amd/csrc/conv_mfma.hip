@@ -676,7 +676,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
   if (i >= n4) return;
   const float4* p = reinterpret_cast<const float4*>(part);
   float4 s = p[i];
-  for (int k = 1; k < splits; ++k) {
+#pragma unroll 4
+  for (int k = 1; k < splits; ++k) {                 // (several splits' loads in flight: the pass is latency-bound; the order of the sum is unchanged)
     const float4 v = p[(size_t)k * stride4 + i];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }

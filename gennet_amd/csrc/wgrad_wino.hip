@@ -250,7 +250,8 @@ __global__ void wgrad_wino_reduce_kernel(const float* __restrict__ part, float* 
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cc) return;
   double Q[6] = {0, 0, 0, 0, 0, 0};
-  for (int s = 0; s < splits; ++s)
+#pragma unroll 4
+  for (int s = 0; s < splits; ++s)                  // (four splits' loads in flight: the pass is latency-bound, not byte-bound)
 #pragma unroll
     for (int p = 0; p < 6; ++p) Q[p] += (double)part[((size_t)s * 6 + p) * cc + i];
   // (the partial sums of points 0, 1, 2, 5 are half of the integer form's: wino_piece scales those rows by 1/2)

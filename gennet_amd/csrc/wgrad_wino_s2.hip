@@ -232,7 +232,8 @@ __global__ void wgrad_wino_s2_reduce_kernel(const float* __restrict__ part, floa
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cc) return;
   double Q[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int s = 0; s < splits; ++s)
+#pragma unroll 4
+  for (int s = 0; s < splits; ++s)                  // (four splits' loads in flight: the pass is latency-bound, not byte-bound)
 #pragma unroll
     for (int p = 0; p < 7; ++p) Q[p] += (double)part[((size_t)s * 7 + p) * cc + i];
   dw[i] = (float)(Q[0] + 0.5 * (Q[1] + Q[2]));
