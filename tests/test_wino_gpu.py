@@ -354,3 +354,27 @@ def test_random_shapes_agree_with_the_direct_kernels():
             worst = max(worst, e)
             assert e <= RTOL, (it, k, B, L, Cin, Cout, stride, padding, act, e)
     print('worst relative difference %.2e' % worst)
+
+
+@pytest.mark.parametrize("Cin,Cout,L,stride,B", [(64, 128, 2048, 1, 256), (128, 256, 2044, 1, 256), (512, 1024, 2048, 1, 32), (256, 512, 2040, 2, 128), (512, 1024, 1018, 2, 64)])
+def test_repeated_launches_are_bit_identical(Cin, Cout, L, stride, B):
+    """Determinism stress (round 5): forward, data gradient and weight gradient of one launch repeated eight times must agree bit for bit -- no atomics, fixed
+    split plans, fixed reduction orders; what this guards against is a RACE inside the hand-scheduled loops.  It was written after one was seen: with the
+    transform's vector instructions grouped in runs behind an MFMA (scripts/valu_rate.hip: 7 instead of 16 cycles each, +3.4 % on the step) the F(2,5) forward
+    kernel returned, once in a few launches, a wrong accumulator register PAIR in one wave -- invisible to every tolerance test, caught only by the bit-for-bit
+    predict comparison of tests/test_bench_sizes_gpu.py.  The grouping was taken out again (profiles/r05_winograd_gate.txt has the record)."""
+    from gennet_amd import ops
+    dev = torch.device('cuda:0')
+    x = ops.fill_normal((B, L, Cin), 0.0, 1.0, 3, 0, dev); w = ops.fill_normal((5, Cin, Cout), 0.0, 0.05, 4, 0, dev)
+    Lout, pl = ops.conv_geometry(L, 5, stride, 'valid')
+    dy = ops.fill_normal((B, Lout, Cout), 0.0, 1.0, 5, 0, dev)
+    wt = ops.conv1d_transpose_w(w)
+    with ops.conv_math('wino'):
+        first = None
+        for rep in range(8):
+            got = (ops.conv1d_fwd(x, w, None, stride, pl, Lout, 'relu'), ops.conv1d_dgrad(dy, wt, L, stride, pl), ops.conv1d_wgrad(x, dy, 5, stride, pl)[0])
+            if first is None:
+                first = got
+            else:
+                for name, a, b in zip(('forward', 'data gradient', 'weight gradient'), got, first):
+                    assert torch.equal(a, b), (name, rep, int((a != b).sum()), float((a - b).abs().max()))
