@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgs a, const u
     }
   }
   auto dma_one = [&](int i, int c, unsigned char* stage) {
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)c * step[i]), (lptr_t)(stage + dst[i]), 16, 0, 0);
+    gn_global_load_lds((gptr_t)(src[i] + (size_t)c * step[i]), (lptr_t)(stage + dst[i]), 16, 0, 0);
   };
 
   auto read_tap = [&](const unsigned char* sa, int j, bf16x8 (&av)[3][2], bf16x8 (&bv)[3]) {
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide_kernel(ConvArgs a, co
       d = pure_dst[i - 6 * NREG - 2];
     }
     // only the two instructions of the (partial) last segment can have lanes past the region
-    if (!MASKED || (i != 6 * NREG && i != 6 * NREG + 1) || voff >= 0) __builtin_amdgcn_global_load_lds((gptr_t)(base + voff), (lptr_t)(stage + d), 16, 0, 0);
+    if (!MASKED || (i != 6 * NREG && i != 6 * NREG + 1) || voff >= 0) gn_global_load_lds((gptr_t)(base + voff), (lptr_t)(stage + d), 16, 0, 0);
   };
   auto read_tap = [&](const unsigned char* sa, int j, bf16x8 (&av)[3][2], bf16x8 (&bv)[3][2], bool with_a = true) {
     if ((ABL & 1) && in_loop) return;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_wide3_kernel(ConvArgs a, c
   bool in_loop = false;
   auto dma_one = [&](int i, int c, unsigned char* stage) {
     if ((ABL & 2) && in_loop) return;
-    if (IS == 1 || live[i]) __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)c * step[i]), (lptr_t)(stage + dst[i]), 16, 0, 0);
+    if (IS == 1 || live[i]) gn_global_load_lds((gptr_t)(src[i] + (size_t)c * step[i]), (lptr_t)(stage + dst[i]), 16, 0, 0);
   };
   auto read_tap = [&](const unsigned char* sa, int j, bf16x8 (&av)[3][2], bf16x8 (&bv)[3][2]) {
     if ((ABL & 1) && in_loop) return;

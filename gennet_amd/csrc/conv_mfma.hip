@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_kernel(Co
     typedef __attribute__((address_space(3))) void* lptr_t;
     const float* src = wp[it] + (size_t)c0 * a.Cout;
     float* dst = stage + slab_floats + (it * NT + (tid & ~63)) * 4;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    gn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
   };
 
   const int n_chunks = (a.Cin + KC - 1) / KC;
@@ -348,12 +348,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_mfma_dma_kerne
 #pragma unroll
     for (int it = 0; it < S_ITEMS; ++it) {
       if (tid + it * NT < s_count)                        // lanes past the slab end stay masked off (EXEC): they would land in the weight tile
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stage + (it * NT + (tid & ~63)) * 4), 16, soff[it] + c0 * 4, 0, 0, 0);
+        gn_buffer_load_lds(xsrd, (lptr_t)(stage + (it * NT + (tid & ~63)) * 4), 16, soff[it] + c0 * 4, 0, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < W_ITEMS; ++it)
       if ((it + 1) * NT <= W_TOTAL || (tid & ~63) + it * NT < W_TOTAL)      // wave-uniform: whole waves issue or skip
-        __builtin_amdgcn_global_load_lds((gptr_t)(wp[it] + (size_t)c0 * a.Cout), (lptr_t)(stage + slab_floats + (it * NT + (tid & ~63)) * 4), 16, 0, 0);
+        gn_global_load_lds((gptr_t)(wp[it] + (size_t)c0 * a.Cout), (lptr_t)(stage + slab_floats + (it * NT + (tid & ~63)) * 4), 16, 0, 0);
   };
 
   const int n_chunks = a.Cin / KC;

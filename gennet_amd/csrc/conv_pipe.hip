@@ -359,11 +359,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * (MERGE == 2 ? 2 : 1), (64 
     float* stage = smem + decltype(stg)::value * BUF;
     if constexpr (k < S_ITEMS) {
       if ((k + 1) * NT <= S_COUNT || tid + k * NT < S_COUNT)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stage + (k * NT + wv64) * 4), 16, soff[k], c0_next * 4, 0, 0);
+        gn_buffer_load_lds(xsrd, (lptr_t)(stage + (k * NT + wv64) * 4), 16, soff[k], c0_next * 4, 0, 0);
     } else {
       constexpr int it = k - S_ITEMS;
       if ((it + 1) * NT <= W_TOTAL || wv64 + it * NT < W_TOTAL)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(stage + SLAB + (it * NT + wv64) * 4), 16, woff[it], c0_next * a.Cout * 4, 0, 0);
+        gn_buffer_load_lds(wsrd, (lptr_t)(stage + SLAB + (it * NT + wv64) * 4), 16, woff[it], c0_next * a.Cout * 4, 0, 0);
     }
   };
 

@@ -63,7 +63,7 @@ __global__ void wino_u_kernel(const float* __restrict__ w, float* __restrict__ U
 //   slot 8p     issues the two reads of the NEXT point's U values (after the last point: point 0 of the next chunk, whose stage has been complete since
 //               the previous barrier), slot 0 also this lane's six raw row fragments of the NEXT chunk; a counted lgkmcnt retires exactly what the slot
 //               consumes (LDS returns in order);
-//   slots >= 8  carry the 14 transform instructions of the next chunk, one every third slot; the staging pieces of chunk + 2 sit behind slots 1, 3, ...
+//   slots 12, 24, 36 carry the 14 transform instructions of the next chunk in three runs; the staging pieces of chunk + 2 sit behind slots 1, 3, ...
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wino_slot(f32x4& c, float a, float b) {
   asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "memory");
@@ -128,9 +128,13 @@ struct WinoChunk {
       else if constexpr (I % 8 == 0) wino_slot_rb<(P + 1) * 2048, 2>(acc[P][0], av, bv, bn[0], bn[1], addr_b);
       else wino_slot(acc[P][CT], av, bv);
       if constexpr ((I & 1) && (I >> 1) < NPIECES) dma(std::integral_constant<int, (I >> 1)>{});
-      if constexpr (!(ABL & 2) && I >= 8) {
-        constexpr int lo = (I - 8) * kWinoPieces / 40, hi = (I - 7) * kWinoPieces / 40;
-        if constexpr (lo < hi) wino_piece<lo>(d, vn, t, k15, km15);
+      if constexpr (!(ABL & 2)) {
+        // the 14 transform instructions in THREE runs (behind slots 12, 24, 36), not one every third slot: a vector instruction alone between two MFMAs of a wave
+        // costs the switch as well as its own issue (scripts/valu_rate.hip: 14.5-16 cycles alone, 7.4 in a run of three or more; one, two or three runs
+        // measure the same).  (This schedule is what exposed the LDS-DMA's write into v[0:3], common.h: GN_LDS_DMA_CLOBBER.)
+        if constexpr (I == 12) wino_run<0, 5>(d, vn, t, k15, km15);
+        if constexpr (I == 24) wino_run<5, 10>(d, vn, t, k15, km15);
+        if constexpr (I == 36) wino_run<10, kWinoPieces>(d, vn, t, k15, km15);
       }
       run<NPIECES, I + 1>(acc, v, vn, d, t, B, addr_b, addr_b_next, addr_a, k15, km15, dma);
     }
@@ -214,11 +218,11 @@ __global__ __launch_bounds__(64 * WAVES_M, (WAVES_M > 4 ? 1 : 2)) void conv_wino
     float* stg = smem + st_next * BUF;
     if constexpr (k < S_ITEMS) {
       if ((k + 1) * NT <= S_COUNT || tid + k * NT < S_COUNT)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stg + (k * NT + wv64) * 4), 16, soff[k], c_next * KC * 4, 0, 0);
+        gn_buffer_load_lds(xsrd, (lptr_t)(stg + (k * NT + wv64) * 4), 16, soff[k], c_next * KC * 4, 0, 0);
     } else {
       constexpr int it = k - S_ITEMS;
       if ((it + 1) * NT <= W_TOTAL || wv64 + it * NT < W_TOTAL)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(stg + SLAB + (it * NT + wv64) * 4), 16, (n_tile * UT + (tid + it * NT) * 4) * 4,
+        gn_buffer_load_lds(wsrd, (lptr_t)(stg + SLAB + (it * NT + wv64) * 4), 16, (n_tile * UT + (tid + it * NT) * 4) * 4,
                                                  c_next * w_chunk_bytes, 0, 0);
     }
   };

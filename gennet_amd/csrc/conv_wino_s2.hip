@@ -67,6 +67,13 @@ __device__ __forceinline__ void s2_piece(const f32x2 (&d)[NR], f32x2 (&v)[7]) {
   else if constexpr (K == 5) GN_PK_COPY(v[5], d[B1]);
   else GN_PK_SUB(v[6], d[B2], d[B1]);
 }
+template <int KIND, int SB, int NR, int K0, int K1>
+__device__ __forceinline__ void s2_run(const f32x2 (&d)[NR], f32x2 (&v)[7]) {
+  if constexpr (K0 < K1) {
+    s2_piece<KIND, SB, K0, NR>(d, v);
+    s2_run<KIND, SB, NR, K0 + 1, K1>(d, v);
+  }
+}
 template <int KIND, int SB, int NR, int K = 0>
 __device__ __forceinline__ void s2_bt_all(const f32x2 (&d)[NR], f32x2 (&v)[7]) {
   if constexpr (K < 7) {
@@ -171,7 +178,9 @@ struct S2Chunk {
       else if constexpr (I % 8 == 0) s2_slot_rb<(P + 1) * 2048, 2>(acc[P][0], av, bv, bn[0], bn[1], addr_b);
       else s2_slot(acc[P][CT], av, bv);
       if constexpr ((I & 1) && (I >> 1) < NPIECES) dma(std::integral_constant<int, (I >> 1)>{});
-      if constexpr (I >= 16 && (I - 16) % 5 == 0 && (I - 16) / 5 < 7) s2_piece<KIND, SB, (I - 16) / 5, NR>(d, vn);      // slots 16, 21, ..., 46
+      // the seven transform instructions in two runs (a vector instruction alone between two MFMAs of a wave costs 16 cycles, in a run 7: scripts/valu_rate.hip)
+      if constexpr (I == 20) s2_run<KIND, SB, NR, 0, 4>(d, vn);
+      if constexpr (I == 36) s2_run<KIND, SB, NR, 4, 7>(d, vn);
       run<NPIECES, I + 1>(acc, v, vn, d, B, addr_b, addr_b_next, addr_a, dma);
     }
   }
@@ -249,11 +258,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_s2_kernel(ConvArgs a, const 
     float* stg = smem + st_next * BUF;
     if constexpr (k < S_ITEMS) {
       if ((k + 1) * NT <= S_COUNT || tid + k * NT < S_COUNT)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(stg + (k * NT + wv64) * 4), 16, soff[k], c_next * KC * 4, 0, 0);
+        gn_buffer_load_lds(xsrd, (lptr_t)(stg + (k * NT + wv64) * 4), 16, soff[k], c_next * KC * 4, 0, 0);
     } else {
       constexpr int it = k - S_ITEMS;
       if ((it + 1) * NT <= W_TOTAL || wv64 + it * NT < W_TOTAL)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(stg + SLAB + (it * NT + wv64) * 4), 16, (n_tile * UT + (tid + it * NT) * 4) * 4,
+        gn_buffer_load_lds(wsrd, (lptr_t)(stg + SLAB + (it * NT + wv64) * 4), 16, (n_tile * UT + (tid + it * NT) * 4) * 4,
                                                  c_next * w_chunk_bytes, 0, 0);
     }
   };

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512 / IB, 1) void wgrad_bf16x3_kernel(WgradArgs a, 
 #pragma unroll
     for (int i = 0; i < Q_WAVE; ++i) {
       const size_t xb = ((size_t)(b * IS + max(spar[i], 0)) * cpb + kc) * a.Cin * 80;
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcp[i] + (spar[i] >= 0 ? xb : yb)), (lptr_t)(stage + dst[i]), 16, 0, 0);
+      gn_global_load_lds((gptr_t)(srcp[i] + (spar[i] >= 0 ? xb : yb)), (lptr_t)(stage + dst[i]), 16, 0, 0);
     }
   };
 

@@ -191,10 +191,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_N, 2) void wgrad_pipe_kernel(W
     float* stage = smem + decltype(stg)::value * BUF;
     if constexpr (k < S_ITEMS) {
       if ((k + 1) * NT <= S_COUNT || tid + k * NT < S_COUNT)            // x rows before 0 give a negative (= huge unsigned) offset: out of range -> 0
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lptr_t)(stage + (k * NT + wv64) * 4), 16, soff[k] + xrow, 0, 0, 0);
+        gn_buffer_load_lds(xs, (lptr_t)(stage + (k * NT + wv64) * 4), 16, soff[k] + xrow, 0, 0, 0);
     } else {
       constexpr int it = k - S_ITEMS;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ds, (lptr_t)(stage + SLAB + (it * NT + wv64) * 4), 16, doff[it] + drow, 0, 0, 0);
+      gn_buffer_load_lds(ds, (lptr_t)(stage + SLAB + (it * NT + wv64) * 4), 16, doff[it] + drow, 0, 0, 0);
     }
   };
 

@@ -100,11 +100,15 @@ struct WgPair {
         if constexpr (CT < (H == 0 ? NP0 : NP1)) dma(std::integral_constant<int, K>{});
       }
       if constexpr (!(ABL & 2)) {
-        if constexpr (G >= 5 && G <= 8) wino_a_piece<G - 5>(dn[0], dn[5], dn[1], dn[2], dn[3], dn[4]);
-        if constexpr (CT >= 1 && (G <= 3 || G >= 9)) {
-          constexpr int K = (CT - 1) * 6 + (G <= 3 ? G - 1 : G - 6);            // G = 1, 2, 3, 9, 10, 11 -> 0 .. 5
-          if constexpr (G >= 1 && K < kWinoPieces) wino_piece<K>(d, vn, t, k15, km15);
+        // vector instructions in RUNS (alone between two MFMAs of a wave one costs 16 cycles, in a run 7: scripts/valu_rate.hip): the dy transform's four
+        // behind slot 5 of every column tile, the next x transform as 5 + 5 + 4 behind slot 9 of column tiles 1, 2, 3
+        if constexpr (G == 5) {
+          wino_a_piece<0>(dn[0], dn[5], dn[1], dn[2], dn[3], dn[4]); wino_a_piece<1>(dn[0], dn[5], dn[1], dn[2], dn[3], dn[4]);
+          wino_a_piece<2>(dn[0], dn[5], dn[1], dn[2], dn[3], dn[4]); wino_a_piece<3>(dn[0], dn[5], dn[1], dn[2], dn[3], dn[4]);
         }
+        if constexpr (CT == 1 && G == 9) wino_run<0, 5>(d, vn, t, k15, km15);
+        if constexpr (CT == 2 && G == 9) wino_run<5, 10>(d, vn, t, k15, km15);
+        if constexpr (CT == 3 && G == 9) wino_run<10, kWinoPieces>(d, vn, t, k15, km15);
       }
       run<NP0, NP1, I + 1>(acc, v, vn, d, t, D, addr_b, addr_b_next, addr_a, addr_a_next, k15, km15, dma);
     }
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradArgs a, int off
         // shifted descriptor base would turn into out-of-range = zero)
         const uintptr_t p = (uintptr_t)(a.x + (size_t)b * a.Lin * a.Cin);
         const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, xbytes, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(stg + (k * NT + wv64) * 4), 16, xoff[k] + cb * 32 * a.Cin * 4, 0, 0, 0);
+        gn_buffer_load_lds(srd, (lptr_t)(stg + (k * NT + wv64) * 4), 16, xoff[k] + cb * 32 * a.Cin * 4, 0, 0, 0);
       }
     } else {
       constexpr int it = k - X_ITEMS;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradArgs a, int off
       const int cbo = cb * 32 * a.Cout * 4;
       const uintptr_t p = (uintptr_t)(a.dy + (size_t)b * a.M * a.Cout) + (uintptr_t)(unsigned)cbo;
       const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, ybytes - cbo, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(stg + XS + (it * NT + wv64) * 4), 16, yoff[it], 0, 0, 0);
+      gn_buffer_load_lds(srd, (lptr_t)(stg + XS + (it * NT + wv64) * 4), 16, yoff[it], 0, 0, 0);
     }
   };
   auto dma_all = [&]() {

@@ -98,12 +98,14 @@ struct Wg2Chunk {
       } else if constexpr (G == 4) wg2_slot_w<(I == 4 ? 7 : 0)>(acc[P][CT], av, bv, dn[0], dn[1]);
       else wg2_slot(acc[P][CT], av, bv);
       if constexpr (G == 4 && CT < NPIECES) dma(std::integral_constant<int, CT>{});
-      if constexpr (G == 5) GN_PK_ADD2(dn[2], dn[0], dn[1]);
-      if constexpr (G == 6) GN_PK_SUB(dn[3], dn[0], dn[1]);
-      if constexpr (CT >= 1 && (G == 8 || G == 10 || G == 12)) {
-        constexpr int K = (CT - 1) * 3 + (G - 8) / 2;                          // 9 positions for the 7 instructions of the next chunk's x transform
-        if constexpr (K < 7) wg2_x_piece<K>(d, vn);
+      // vector instructions in RUNS (alone between two MFMAs of a wave one costs 16 cycles, in a run 7: scripts/valu_rate.hip): the dy pair's two behind
+      // slot 5 of every column tile, the next chunk's x transform as 4 + 3 behind slot 9 of column tiles 1 and 2
+      if constexpr (G == 5) {
+        GN_PK_ADD2(dn[2], dn[0], dn[1]);
+        GN_PK_SUB(dn[3], dn[0], dn[1]);
       }
+      if constexpr (CT == 1 && G == 9) { wg2_x_piece<0>(d, vn); wg2_x_piece<1>(d, vn); wg2_x_piece<2>(d, vn); wg2_x_piece<3>(d, vn); }
+      if constexpr (CT == 2 && G == 9) { wg2_x_piece<4>(d, vn); wg2_x_piece<5>(d, vn); wg2_x_piece<6>(d, vn); }
       run<NPIECES, I + 1>(acc, v, vn, d, D, addr_b, addr_b_next, addr_a_next, dma);
     }
   }
@@ -156,13 +158,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_s2_kernel(WgradArgs a, int 
     if constexpr (k < X_ITEMS) {
       const uintptr_t p = (uintptr_t)(a.x + (size_t)b * a.Lin * a.Cin);
       const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, xbytes, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(stg + (k * NT + wv64) * 4), 16, xoff[k] + cb * 32 * a.Cin * 4, 0, 0, 0);
+      gn_buffer_load_lds(srd, (lptr_t)(stg + (k * NT + wv64) * 4), 16, xoff[k] + cb * 32 * a.Cin * 4, 0, 0, 0);
     } else {
       // dy: the chunk's row offset in the descriptor's base and size, as in wgrad_wino.hip (x cannot: its halo rows sit at negative offsets)
       const int cbo = cb * 16 * a.Cout * 4;
       const uintptr_t p = (uintptr_t)(a.dy + (size_t)b * a.M * a.Cout) + (uintptr_t)(unsigned)cbo;
       const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, ybytes - cbo, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(stg + XS + wv64 * 4), 16, yoff, 0, 0, 0);
+      gn_buffer_load_lds(srd, (lptr_t)(stg + XS + wv64 * 4), 16, yoff, 0, 0, 0);
     }
   };
   auto dma_all = [&]() {

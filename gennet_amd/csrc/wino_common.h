@@ -47,6 +47,14 @@ __device__ __forceinline__ void wino_piece(const f32x2 (&d)[6], f32x2 (&v)[6], W
   else if constexpr (K == 12) GN_PK_ADD_SELF(v[1], v[2]);                       // s + t
   else if constexpr (K == 13) GN_PK_FMA_SELF(v[2], "-2.0", v[1]);               // (s + t) - 2 t = s - t
 }
+// pieces K0 .. K1-1 back to back
+template <int K0, int K1>
+__device__ __forceinline__ void wino_run(const f32x2 (&d)[6], f32x2 (&v)[6], WinoT& t, unsigned long long k15, unsigned long long km15) {
+  if constexpr (K0 < K1) {
+    wino_piece<K0>(d, v, t, k15, km15);
+    wino_run<K0 + 1, K1>(d, v, t, k15, km15);
+  }
+}
 template <int K = 0>
 __device__ __forceinline__ void wino_bt_all(const f32x2 (&d)[6], f32x2 (&v)[6], WinoT& t, unsigned long long k15, unsigned long long km15) {
   if constexpr (K < kWinoPieces) {
