@@ -360,9 +360,11 @@ def test_random_shapes_agree_with_the_direct_kernels():
 def test_repeated_launches_are_bit_identical(Cin, Cout, L, stride, B):
     """Determinism stress (round 5): forward, data gradient and weight gradient of one launch repeated eight times must agree bit for bit -- no atomics, fixed
     split plans, fixed reduction orders; what this guards against is a RACE inside the hand-scheduled loops.  It was written after one was seen: with the
-    transform's vector instructions grouped in runs behind an MFMA (scripts/valu_rate.hip: 7 instead of 16 cycles each, +3.4 % on the step) the F(2,5) forward
-    kernel returned, once in a few launches, a wrong accumulator register PAIR in one wave -- invisible to every tolerance test, caught only by the bit-for-bit
-    predict comparison of tests/test_bench_sizes_gpu.py.  The grouping was taken out again (profiles/r05_winograd_gate.txt has the record)."""
+    transform's vector instructions grouped in runs behind an MFMA (scripts/valu_rate.hip: 7 instead of 16 cycles each) the F(2,5) forward kernel returned, once
+    in a few launches, a wrong accumulator register PAIR in one wave -- invisible to every tolerance test, caught only by the bit-for-bit predict comparison of
+    tests/test_bench_sizes_gpu.py.  Cause: LDS-DMA (buffer_load ... lds) at times writes into v[0:3], its unused VDATA field; the library now declares that clobber
+    at every LDS-DMA statement (csrc/common.h, gn_buffer_load_lds) and the runs are in (profiles/r05_winograd_gate.txt has the record; soak:
+    tests/tools/determinism_soak.py)."""
     from gennet_amd import ops
     dev = torch.device('cuda:0')
     x = ops.fill_normal((B, L, Cin), 0.0, 1.0, 3, 0, dev); w = ops.fill_normal((5, Cin, Cout), 0.0, 0.05, 4, 0, dev)
